@@ -1,0 +1,183 @@
+// C ABI: error plumbing + YAML problem factory entry points (host only).  Solver entry points live in
+// empc_solver.hip.  See include/empc.h for the reference interfaces each function replaces.
+#include <cstring>
+#include <exception>
+#include <string>
+
+#include "../host/eagle_mpc.hpp"
+#include "empc_internal.hpp"
+
+using namespace eagle_mpc;
+
+namespace empc {
+static thread_local std::string g_last_error;
+void set_last_error(const std::string& msg) { g_last_error = msg; }
+}  // namespace empc
+
+struct EmpcTrajectory {
+  std::shared_ptr<Trajectory> t;
+};
+struct EmpcProblem {
+  std::shared_ptr<ShootingProblem> p;
+};
+
+#define EMPC_TRY try {
+#define EMPC_CATCH(ret)                       \
+  }                                           \
+  catch (const std::exception& e) {           \
+    empc::set_last_error(e.what());           \
+    return ret;                               \
+  }                                           \
+  catch (...) {                               \
+    empc::set_last_error("unknown exception"); \
+    return ret;                               \
+  }
+
+extern "C" {
+
+const char* empc_last_error(void) { return empc::g_last_error.c_str(); }
+const char* empc_version(void) { return "eagle-mpc_amd 0.1 (gfx950)"; }
+
+int empc_set_data_dirs(const char* yaml_dir, const char* robot_data_dir) {
+  EMPC_TRY
+  if (yaml_dir) set_yaml_dir(yaml_dir);
+  if (robot_data_dir) set_robot_data_dir(robot_data_dir);
+  return EMPC_OK;
+  EMPC_CATCH(EMPC_ERR_INVALID)
+}
+
+EmpcTrajectory* empc_trajectory_create(const char* yaml_path) {
+  EMPC_TRY
+  if (!yaml_path) throw std::invalid_argument("yaml_path is NULL");
+  auto t = Trajectory::create();
+  t->autoSetup(yaml_path);
+  return new EmpcTrajectory{t};
+  EMPC_CATCH(nullptr)
+}
+void empc_trajectory_destroy(EmpcTrajectory* t) { delete t; }
+
+int empc_trajectory_dims(const EmpcTrajectory* t, int* nx, int* ndx, int* nu, int* n_stages, int* has_contact,
+                         int* duration_ms) {
+  EMPC_TRY
+  if (!t) throw std::invalid_argument("trajectory is NULL");
+  if (nx) *nx = (int)t->t->get_nx();
+  if (ndx) *ndx = (int)t->t->get_ndx();
+  if (nu) *nu = (int)t->t->get_nu();
+  if (n_stages) *n_stages = (int)t->t->get_stages().size();
+  if (has_contact) *has_contact = t->t->get_has_contact() ? 1 : 0;
+  if (duration_ms) *duration_ms = (int)t->t->get_duration();
+  return EMPC_OK;
+  EMPC_CATCH(EMPC_ERR_INVALID)
+}
+
+int empc_trajectory_stage_info(const EmpcTrajectory* t, int stage, char* name, int name_len, int* duration_ms,
+                               int* is_transition, int* n_costs, int* n_contacts) {
+  EMPC_TRY
+  if (!t) throw std::invalid_argument("trajectory is NULL");
+  const auto& st = t->t->get_stages().at((size_t)stage);
+  if (name && name_len > 0) {
+    std::strncpy(name, st->get_name().c_str(), (size_t)name_len - 1);
+    name[name_len - 1] = 0;
+  }
+  if (duration_ms) *duration_ms = (int)st->get_duration();
+  if (is_transition) *is_transition = st->get_is_transition() ? 1 : 0;
+  if (n_costs) *n_costs = (int)st->get_costs()->get_costs().size();
+  if (n_contacts) *n_contacts = (int)st->get_contacts()->get_contacts().size();
+  return EMPC_OK;
+  EMPC_CATCH(EMPC_ERR_INVALID)
+}
+
+int empc_trajectory_get_initial_state(const EmpcTrajectory* t, double* x0) {
+  EMPC_TRY
+  if (!t || !x0) throw std::invalid_argument("NULL argument");
+  const auto& x = t->t->get_initial_state();
+  std::memcpy(x0, x.data(), sizeof(double) * x.size());
+  return EMPC_OK;
+  EMPC_CATCH(EMPC_ERR_INVALID)
+}
+int empc_trajectory_set_initial_state(EmpcTrajectory* t, const double* x0) {
+  EMPC_TRY
+  if (!t || !x0) throw std::invalid_argument("NULL argument");
+  t->t->set_initial_state(VectorXd(x0, x0 + t->t->get_nx()));
+  return EMPC_OK;
+  EMPC_CATCH(EMPC_ERR_INVALID)
+}
+int empc_trajectory_get_platform(const EmpcTrajectory* t, double* tau_f, double* u_lb, double* u_ub, int* n_rotors) {
+  EMPC_TRY
+  if (!t) throw std::invalid_argument("trajectory is NULL");
+  const auto& pp = t->t->get_platform_params();
+  if (n_rotors) *n_rotors = (int)pp->n_rotors_;
+  if (tau_f) std::memcpy(tau_f, pp->tau_f_.data.data(), sizeof(double) * pp->tau_f_.data.size());
+  if (u_lb) std::memcpy(u_lb, pp->u_lb.data(), sizeof(double) * pp->u_lb.size());
+  if (u_ub) std::memcpy(u_ub, pp->u_ub.data(), sizeof(double) * pp->u_ub.size());
+  return EMPC_OK;
+  EMPC_CATCH(EMPC_ERR_INVALID)
+}
+
+EmpcProblem* empc_trajectory_create_problem(const EmpcTrajectory* t, int dt_ms, int squash, const char* integration_method) {
+  EMPC_TRY
+  if (!t) throw std::invalid_argument("trajectory is NULL");
+  std::shared_ptr<ShootingProblem> p;
+  if (dt_ms <= 0)
+    p = t->t->createProblem();
+  else
+    p = t->t->createProblem((std::size_t)dt_ms, squash != 0,
+                            integration_method ? integration_method : "IntegratedActionModelEuler");
+  return new EmpcProblem{p};
+  EMPC_CATCH(nullptr)
+}
+void empc_problem_destroy(EmpcProblem* p) { delete p; }
+const EmpcProblemDesc* empc_problem_desc(EmpcProblem* p) {
+  EMPC_TRY
+  if (!p) throw std::invalid_argument("problem is NULL");
+  return &p->p->desc();
+  EMPC_CATCH(nullptr)
+}
+int empc_problem_set_x0(EmpcProblem* p, const double* x0) {
+  EMPC_TRY
+  if (!p || !x0) throw std::invalid_argument("NULL argument");
+  p->p->set_x0(VectorXd(x0, x0 + p->p->get_nx()));
+  return EMPC_OK;
+  EMPC_CATCH(EMPC_ERR_INVALID)
+}
+int empc_trajectory_get_param(const EmpcTrajectory* t, const char* key, char* value, int value_len) {
+  EMPC_TRY
+  if (!t || !key) throw std::invalid_argument("NULL argument");
+  const std::string v = t->t->get_params_server()->getParam<std::string>(key);
+  if (value && value_len > 0) {
+    std::strncpy(value, v.c_str(), (size_t)value_len - 1);
+    value[value_len - 1] = 0;
+  }
+  return (int)v.size();
+  EMPC_CATCH(EMPC_ERR_INVALID)
+}
+
+void empc_solver_params_default(EmpcSolverParams* p) {
+  if (!p) return;
+  std::memset(p, 0, sizeof(*p));
+  p->smooth_init = 0.1;        // src/sbfddp.cpp:9
+  p->smooth_mult = 0.5;        // :10
+  p->barrier_weight = 1e-3;    // :11
+  p->convergence_init = 1e-2;  // :12
+  p->convergence_stop = 1e-3;  // :13
+  p->convergence_mult = 1e-1;  // :14
+  p->reg_init = 1e-9;          // :16
+  p->th_acceptnegstep = 2;     // :17
+  p->th_stop_gaps = 1.0;       // :27
+  p->th_grad = 1e-12;          // crocoddyl::SolverDDP defaults
+  p->th_acceptstep = 0.1;
+  p->th_stepdec = 0.5;
+  p->th_stepinc = 0.01;
+  p->reg_incfactor = 10;
+  p->reg_decfactor = 10;
+  p->reg_min = 1e-9;
+  p->reg_max = 1e9;
+  p->th_gaptol = 1e-16;
+  p->n_alphas = 10;
+  p->stop_criteria = EMPC_STOP_COST_REDUCTION;
+  p->gap_norm = EMPC_GAP_L1;
+  p->terminal_dt_scaling = 1;
+  p->smoothsat_power = 2;
+}
+
+}  // extern "C"

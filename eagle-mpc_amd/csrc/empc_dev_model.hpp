@@ -1,0 +1,712 @@
+// empc_dev_model.hpp -- device-side problem description and the per-lane rigid-body / cost routines.
+//
+// Replaces, for the hot path, what the reference obtains from Crocoddyl + Pinocchio:
+//   DifferentialActionModel{Free,Contact}FwdDynamics::calc   (src/factory/diff-action.cpp:31,34)
+//   IntegratedActionModelEuler::calc                          (src/factory/int-action.cpp:26)
+//   ActuationSquashingModel / SquashingModelSmoothSat         (src/trajectory.cpp:48-52)
+//   CostModelSum of CostModelResidual(...)                    (src/factory/cost.cpp:38-168)
+// Semantics: SURVEY.md Appendix A.3-A.7.  The kinematic tree must be a serial chain (body i's parent is body i-1),
+// which holds for every multicopter + arm model the reference ships problems for.
+#pragma once
+#include "../../include/empc_types.h"
+#include "empc_dev_math.hpp"
+
+namespace empc {
+
+// Device copies are the host structs themselves (plain data); only the cost-set table and knot table are separate
+// device arrays.  Costs carry their names, unused on the device.
+struct DevProblem {
+  EmpcModelDesc model;
+  int nx, ndx, nu, n_rotors, T, n_sets, has_contact, use_squash;
+  double dt;
+  double tau_f[6 * EMPC_MAX_ROTORS];
+  double u_lb[EMPC_MAX_NU];
+  double u_ub[EMPC_MAX_NU];
+  EmpcSolverParams prm;
+};
+
+template <int NB_, int NROT_>
+struct Dims {
+  static constexpr int NB = NB_;
+  static constexpr int NROT = NROT_;
+  static constexpr int NJ = NB_ - 1;
+  static constexpr int NV = 6 + NJ;
+  static constexpr int NQ = 7 + NJ;
+  static constexpr int NX = NQ + NV;
+  static constexpr int NDX = 2 * NV;
+  static constexpr int NU = NROT_ + NJ;
+  static constexpr int NTRI = NV * (NV + 1) / 2;
+  // tape record of one node (doubles); layout shared by linearize (writer) and backward (reader)
+  static constexpr int OFF_FX = 0;                       // ndx x ndx row-major
+  static constexpr int OFF_FU = OFF_FX + NDX * NDX;      // ndx x nu
+  static constexpr int OFF_LXX = OFF_FU + NDX * NU;      // ndx x ndx
+  static constexpr int OFF_LXU = OFF_LXX + NDX * NDX;    // ndx x nu
+  static constexpr int OFF_LUU = OFF_LXU + NDX * NU;     // nu x nu
+  static constexpr int OFF_LX = OFF_LUU + NU * NU;       // ndx
+  static constexpr int OFF_LU = OFF_LX + NDX;            // nu
+  static constexpr int OFF_GAP = OFF_LU + NU;            // ndx   fs[t]
+  static constexpr int OFF_COST = OFF_GAP + NDX;         // 1
+  static constexpr int REC_RAW = OFF_COST + 1;
+  static constexpr int REC = (REC_RAW + 15) / 16 * 16;   // padded to 128 B
+};
+
+// Rodrigues rotation about a unit axis from cos/sin
+template <class S>
+EMPC_HD void axis_rot(const double* ax, const S& c, const S& s, S* R) {
+  S omc = 1.0 - c;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) R[3 * i + j] = (ax[i] * ax[j]) * omc;
+  R[0] += c;
+  R[4] += c;
+  R[8] += c;
+  R[1] -= ax[2] * s;
+  R[2] += ax[1] * s;
+  R[3] += ax[2] * s;
+  R[5] -= ax[0] * s;
+  R[6] -= ax[1] * s;
+  R[7] += ax[0] * s;
+}
+
+// spatial inertia of body b applied to a motion (body frame): [m (v + w x c); Ic w + c x m (v + w x c)]
+template <class S>
+EMPC_HD void inertia_apply(const EmpcModelDesc& m, int b, const S* mot, S* out) {
+  S wxc[3], lin[3], Iw[3], cxl[3];
+  cross3<S>(mot + 3, m.com[b], wxc);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) lin[i] = m.mass[b] * (mot[i] + wxc[i]);
+  matvec3<S>(m.inertia[b], mot + 3, Iw);
+  cross3<S>(m.com[b], lin, cxl);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    out[i] = lin[i];
+    out[3 + i] = Iw[i] + cxl[i];
+  }
+}
+
+// Operational-frame capture: placement and LOCAL velocity / acceleration of up to NCAP frames, filled during the
+// forward recursion when the recursion reaches the frame's body.
+constexpr int NCAP = 3;
+template <class S>
+struct FrameCap {
+  S R[9], p[3];  // world placement
+  S v[6];        // LOCAL spatial velocity
+  S a[6];        // LOCAL spatial acceleration (of the recursion's a, i.e. including the gravity offset if enabled)
+};
+template <class S>
+EMPC_HD void frame_capture(const EmpcModelDesc& m, int f, const S* Rb, const S* pb, const S* vb, const S* ab,
+                           FrameCap<S>& fk) {
+  matmul3<S>(Rb, m.frame_R[f], fk.R);
+  S Rp[3];
+  matvec3<S>(Rb, m.frame_p[f], Rp);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) fk.p[i] = pb[i] + Rp[i];
+  S wxr[3], tmp[3];
+  cross3<S>(vb + 3, m.frame_p[f], wxr);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) tmp[i] = vb[i] + wxr[i];
+  matTvec3<S>(m.frame_R[f], tmp, fk.v);
+  matTvec3<S>(m.frame_R[f], vb + 3, fk.v + 3);
+  cross3<S>(ab + 3, m.frame_p[f], wxr);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) tmp[i] = ab[i] + wxr[i];
+  matTvec3<S>(m.frame_R[f], tmp, fk.a);
+  matTvec3<S>(m.frame_R[f], ab + 3, fk.a + 3);
+}
+
+// Recursive Newton-Euler on a serial chain, body-frame Featherstone form, generic in the scalar (double or D1).
+//   R0,p0     base placement; cs,sn cos/sin of the joint angles; v,a generalized velocity / acceleration
+//   gravity   fold -g into the base acceleration
+//   fext_b/fext: optional external spatial force (body frame) acting on body fext_b
+//   cap_frames[ncap]: operational frames to capture (indices into the model's frame table)
+// Register discipline: only the per-body forces survive the forward sweep; joint rotations are rebuilt from cs/sn
+// in the backward sweep.
+template <int NB, class S>
+EMPC_HD void rnea_chain(const EmpcModelDesc& m, const S* R0, const S* p0, const S* cs, const S* sn, const S* v,
+                        const S* a, bool gravity, int fext_b, const S* fext, S* tau, int ncap, const int* cap_frames,
+                        FrameCap<S>* caps) {
+  S f[NB][6];
+  S Rw[9], pw[3], vb[6], ab[6];  // rolling: world placement, body-frame velocity / acceleration of the current body
+#pragma unroll
+  for (int i = 0; i < 9; ++i) Rw[i] = R0[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) pw[i] = p0[i];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    vb[i] = v[i];
+    ab[i] = a[i];
+  }
+  if (gravity) {
+    double ng[3] = {-m.gravity[0], -m.gravity[1], -m.gravity[2]};
+    S gl[3];
+    matTvec3<S>(R0, ng, gl);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) ab[i] += gl[i];
+  }
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    if (b > 0) {
+      S Rj[9], XR[9];
+      axis_rot<S>(m.axis[b], cs[b - 1], sn[b - 1], Rj);
+      matmul3<S>(m.jplace_R[b], Rj, XR);
+      const double* r = m.jplace_p[b];
+      S Rr[3], Rn[9];
+      matvec3<S>(Rw, r, Rr);
+      matmul3<S>(Rw, XR, Rn);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) Rw[i] = Rn[i];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) pw[i] += Rr[i];
+      // v_c = E (v_p + w_p x r), w_c = E w_p, E = XR^T ; + S qd
+      S wxr[3], tmp[3], vn[6], an[6];
+      cross3<S>(vb + 3, r, wxr);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) tmp[i] = vb[i] + wxr[i];
+      matTvec3<S>(XR, tmp, vn);
+      matTvec3<S>(XR, vb + 3, vn + 3);
+      const S& qd = v[6 + b - 1];
+      S sv[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) sv[i] = m.axis[b][i] * qd;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) vn[3 + i] += sv[i];
+      cross3<S>(ab + 3, r, wxr);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) tmp[i] = ab[i] + wxr[i];
+      matTvec3<S>(XR, tmp, an);
+      matTvec3<S>(XR, ab + 3, an + 3);
+      const S& qdd = a[6 + b - 1];
+      S c1[3], c2[3];
+      cross3<S>(vn, sv, c1);
+      cross3<S>(vn + 3, sv, c2);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        an[i] += c1[i];
+        an[3 + i] += m.axis[b][i] * qdd + c2[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        vb[i] = vn[i];
+        ab[i] = an[i];
+      }
+    }
+    // frame captures on this body
+    for (int c = 0; c < ncap; ++c)
+      if (m.frame_body[cap_frames[c]] == b) frame_capture<S>(m, cap_frames[c], Rw, pw, vb, ab, caps[c]);
+    // f_b = I a + v x* (I v) - fext
+    S Ia[6], Iv[6], c1[3], c2[3], c3[3];
+    inertia_apply<S>(m, b, ab, Ia);
+    inertia_apply<S>(m, b, vb, Iv);
+    cross3<S>(vb + 3, Iv, c1);
+    cross3<S>(vb + 3, Iv + 3, c2);
+    cross3<S>(vb, Iv, c3);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      f[b][i] = Ia[i] + c1[i];
+      f[b][3 + i] = Ia[3 + i] + c2[i] + c3[i];
+    }
+    if (fext != nullptr && fext_b == b) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) f[b][i] -= fext[i];
+    }
+  }
+#pragma unroll
+  for (int b = NB - 1; b >= 1; --b) {
+    tau[6 + b - 1] = dot3<S>(m.axis[b], f[b] + 3);
+    S Rj[9], XR[9];
+    axis_rot<S>(m.axis[b], cs[b - 1], sn[b - 1], Rj);
+    matmul3<S>(m.jplace_R[b], Rj, XR);
+    S fl[3], fn[3], rxf[3];
+    matvec3<S>(XR, f[b], fl);
+    matvec3<S>(XR, f[b] + 3, fn);
+    cross3<S>(m.jplace_p[b], fl, rxf);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      f[b - 1][i] += fl[i];
+      f[b - 1][3 + i] += fn[i] + rxf[i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) tau[i] = f[0][i];
+}
+
+// Composite-rigid-body algorithm on a serial chain; output: packed lower triangle of M (idx(i,j) = i(i+1)/2 + j).
+// Composite inertias are carried as (mass, COM, rotational inertia about the COM) in body axes.
+template <int NB>
+EMPC_HD void crba_chain(const EmpcModelDesc& m, const double* cs, const double* sn, double* Mp) {
+  constexpr int NV = 6 + NB - 1;
+  double XR[NB][9];
+  double cm[NB], cc[NB][3], cI[NB][9];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    cm[b] = m.mass[b];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) cc[b][i] = m.com[b][i];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) cI[b][i] = m.inertia[b][i];
+    if (b > 0) {
+      double Rj[9];
+      axis_rot<double>(m.axis[b], cs[b - 1], sn[b - 1], Rj);
+      matmul3<double>(m.jplace_R[b], Rj, XR[b]);
+    }
+  }
+#pragma unroll
+  for (int b = NB - 1; b >= 1; --b) {
+    // F = Ic_b * [0; axis_b]
+    double F[6];
+    {
+      double wxc[3], Iw[3], cxl[3];
+      cross3<double>(m.axis[b], cc[b], wxc);
+      matvec3<double>(cI[b], m.axis[b], Iw);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) F[i] = cm[b] * wxc[i];
+      cross3<double>(cc[b], F, cxl);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) F[3 + i] = Iw[i] + cxl[i];
+    }
+    const int col = 6 + b - 1;
+    Mp[col * (col + 1) / 2 + col] = dot3<double>(m.axis[b], F + 3);
+#pragma unroll
+    for (int j = b; j >= 1; --j) {
+      double fl[3], fn[3], rxf[3];
+      matvec3<double>(XR[j], F, fl);
+      matvec3<double>(XR[j], F + 3, fn);
+      cross3<double>(m.jplace_p[j], fl, rxf);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        F[i] = fl[i];
+        F[3 + i] = fn[i] + rxf[i];
+      }
+      if (j - 1 >= 1) {
+        const int row = 6 + (j - 1) - 1;
+        Mp[col * (col + 1) / 2 + row] = dot3<double>(m.axis[j - 1], F + 3);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) Mp[col * (col + 1) / 2 + i] = F[i];
+      }
+    }
+    // add the composite of body b to its parent (expressed in the parent's axes)
+    double c2[3], RI[9], I2[9];
+    matvec3<double>(XR[b], cc[b], c2);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) c2[i] += m.jplace_p[b][i];
+    matmul3<double>(XR[b], cI[b], RI);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        I2[3 * i + j] = RI[3 * i] * XR[b][3 * j] + RI[3 * i + 1] * XR[b][3 * j + 1] + RI[3 * i + 2] * XR[b][3 * j + 2];
+    const double m1 = cm[b - 1], m2 = cm[b], Mt = m1 + m2;
+    double cn[3], d1[3], d2[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      cn[i] = (m1 * cc[b - 1][i] + m2 * c2[i]) / Mt;
+      d1[i] = cc[b - 1][i] - cn[i];
+      d2[i] = c2[i] - cn[i];
+    }
+    const double dd1 = dot3<double>(d1, d1), dd2 = dot3<double>(d2, d2);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        cI[b - 1][3 * i + j] += I2[3 * i + j] + m1 * ((i == j ? dd1 : 0.0) - d1[i] * d1[j]) +
+                                m2 * ((i == j ? dd2 : 0.0) - d2[i] * d2[j]);
+    cm[b - 1] = Mt;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) cc[b - 1][i] = cn[i];
+  }
+  // base 6x6 block: [[m I, -m [c]x],[m [c]x, Ic - m [c]x^2]]
+  {
+    double C[9], CC[9];
+    skew3(cc[0], C);
+    matmul3<double>(C, C, CC);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j <= i; ++j) Mp[i * (i + 1) / 2 + j] = (i == j) ? cm[0] : 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) Mp[(3 + i) * (4 + i) / 2 + j] = cm[0] * C[3 * i + j];
+#pragma unroll
+      for (int j = 0; j <= i; ++j) Mp[(3 + i) * (4 + i) / 2 + 3 + j] = cI[0][3 * i + j] - cm[0] * CC[3 * i + j];
+    }
+  }
+}
+
+// In-register Cholesky of a packed lower-triangular NV x NV matrix (row-major packed: idx(i,j) = i(i+1)/2 + j).
+// On exit L holds the factor with RECIPROCAL diagonal entries. Returns false if not positive definite.
+template <int N>
+EMPC_HD bool chol_packed(double* L) {
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    double s = L[j * (j + 1) / 2 + j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) s -= L[j * (j + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
+    if (!(s > 0.0)) ok = false;
+    const double inv = 1.0 / sqrt(s);
+    L[j * (j + 1) / 2 + j] = inv;
+#pragma unroll
+    for (int i = j + 1; i < N; ++i) {
+      double t = L[i * (i + 1) / 2 + j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) t -= L[i * (i + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
+      L[i * (i + 1) / 2 + j] = t * inv;
+    }
+  }
+  return ok;
+}
+template <int N>
+EMPC_HD void chol_solve_packed(const double* L, double* b) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    double s = b[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) s -= L[i * (i + 1) / 2 + k] * b[k];
+    b[i] = s * L[i * (i + 1) / 2 + i];
+  }
+#pragma unroll
+  for (int i = N - 1; i >= 0; --i) {
+    double s = b[i];
+#pragma unroll
+    for (int k = i + 1; k < N; ++k) s -= L[k * (k + 1) / 2 + i] * b[k];
+    b[i] = s * L[i * (i + 1) / 2 + i];
+  }
+}
+
+// SquashingModelSmoothSat: u = sigma(s), du = sigma'(s)
+EMPC_HD void squash1(double s, double lb, double ub, double smooth, int power, double& u, double& du) {
+  const double dd = smooth * (ub - lb);
+  const double a = (power == 4) ? dd * dd * dd * dd : dd * dd;
+  const double sl = sqrt((s - lb) * (s - lb) + a);
+  const double su = sqrt((s - ub) * (s - ub) + a);
+  u = 0.5 * (sl - su + ub + lb);
+  du = 0.5 * ((s - lb) / sl - (s - ub) / su);
+}
+
+// activation value and derivatives of one residual component
+EMPC_HD void activation1(int act, double r, double w, double lb, double ub, double& a, double& Ar, double& Arr) {
+  if (act == EMPC_ACT_QUAD) {
+    a = 0.5 * r * r;
+    Ar = r;
+    Arr = 1.0;
+  } else if (act == EMPC_ACT_WEIGHTED_QUAD) {
+    a = 0.5 * w * r * r;
+    Ar = w * r;
+    Arr = w;
+  } else {
+    const double ww = (act == EMPC_ACT_QUADRATIC_BARRIER) ? 1.0 : w;
+    const double lo = fmin(r - lb, 0.0);
+    const double hi = fmax(r - ub, 0.0);
+    a = 0.5 * ww * lo * lo + 0.5 * ww * hi * hi;
+    Ar = ww * (lo + hi);
+    const double ind = ((r - lb <= 0.0) ? 1.0 : 0.0) + ((r - ub >= 0.0) ? 1.0 : 0.0);
+    Arr = ww * ind;
+  }
+}
+// weight of component i of cost c, with the barrier cost's weights derived from the trajectory's current smooth
+// (SolverSbFDDP::barrierUpdate, src/sbfddp.cpp:464-477)
+EMPC_HD double act_weight(const EmpcCost& c, int i, double smooth, const DevProblem& P) {
+  if (c.is_barrier) {
+    const double aux = smooth * (P.u_ub[i] - P.u_lb[i]);
+    return 1.0 / (aux * aux);
+  }
+  return c.act_w[i];
+}
+
+// StateMultibody::diff(x0, x1) for the free-flyer + joints layout; also returns the translation part of
+// M0^-1 M1 (needed by Jlog6)
+template <class DM>
+EMPC_HD void state_diff(const double* x0, const double* x1, double* dx, double* dpl_out) {
+  double qc[4] = {-x0[3], -x0[4], -x0[5], x0[6]};
+  double qd[4], R0[9], dp[3], dpl[3];
+  quat_mul(qc, x1 + 3, qd);
+  quat_normalize(qd);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) dp[i] = x1[i] - x0[i];
+  quat_to_R(x0 + 3, R0);
+  matTvec3<double>(R0, dp, dpl);
+  log6_quat(qd, dpl, dx);
+#pragma unroll
+  for (int i = 7; i < DM::NQ; ++i) dx[i - 1] = x1[i] - x0[i];
+#pragma unroll
+  for (int i = 0; i < DM::NV; ++i) dx[DM::NV + i] = x1[DM::NQ + i] - x0[DM::NQ + i];
+  if (dpl_out) {
+    dpl_out[0] = dpl[0];
+    dpl_out[1] = dpl[1];
+    dpl_out[2] = dpl[2];
+  }
+}
+// StateMultibody::integrate(x, dx); optionally returns the translation of exp6(dx[0:6]) (for Jexp6)
+template <class DM>
+EMPC_HD void state_integrate(const double* x, const double* dx, double* xout, double* pe_out) {
+  double qe[4], pe[3], R0[9], Rp[3], qn[4];
+  exp6_quat(dx, qe, pe);
+  quat_to_R(x + 3, R0);
+  matvec3<double>(R0, pe, Rp);
+  quat_mul(x + 3, qe, qn);
+  quat_normalize(qn);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) xout[i] = x[i] + Rp[i];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) xout[3 + i] = qn[i];
+#pragma unroll
+  for (int i = 7; i < DM::NQ; ++i) xout[i] = x[i] + dx[i - 1];
+#pragma unroll
+  for (int i = 0; i < DM::NV; ++i) xout[DM::NQ + i] = x[DM::NQ + i] + dx[DM::NV + i];
+  if (pe_out) {
+    pe_out[0] = pe[0];
+    pe_out[1] = pe[1];
+    pe_out[2] = pe[2];
+  }
+}
+
+// Friction-cone matrix rows (FrictionCone(n, mu, 4, false)): row i of A R_n^T
+EMPC_HD void cone_rows(const double* nsurf, double mu, double AR[5][3]) {
+  const double A[5][3] = {{1, 0, -mu}, {0, 1, -mu}, {-1, 0, -mu}, {0, -1, -mu}, {0, 0, 1}};
+  double nrm = sqrt(dot3<double>(nsurf, nsurf));
+  double nz[3] = {nsurf[0] / nrm, nsurf[1] / nrm, nsurf[2] / nrm};
+  double Rn[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  const double e3[3] = {0, 0, 1};
+  double ax[3];
+  cross3<double>(e3, nz, ax);
+  const double sn_ = sqrt(dot3<double>(ax, ax)), cs_ = nz[2];
+  if (sn_ > 1e-12) {
+    const double ang = atan2(sn_, cs_);
+    double w[3] = {ax[0] / sn_, ax[1] / sn_, ax[2] / sn_};
+    axis_rot<double>(w, cos(ang), sin(ang), Rn);
+  } else if (cs_ < 0) {
+    Rn[4] = -1;
+    Rn[8] = -1;
+  }
+  for (int i = 0; i < 5; ++i)
+    for (int j = 0; j < 3; ++j) AR[i][j] = A[i][0] * Rn[3 * j] + A[i][1] * Rn[3 * j + 1] + A[i][2] * Rn[3 * j + 2];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Nominal evaluation of one node by ONE lane: IAM.calc(x, s)  (used by the rollout and calc kernels).
+//   terminal: the reference's IAM.calc(x) == calc(x, u = 0)   
+// Outputs: xnext[NX], acc[NV] (generalized acceleration, reused by linearize), cost, usq[NU] (squashed control),
+//          lam[6] (contact force).
+// ---------------------------------------------------------------------------------------------------------
+template <class DM>
+EMPC_HD void node_nominal(const DevProblem& P, const EmpcCostSet& set, double smooth, const double* x, const double* s_in,
+                          bool terminal, double* xnext, double* acc, double& cost_out, double* usq, double* lam_out) {
+  constexpr int NB = DM::NB, NV = DM::NV, NQ = DM::NQ, NU = DM::NU, NROT = DM::NROT;
+  const EmpcModelDesc& m = P.model;
+  const double dt = P.dt;
+  double s[NU], u[NU];
+#pragma unroll
+  for (int i = 0; i < NU; ++i) s[i] = terminal ? 0.0 : s_in[i];
+#pragma unroll
+  for (int i = 0; i < NU; ++i) {
+    if (P.use_squash) {
+      double du;
+      squash1(s[i], P.u_lb[i], P.u_ub[i], smooth, P.prm.smoothsat_power, u[i], du);
+    } else {
+      u[i] = s[i];
+    }
+    usq[i] = u[i];
+  }
+  double tau[NV];
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    double a_ = 0;
+#pragma unroll
+    for (int c = 0; c < NROT; ++c) a_ += P.tau_f[r * NROT + c] * u[c];
+    tau[r] = a_;
+  }
+#pragma unroll
+  for (int i = 6; i < NV; ++i) tau[i] = u[NROT + i - 6];
+
+  const double* q = x;
+  const double* v = x + NQ;
+  double R0[9], cs[NB], sn[NB];
+  quat_to_R(q + 3, R0);
+#pragma unroll
+  for (int b = 1; b < NB; ++b) {
+    sn[b - 1] = sin(q[7 + b - 1]);
+    cs[b - 1] = cos(q[7 + b - 1]);
+  }
+  // frames referenced by this node's costs / contacts
+  int capf[NCAP];
+  int ncap = 0;
+  for (int ci = 0; ci < set.ncosts; ++ci) {
+    const EmpcCost& c = set.costs[ci];
+    if (!c.active || c.frame < 0 || c.type == EMPC_COST_CONTACT_FRICTION_CONE) continue;
+    bool seen = false;
+    for (int k = 0; k < ncap; ++k) seen = seen || (capf[k] == c.frame);
+    if (!seen && ncap < NCAP) capf[ncap++] = c.frame;
+  }
+  FrameCap<double> caps[NCAP];
+  // bias forces h = RNEA(q, v, 0)
+  double zero[NV], h[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) zero[i] = 0.0;
+  rnea_chain<NB, double>(m, R0, q, cs, sn, v, zero, true, -1, nullptr, h, ncap, capf, caps);
+  // joint-space inertia (packed lower triangle) by the composite-rigid-body algorithm
+  double L[DM::NTRI];
+  crba_chain<NB>(m, cs, sn, L);
+  chol_packed<NV>(L);
+  double a[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) a[i] = tau[i] - h[i];
+  chol_solve_packed<NV>(L, a);
+  double lam[6] = {0, 0, 0, 0, 0, 0};
+  const bool use_contact = P.has_contact && set.ncontacts > 0;
+  if (use_contact) {
+    // ContactModel3D/6D: [M Jc^T; Jc 0][a; -lam] = [tau - h; -a0]
+    const EmpcContact& ct = set.contacts[0];
+    const int nc = (ct.type == EMPC_CONTACT_3D) ? 3 : 6;
+    int cf[1] = {ct.frame};
+    FrameCap<double> ck[1];
+    double dummy[NV];
+    // drift with qdd = 0, no gravity
+    rnea_chain<NB, double>(m, R0, q, cs, sn, v, zero, false, -1, nullptr, dummy, 1, cf, ck);
+    double a0[6];
+    if (nc == 3) {
+      double wxv[3];
+      cross3<double>(ck[0].v + 3, ck[0].v, wxv);
+      for (int r = 0; r < 3; ++r) a0[r] = ck[0].a[r] + wxv[r];
+    } else {
+      for (int r = 0; r < 6; ++r) a0[r] = ck[0].a[r];
+    }
+    if (ct.gains[0] != 0.0 && nc == 3) {
+      double dp[3], dpl[3];
+      for (int r = 0; r < 3; ++r) dp[r] = ck[0].p[r] - ct.ref_p[r];
+      matTvec3<double>(ck[0].R, dp, dpl);
+      for (int r = 0; r < 3; ++r) a0[r] += ct.gains[0] * dpl[r];
+    }
+    if (ct.gains[1] != 0.0)
+      for (int r = 0; r < nc; ++r) a0[r] += ct.gains[1] * ck[0].v[r];
+    // Jc columns: LOCAL frame velocity for unit generalized velocities
+    double Jc[6][NV], MiJt[6][NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      double ej[NV];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) ej[i] = (i == j) ? 1.0 : 0.0;
+      FrameCap<double> cj[1];
+      rnea_chain<NB, double>(m, R0, q, cs, sn, ej, zero, false, -1, nullptr, dummy, 1, cf, cj);
+      for (int r = 0; r < nc; ++r) Jc[r][j] = cj[0].v[r];
+    }
+    double G[21];  // packed nc x nc
+    for (int r = 0; r < nc; ++r) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) MiJt[r][i] = Jc[r][i];
+      chol_solve_packed<NV>(L, MiJt[r]);
+    }
+    for (int r = 0; r < nc; ++r)
+      for (int c = 0; c <= r; ++c) {
+        double g = 0;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) g += Jc[r][i] * MiJt[c][i];
+        G[r * (r + 1) / 2 + c] = g;
+      }
+    if (nc == 3)
+      chol_packed<3>(G);
+    else
+      chol_packed<6>(G);
+    for (int r = 0; r < nc; ++r) {
+      double g = a0[r];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) g += Jc[r][i] * a[i];
+      lam[r] = -g;
+    }
+    if (nc == 3)
+      chol_solve_packed<3>(G, lam);
+    else
+      chol_solve_packed<6>(G, lam);
+    for (int r = 0; r < nc; ++r)
+#pragma unroll
+      for (int i = 0; i < NV; ++i) a[i] += MiJt[r][i] * lam[r];
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) acc[i] = a[i];
+  if (lam_out)
+    for (int i = 0; i < 6; ++i) lam_out[i] = lam[i];
+
+  // Euler step (A.3)
+  double dxe[DM::NDX];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    dxe[i] = v[i] * dt + a[i] * dt * dt;
+    dxe[NV + i] = a[i] * dt;
+  }
+  state_integrate<DM>(x, dxe, xnext, nullptr);
+
+  // costs (A.6)
+  double ell = 0;
+  for (int ci = 0; ci < set.ncosts; ++ci) {
+    const EmpcCost& c = set.costs[ci];
+    if (!c.active) continue;
+    double cval = 0;
+    if (c.type == EMPC_COST_STATE) {
+      double r[DM::NDX];
+      state_diff<DM>(c.ref, x, r, nullptr);
+#pragma unroll
+      for (int i = 0; i < DM::NDX; ++i) {
+        double av, Ar, Arr;
+        activation1(c.activation, r[i], c.act_w[i], c.lb[i], c.ub[i], av, Ar, Arr);
+        cval += av;
+      }
+    } else if (c.type == EMPC_COST_CONTROL) {
+#pragma unroll
+      for (int i = 0; i < NU; ++i) {
+        double av, Ar, Arr;
+        activation1(c.activation, s[i] - c.ref[i], act_weight(c, i, smooth, P), c.lb[i], c.ub[i], av, Ar, Arr);
+        cval += av;
+      }
+    } else if (c.type == EMPC_COST_CONTACT_FRICTION_CONE) {
+      double AR[5][3];
+      cone_rows(c.ref, c.ref[3], AR);
+      for (int i = 0; i < 5; ++i) {
+        double r = use_contact ? (AR[i][0] * lam[0] + AR[i][1] * lam[1] + AR[i][2] * lam[2]) : 0.0;
+        double av, Ar, Arr;
+        activation1(c.activation, r, c.act_w[i], c.lb[i], c.ub[i], av, Ar, Arr);
+        cval += av;
+      }
+    } else {
+      int k = 0;
+      for (int kk = 0; kk < ncap; ++kk)
+        if (capf[kk] == c.frame) k = kk;
+      const FrameCap<double>& fk = caps[k];
+      double r[6];
+      int nr = 6;
+      if (c.type == EMPC_COST_FRAME_PLACEMENT) {
+        double rR[9], dp[3], rp[3], qq[4];
+        matTmul3<double>(c.ref + 3, fk.R, rR);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) dp[i] = fk.p[i] - c.ref[i];
+        matTvec3<double>(c.ref + 3, dp, rp);
+        R_to_quat(rR, qq);
+        log6_quat(qq, rp, r);
+      } else if (c.type == EMPC_COST_FRAME_ROTATION) {
+        double rR[9], qq[4];
+        matTmul3<double>(c.ref, fk.R, rR);
+        R_to_quat(rR, qq);
+        quat_log3(qq, r);
+        nr = 3;
+      } else if (c.type == EMPC_COST_FRAME_TRANSLATION) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) r[i] = fk.p[i] - c.ref[i];
+        nr = 3;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) r[i] = fk.v[i] - c.ref[i];
+      }
+      for (int i = 0; i < nr; ++i) {
+        double av, Ar, Arr;
+        activation1(c.activation, r[i], c.act_w[i], c.lb[i], c.ub[i], av, Ar, Arr);
+        cval += av;
+      }
+    }
+    ell += c.weight * cval;
+  }
+  const double cscale = (terminal && !P.prm.terminal_dt_scaling) ? 1.0 : dt;
+  cost_out = cscale * ell;
+}
+
+}  // namespace empc

@@ -1,0 +1,303 @@
+// eagle_mpc.hpp: host-side C++ mirror of the eagle-mpc classes that sit on the north-star hot path.
+//
+// Same class / method names and argument meaning as the reference, with
+// std::shared_ptr and plain std::vector<double> in place of boost::shared_ptr / Eigen / Crocoddyl types:
+//   MultiCopterBaseParams  include/eagle_mpc/multicopter-base-params.hpp:25-58
+//   Stage                  include/eagle_mpc/stage.hpp:33-83
+//   Trajectory             include/eagle_mpc/trajectory.hpp:43-103
+//   factories              include/eagle_mpc/factory/{cost,activation,contacts,diff-action,int-action}.hpp
+//   ShootingProblem        crocoddyl::ShootingProblem as used at src/trajectory.cpp:139-140 (x0, running models,
+//                          terminal model) -- here: the flat EmpcProblemDesc the HIP solver consumes
+//   SolverSbFDDP           include/eagle_mpc/sbfddp.hpp:34-126 (+ a batched overload; B = 1 is the reference call)
+//   MpcAbstract/CarrotMpc  include/eagle_mpc/mpc-base.hpp:62-119, mpc-controllers/carrot-mpc.hpp:23-88
+// The arithmetic of the hot path runs in HIP kernels behind the C ABI of include/empc.h; nothing in this
+// directory computes dynamics or Riccati recursions on the CPU.
+#pragma once
+#include <cstddef>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/empc.h"
+#include "params.hpp"
+#include "robot_model.hpp"
+
+namespace eagle_mpc {
+
+struct MatrixXd {
+  int rows = 0, cols = 0;
+  std::vector<double> data;  // row-major
+  MatrixXd() {}
+  MatrixXd(int r, int c) : rows(r), cols(c), data((size_t)r * c, 0.0) {}
+  double& operator()(int r, int c) { return data[(size_t)r * cols + c]; }
+  double operator()(int r, int c) const { return data[(size_t)r * cols + c]; }
+};
+
+struct SE3 {
+  double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  double p[3] = {0, 0, 0};
+};
+// Eigen::Quaterniond(Vector4d(x,y,z,w)).normalized().toRotationMatrix()
+void quaternionToRotation(const VectorXd& xyzw, double* R);
+
+enum class CostModelTypes {
+  CostModelState,
+  CostModelControl,
+  CostModelFramePlacement,
+  CostModelFrameRotation,
+  CostModelFrameVelocity,
+  CostModelFrameTranslation,
+  CostModelContactFrictionCone,
+  NbCostModelTypes
+};
+enum class ActivationModelTypes {
+  ActivationModelQuad,
+  ActivationModelQuadFlatExp,
+  ActivationModelQuadFlatLog,
+  ActivationModelSmooth1Norm,
+  ActivationModelSmooth2Norm,
+  ActivationModelWeightedQuad,
+  ActivationModelQuadraticBarrier,
+  ActivationModelWeightedQuadraticBarrier,
+  NbActivationModelTypes
+};
+enum class ContactModelTypes { ContactModel2D, ContactModel3D, ContactModel6D, NbContactModelTypes };
+enum class DifferentialActionModelTypes {
+  DifferentialActionModelFreeFwdDynamics,
+  DifferentialActionModelContactFwdDynamics,
+  NbDifferentialActionModelTypes
+};
+enum class IntegratedActionModelTypes { IntegratedActionModelEuler, IntegratedActionModelRK4, NbIntegratedActionModelTypes };
+
+class MultiCopterBaseParams {
+ public:
+  MultiCopterBaseParams() {}
+  MultiCopterBaseParams(double cf, double cm, const MatrixXd& tau_f, double max_th, double min_th, const std::string& base_link);
+  void autoSetup(const std::string& path_to_platform, const std::shared_ptr<ParamsServer>& server);
+  void autoSetup(const std::string& path_to_platform, const std::shared_ptr<ParamsServer>& server,
+                 const std::shared_ptr<RobotModel>& robot_model);
+  void setControlLimits(const std::shared_ptr<RobotModel>& robot_model);
+
+  double cf_ = 0, cm_ = 0;
+  std::size_t n_rotors_ = 0;
+  MatrixXd tau_f_;  // 6 x n_rotors
+  double max_thrust_ = 0, min_thrust_ = 0, max_prop_speed_ = 0, min_prop_speed_ = 0;
+  std::string base_link_name_;
+  std::vector<SE3> rotors_pose_;
+  std::vector<int> rotors_spin_dir_;
+  VectorXd u_lb, u_ub;
+};
+
+class Trajectory;
+
+// Registry of the operational frames a problem references (index = position in EmpcModelDesc's frame table).
+class FrameTable {
+ public:
+  int use(int model_frame_id);
+  const std::vector<int>& ids() const { return ids_; }
+
+ private:
+  std::vector<int> ids_;
+};
+
+class ActivationModelFactory {
+ public:
+  // fills activation / act_w / lb / ub of `cost` (reference: src/factory/activation.cpp:17-102)
+  void create(const std::string& path_to_cost, const std::shared_ptr<ParamsServer>& server, std::size_t nr, EmpcCost& cost) const;
+};
+class CostModelFactory {
+ public:
+  // reference: src/factory/cost.cpp:17-171
+  EmpcCost create(const std::string& path_to_cost, const std::shared_ptr<ParamsServer>& server,
+                  const std::shared_ptr<RobotModel>& robot_model, FrameTable& frames, std::size_t nu,
+                  CostModelTypes& cost_type) const;
+
+ private:
+  ActivationModelFactory activation_factory_;
+};
+class ContactModelFactory {
+ public:
+  // reference: src/factory/contacts.cpp:17-82
+  EmpcContact create(const std::string& path_to_contact, const std::shared_ptr<ParamsServer>& server,
+                     const std::shared_ptr<RobotModel>& robot_model, FrameTable& frames, std::size_t nu,
+                     ContactModelTypes& contact_type) const;
+};
+
+// CostModelSum analogue: name-ordered table (std::map iteration order)
+class CostModelSum {
+ public:
+  void addCost(const std::string& name, const EmpcCost& cost, double weight, bool active = true);
+  void removeCost(const std::string& name);
+  const std::map<std::string, EmpcCost>& get_costs() const { return costs_; }
+  std::map<std::string, EmpcCost>& get_costs() { return costs_; }
+
+ private:
+  std::map<std::string, EmpcCost> costs_;
+};
+class ContactModelMultiple {
+ public:
+  void addContact(const std::string& name, const EmpcContact& contact);
+  const std::map<std::string, EmpcContact>& get_contacts() const { return contacts_; }
+
+ private:
+  std::map<std::string, EmpcContact> contacts_;
+};
+EmpcCostSet makeCostSet(const CostModelSum& costs, const ContactModelMultiple& contacts);
+
+class Stage : public std::enable_shared_from_this<Stage> {
+ public:
+  static std::shared_ptr<Stage> create(const std::shared_ptr<Trajectory>& trajectory);
+  void autoSetup(const std::string& path_to_stages, const std::map<std::string, std::string>& stage,
+                 const std::shared_ptr<ParamsServer>& server, std::size_t t_ini);
+  void set_t_ini(std::size_t t_ini) { t_ini_ = t_ini; }
+  void set_duration(std::size_t duration) { duration_ = duration; }
+  const std::shared_ptr<Trajectory>& get_trajectory() const { return trajectory_; }
+  const std::shared_ptr<CostModelSum>& get_costs() const { return costs_; }
+  const std::shared_ptr<ContactModelMultiple>& get_contacts() const { return contacts_; }
+  const std::map<std::string, CostModelTypes>& get_cost_types() const { return cost_types_; }
+  const std::map<std::string, ContactModelTypes>& get_contact_types() const { return contact_types_; }
+  std::size_t get_duration() const { return duration_; }
+  std::size_t get_t_ini() const { return t_ini_; }
+  const std::string& get_name() const { return name_; }
+  bool get_is_terminal() const { return is_terminal_; }
+  bool get_is_transition() const { return is_transition_; }
+
+ private:
+  explicit Stage(const std::shared_ptr<Trajectory>& trajectory);
+  std::shared_ptr<Trajectory> trajectory_;
+  std::shared_ptr<CostModelSum> costs_;
+  std::shared_ptr<ContactModelMultiple> contacts_;
+  std::map<std::string, CostModelTypes> cost_types_;
+  std::map<std::string, ContactModelTypes> contact_types_;
+  std::string name_;
+  std::size_t duration_ = 0, t_ini_ = 0;
+  bool is_transition_ = false, is_terminal_ = false;
+};
+
+// What crocoddyl::ShootingProblem is to the reference: initial state + one action model per node.  Action models
+// are rows of a cost-set table (all knots of a Stage share one row, exactly like the shared iam pointer at
+// src/trajectory.cpp:133-136); desc() flattens it for the C ABI.
+class ShootingProblem {
+ public:
+  ShootingProblem(const VectorXd& x0, const EmpcModelDesc& model, const std::vector<EmpcCostSet>& sets,
+                  const std::vector<int>& knot_set, const MatrixXd& tau_f, const VectorXd& u_lb, const VectorXd& u_ub,
+                  double dt, bool has_contact, bool use_squash, int integrator);
+  std::size_t get_T() const { return (std::size_t)(knot_set_.size() - 1); }
+  const VectorXd& get_x0() const { return x0_; }
+  void set_x0(const VectorXd& x0);
+  std::size_t get_nx() const { return (std::size_t)desc_.nx; }
+  std::size_t get_ndx() const { return (std::size_t)desc_.ndx; }
+  std::size_t get_nu() const { return (std::size_t)desc_.nu; }
+  double get_dt() const { return desc_.dt; }
+  std::vector<EmpcCostSet>& get_sets() { return sets_; }
+  const std::vector<int>& get_knot_set() const { return knot_set_; }
+  const EmpcProblemDesc& desc();  // pointers valid until the problem is modified or destroyed
+
+ private:
+  VectorXd x0_;
+  std::vector<EmpcCostSet> sets_;
+  std::vector<int> knot_set_;
+  EmpcProblemDesc desc_;
+};
+
+struct ProblemParams {
+  bool use_squash = false;
+  std::size_t dt = 0;
+  std::string integrator;
+};
+
+class Trajectory : public std::enable_shared_from_this<Trajectory> {
+ public:
+  static std::shared_ptr<Trajectory> create();
+  void autoSetup(const std::string& yaml_path);
+  std::shared_ptr<ShootingProblem> createProblem() const;
+  std::shared_ptr<ShootingProblem> createProblem(std::size_t dt, bool squash, const std::string& integration_method) const;
+  void removeStage(std::size_t idx_stage);
+  void set_initial_state(const VectorXd& initial_state);
+
+  const std::vector<std::shared_ptr<Stage>>& get_stages() const { return stages_; }
+  const std::shared_ptr<RobotModel>& get_robot_model() const { return robot_model_; }
+  const std::string& get_robot_model_path() const { return robot_model_path_; }
+  const std::shared_ptr<MultiCopterBaseParams>& get_platform_params() const { return platform_params_; }
+  const VectorXd& get_initial_state() const { return initial_state_; }
+  const std::shared_ptr<ParamsServer>& get_params_server() const { return params_server_; }
+  bool get_has_contact() const { return has_contact_; }
+  std::size_t get_duration() const { return duration_; }
+  std::size_t get_nx() const { return (std::size_t)(robot_model_->nq() + robot_model_->nv()); }
+  std::size_t get_ndx() const { return (std::size_t)(2 * robot_model_->nv()); }
+  std::size_t get_nu() const;  // actuation->get_nu() = n_rotors + (nv - 6)
+  VectorXd zero_state() const;
+  FrameTable& frame_table() { return frames_; }
+  const FrameTable& frame_table() const { return frames_; }
+  const ProblemParams& get_problem_params() const { return problem_params_; }
+
+ private:
+  Trajectory();
+  std::vector<std::shared_ptr<Stage>> stages_;
+  std::shared_ptr<RobotModel> robot_model_;
+  std::string robot_model_path_;
+  std::shared_ptr<MultiCopterBaseParams> platform_params_;
+  VectorXd initial_state_;
+  std::shared_ptr<ParamsServer> params_server_;
+  ProblemParams problem_params_;
+  bool has_contact_ = false;
+  std::size_t duration_ = 0;
+  FrameTable frames_;
+};
+
+// Batched Squash-box FDDP on the GPU.  The scalar interface below is the reference's; the *Batch methods are the
+// data-parallel extension (B independent rollouts of the same problem from different initial states).
+class SolverSbFDDP {
+ public:
+  // squashing model == the problem's (u_lb, u_ub) smooth saturation; batch_size trajectories on HIP device `device`
+  explicit SolverSbFDDP(const std::shared_ptr<ShootingProblem>& problem, std::size_t batch_size = 1, int device = 0);
+  ~SolverSbFDDP();
+  SolverSbFDDP(const SolverSbFDDP&) = delete;
+  SolverSbFDDP& operator=(const SolverSbFDDP&) = delete;
+
+  // reference signature (include/eagle_mpc/sbfddp.hpp:42-46); always returns true (src/sbfddp.cpp:225)
+  bool solve(const std::vector<VectorXd>& init_xs = std::vector<VectorXd>(),
+             const std::vector<VectorXd>& init_us = std::vector<VectorXd>(), std::size_t maxiter = 100,
+             bool is_feasible = false, double regInit = 1e-9);
+  // batched: x0s is B x nx; init_xs B x (T+1) x nx and init_us B x T x nu (empty = zero state / zero control)
+  bool solveBatch(const std::vector<double>& x0s, const std::vector<double>& init_xs = std::vector<double>(),
+                  const std::vector<double>& init_us = std::vector<double>(), std::size_t maxiter = 100,
+                  bool is_feasible = false);
+
+  const std::vector<VectorXd>& getSquashControls() const { return us_squash_; }
+  const std::vector<VectorXd>& get_xs() const { return xs_; }
+  const std::vector<VectorXd>& get_us() const { return us_; }
+  std::size_t get_iter() const { return iter_; }
+  double get_cost() const { return cost_; }
+  double get_stop() const { return stop_; }
+  double get_convergence_init() const { return convergence_init_; }
+  void set_convergence_init(double convergence_init);
+  const std::shared_ptr<ShootingProblem>& get_problem() const { return problem_; }
+  std::size_t get_batch_size() const { return batch_; }
+  // re-upload the problem's cost tables / x0 after an MPC updateProblem()
+  void syncProblem();
+
+  // batched results, row-major B x ...
+  const std::vector<double>& get_xs_batch() const { return xs_b_; }
+  const std::vector<double>& get_us_batch() const { return us_b_; }
+  const std::vector<double>& get_us_squash_batch() const { return us_squash_b_; }
+  const std::vector<double>& get_cost_batch() const { return cost_b_; }
+  const std::vector<int>& get_iter_batch() const { return iter_b_; }
+  const std::vector<int>& get_status_batch() const { return status_b_; }
+  EmpcSolver* handle() const { return handle_; }
+
+ private:
+  void fetch();
+  std::shared_ptr<ShootingProblem> problem_;
+  std::size_t batch_;
+  EmpcSolver* handle_ = nullptr;
+  double convergence_init_ = 1e-2;
+  std::vector<VectorXd> xs_, us_, us_squash_;
+  std::size_t iter_ = 0;
+  double cost_ = 0, stop_ = 0;
+  std::vector<double> xs_b_, us_b_, us_squash_b_, cost_b_;
+  std::vector<int> iter_b_, status_b_;
+};
+
+}  // namespace eagle_mpc

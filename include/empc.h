@@ -1,0 +1,134 @@
+/*
+ * empc.h -- C ABI of the MI355X-native batched Squash-box FDDP solver (libempc.so).
+ *
+ * This is the drop-in boundary for the eagle-mpc hot path: plain pointers and sizes, no
+ * C++ / torch / Eigen types.  All host buffers are caller-owned, row-major FP64; device memory is owned by the opaque
+ * handles.  Every function returning int returns 0 on success and a negative EMPC_ERR_* code otherwise;
+ * empc_last_error() gives the message (thread-local).  No C++ exception crosses this boundary.
+ *
+ * Reference interfaces replaced (file:line in /root/reference):
+ *   empc_trajectory_*         Trajectory::create/autoSetup/createProblem/set_initial_state + getters
+ *                             include/eagle_mpc/trajectory.hpp:49-74, src/trajectory.cpp:21-143
+ *   empc_solver_create        SolverSbFDDP::SolverSbFDDP(problem, squashing_model)   include/eagle_mpc/sbfddp.hpp:39-40,
+ *                             src/sbfddp.cpp:5-38 (incl. barrierInit :169-190)
+ *   empc_solver_solve         SolverSbFDDP::solve(init_xs, init_us, maxiter, is_feasible, regInit)
+ *                             include/eagle_mpc/sbfddp.hpp:42-46, src/sbfddp.cpp:192-226
+ *   empc_solver_set_x0        problem->set_x0(x0)   (examples/python/mpc.py:50)
+ *   empc_solver_set_warmstart the init_xs/init_us arguments of solve() (crocoddyl setCandidate, src/sbfddp.cpp:199)
+ *   empc_solver_get_xs/us     SolverAbstract::get_xs/get_us (bindings/python/eagle_mpc/sbfddp.hpp:46-79)
+ *   empc_solver_get_us_squash SolverSbFDDP::getSquashControls   include/eagle_mpc/sbfddp.hpp:48, src/sbfddp.cpp:479-487
+ *   empc_solver_get_cost/iters/stop   get_cost/get_iter/get_stop (crocoddyl::SolverAbstract)
+ *   empc_solver_set_convergence_init  SolverSbFDDP::set_convergence_init   src/sbfddp.cpp:491
+ *   empc_solver_update_problem  what MpcAbstract::updateProblem does by mutating shared cost models in place
+ *                             (src/mpc-controllers/carrot-mpc.cpp:298-359)
+ *   empc_linearize_batch / empc_backward_batch / empc_rollout_batch
+ *                             crocoddyl SolverDDP::calcDiff / backwardPass / SolverFDDP::forwardPass as called at
+ *                             src/sbfddp.cpp:244,264 -- exposed per phase for parity tests and roofline measurements
+ */
+#ifndef EMPC_H
+#define EMPC_H
+
+#include "empc_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EMPC_OK 0
+#define EMPC_ERR_INVALID -1     /* bad argument / malformed problem          */
+#define EMPC_ERR_RUNTIME -2     /* HIP runtime error, no device, out of memory */
+#define EMPC_ERR_UNSUPPORTED -3 /* problem shape the kernels are not built for */
+#define EMPC_ERR_IO -4          /* YAML / URDF could not be read              */
+
+typedef struct EmpcSolver EmpcSolver;
+typedef struct EmpcTrajectory EmpcTrajectory;
+typedef struct EmpcProblem EmpcProblem;
+
+const char* empc_last_error(void);
+const char* empc_version(void);
+/* number of HIP devices visible (0 when there is none); never throws */
+int empc_device_count(void);
+
+/* ---- data directories (reference: EAGLE_MPC_YAML_DIR / EAGLE_MPC_ROBOT_DATA_DIR, config/path.hpp.in:4-11) ---- */
+int empc_set_data_dirs(const char* yaml_dir, const char* robot_data_dir);
+
+/* ---- YAML problem factory ------------------------------------------------------------------------------- */
+EmpcTrajectory* empc_trajectory_create(const char* yaml_path);           /* create() + autoSetup(); NULL on error */
+void empc_trajectory_destroy(EmpcTrajectory* t);
+int empc_trajectory_dims(const EmpcTrajectory* t, int* nx, int* ndx, int* nu, int* n_stages, int* has_contact,
+                         int* duration_ms);
+int empc_trajectory_stage_info(const EmpcTrajectory* t, int stage, char* name, int name_len, int* duration_ms,
+                               int* is_transition, int* n_costs, int* n_contacts);
+int empc_trajectory_get_initial_state(const EmpcTrajectory* t, double* x0 /* nx */);
+int empc_trajectory_set_initial_state(EmpcTrajectory* t, const double* x0 /* nx */);
+int empc_trajectory_get_platform(const EmpcTrajectory* t, double* tau_f /* 6 x n_rotors */, double* u_lb, double* u_ub,
+                                 int* n_rotors);
+/* createProblem(dt_ms, squash, integration_method); dt_ms == 0 uses the YAML's problem_params */
+EmpcProblem* empc_trajectory_create_problem(const EmpcTrajectory* t, int dt_ms, int squash, const char* integration_method);
+void empc_problem_destroy(EmpcProblem* p);
+/* flat descriptor of the problem; valid until the problem is modified or destroyed */
+const EmpcProblemDesc* empc_problem_desc(EmpcProblem* p);
+int empc_problem_set_x0(EmpcProblem* p, const double* x0);
+/* flat-key parameter lookup (ParamsServer::getParam<std::string>); returns length or EMPC_ERR_INVALID */
+int empc_trajectory_get_param(const EmpcTrajectory* t, const char* key, char* value, int value_len);
+
+/* ---- solver ------------------------------------------------------------------------------------------------ */
+void empc_solver_params_default(EmpcSolverParams* p);
+/* batch trajectories of the same problem on HIP device `device`. params == NULL -> defaults. */
+EmpcSolver* empc_solver_create(const EmpcProblemDesc* problem, const EmpcSolverParams* params, int batch, int device);
+void empc_solver_destroy(EmpcSolver* s);
+int empc_solver_update_problem(EmpcSolver* s, const EmpcProblemDesc* problem); /* same shapes; new cost tables / x0 */
+int empc_solver_set_x0(EmpcSolver* s, const double* x0s /* batch x nx, NULL = problem x0 for every trajectory */);
+int empc_solver_set_warmstart(EmpcSolver* s, const double* xs /* batch x (T+1) x nx or NULL = zero state */,
+                              const double* us /* batch x T x nu or NULL = zeros */);
+int empc_solver_set_convergence_init(EmpcSolver* s, double convergence_init);
+/* returns EMPC_OK when the call ran (like the reference's solve(), which always returns true);
+ * per-trajectory outcomes are in empc_solver_get_status */
+int empc_solver_solve(EmpcSolver* s, int maxiter, int is_feasible);
+int empc_solver_get_xs(EmpcSolver* s, double* xs /* batch x (T+1) x nx */);
+int empc_solver_get_us(EmpcSolver* s, double* us /* batch x T x nu */);
+int empc_solver_get_us_squash(EmpcSolver* s, double* us_squash /* batch x T x nu */);
+int empc_solver_get_cost(EmpcSolver* s, double* cost /* batch */);
+int empc_solver_get_stop(EmpcSolver* s, double* stop /* batch */);
+int empc_solver_get_iters(EmpcSolver* s, int* iters /* batch: iter_ = total iterations - 1 */);
+int empc_solver_get_status(EmpcSolver* s, int* status /* batch: EMPC_STATUS_* bits */);
+
+/* timing / accounting of the last solve (device time measured with HIP events on the solver's stream) */
+typedef struct EmpcSolveStats {
+  int sweeps;                 /* host-side sweeps (one sweep = one pass of the kernel sequence)             */
+  int max_iters;              /* largest per-trajectory DDP iteration count                                 */
+  long long total_iters;      /* sum over trajectories of DDP iterations (FDDP passes + DDP clean-up)       */
+  long long linearize_units;  /* (trajectory, node) units linearized                                        */
+  long long rollout_units;    /* (trajectory, alpha, node) units rolled out                                 */
+  long long backward_units;   /* (trajectory, node) units of the backward pass                              */
+  double ms_total;            /* wall time of the solve on the stream                                       */
+  double ms_linearize, ms_backward, ms_rollout, ms_select, ms_calc; /* summed kernel times (events)         */
+  int n_linearize, n_backward, n_rollout, n_select, n_calc;         /* launches                              */
+} EmpcSolveStats;
+int empc_solver_get_stats(EmpcSolver* s, EmpcSolveStats* stats);
+int empc_solver_dims(const EmpcSolver* s, int* batch, int* T, int* nx, int* ndx, int* nu, int* rec_doubles);
+
+/* ---- phase-level entry points (device kernels, one call = one launch over the whole batch) ------------------
+ * xs: batch x (T+1) x nx, us: batch x T x nu. `smooth` is the squashing smoothness (0.1 in the first pass).
+ * Outputs may be NULL. */
+/* calc + calcDiff of every node: tape records batch x (T+1) x rec_doubles (layout: empc_tape_layout), cost per
+ * trajectory, gaps are computed against the solver's x0s when is_feasible == 0 */
+int empc_linearize_batch(EmpcSolver* s, const double* xs, const double* us, double smooth, int is_feasible,
+                         double* tape, double* cost /* batch */, double* xnext /* batch x T x nx */);
+/* backwardPass on the tape left by empc_linearize_batch; ok[b] = 0 where the LLT failed ("backward_error") */
+int empc_backward_batch(EmpcSolver* s, double xreg, int is_feasible, double* K /* batch x T x nu x ndx */,
+                        double* k /* batch x T x nu */, double* Vx /* batch x (T+1) x ndx */,
+                        double* dgdq /* batch x 2 */, int* ok /* batch */);
+/* forwardPass(alpha) from the current candidate and gains; ddp != 0 selects forwardPassDDP (no gap terms) */
+int empc_rollout_batch(EmpcSolver* s, double alpha, int ddp, int is_feasible, double* xs_try, double* us_try,
+                       double* cost_try /* batch */, int* ok /* batch */);
+/* offsets (in doubles) of the blocks inside one tape record */
+typedef struct EmpcTapeLayout {
+  int rec, off_fx, off_fu, off_lxx, off_lxu, off_luu, off_lx, off_lu, off_gap, off_cost;
+} EmpcTapeLayout;
+int empc_tape_layout(const EmpcSolver* s, EmpcTapeLayout* layout);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EMPC_H */
