@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py -- DDP iterations/s of the batched Squash-box FDDP solver on MI355X.
+
+Workload (BASELINE.json configs[1]): hexacopter370_flying_arm_3 `displacement.yaml`, dt = 80 ms -> 100 knots,
+batch 1024 rollouts per GPU from perturbed initial states (recipe of benchmark/utils/utils.hpp:15-27), empty
+initial guess, SolverSbFDDP.solve(maxiter = 100).  One "step" = one full batched solve from scratch.
+
+metric/value: batched DDP iterations per second = (sum over trajectories of DDP iterations executed) / batch / time,
+i.e. trajectory-iterations/s divided by 1024; with N GPUs every rank solves its own 1024 rollouts (weak scaling) and
+`value` is the whole-job aggregate.  The only collective is the gather of results to rank 0 (RCCL).
+
+Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--config displacement|eagle_catch|hover|push_slide]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    "hover": ("hexacopter370/trajectories/hover.yaml", 40),
+    "displacement": ("hexacopter370_flying_arm_3/trajectories/displacement.yaml", 80),
+    "eagle_catch": ("hexacopter370_flying_arm_3/trajectories/eagle_catch.yaml", 32),
+    "push_slide": ("hextilt_flying_arm_5/trajectories/push_slide.yaml", 13),
+}
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_words(nx, ndx, nu):
+    """FP64 words per (trajectory, knot, iteration) for each phase."""
+    a_in = nx + nu
+    a_out = ndx * ndx + ndx * nu + ndx + nu + ndx * (ndx + 1) // 2 + ndx * nu + nu * (nu + 1) // 2 + ndx + 1
+    b_in = a_out - 1
+    b_out = nu * ndx + nu + ndx
+    c_in = nx + nu + nu * ndx + nu + 2 * ndx
+    c_out = nx + nu
+    return dict(linearize=a_in + a_out, backward=b_in + b_out, rollout=c_in + c_out,
+                iteration=a_in + a_out + b_in + b_out + c_in + c_out)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=1024, help="rollouts per GPU")
+    ap.add_argument("--config", default="displacement", choices=sorted(CONFIGS))
+    ap.add_argument("--maxiter", type=int, default=100)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+
+    import torch
+    import empc_loader
+    empc = empc_loader.load()
+    if empc.device_count() < 1:
+        raise SystemExit("bench.py needs a GPU: the solver has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+
+    rel, dt = CONFIGS[args.config]
+    traj = empc.Trajectory()
+    traj.autoSetup(empc.yaml_path(rel))
+    problem = traj.createProblem(dt, True, "IntegratedActionModelEuler")
+    d = problem.desc
+    B = args.batch
+    # rank r owns rollouts [r*B, (r+1)*B) of the global batch; rollout 0 is the unperturbed YAML state
+    x0_all = empc.perturbed_x0s(problem.x0, B * world, nq=d.model.nq)
+    x0s = np.ascontiguousarray(x0_all[rank * B:(rank + 1) * B])
+    solver = empc.SolverSbFDDP(problem, batch=B, device=local_rank)
+
+    def one_step():
+        solver.solve([], [], args.maxiter, x0s=x0s)
+        if dist is not None:
+            # the only exchange of the algorithm: results to rank 0 (RCCL gather over xGMI)
+            res = torch.from_numpy(np.concatenate([solver.xs_batch.reshape(B, -1), solver.us_squash_batch.reshape(B, -1),
+                                                   solver.cost_batch.reshape(B, 1)], axis=1)).cuda()
+            out = [torch.empty_like(res) for _ in range(world)] if rank == 0 else None
+            dist.gather(res, out, dst=0)
+        return solver.stats()
+
+    for _ in range(args.warmup):
+        one_step()
+    agg = {}
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        st = one_step()
+        for k, v in st.items():
+            agg[k] = agg.get(k, 0) + v
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    iters_rank = float(agg["total_iters"])
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        tsum = torch.tensor([iters_rank], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        iters_total = float(tsum.item())
+    else:
+        iters_total = iters_rank
+
+    if rank == 0:
+        words = algorithmic_words(d.nx, d.ndx, d.nu)
+        value = iters_total / B / elapsed
+        # dominant kernel of the timed region (HIP-event durations recorded on the solver's stream)
+        kern = {"linearize": (agg["ms_linearize"], agg["n_linearize"], agg["linearize_units"]),
+                "backward": (agg["ms_backward"], agg["n_backward"], agg["backward_units"]),
+                "rollout": (agg["ms_rollout"], agg["n_rollout"], agg["rollout_units"])}
+        dom = max(kern, key=lambda k: kern[k][0])
+        ms, nlaunch, units = kern[dom]
+        bytes_per_launch = units / max(nlaunch, 1) * words[dom] * 8.0
+        avg_ms = ms / max(nlaunch, 1)
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic = None
+        prof = os.path.join(ROOT, "profiles", "traffic_%s.json" % dom)
+        if os.path.exists(prof):
+            try:
+                traffic = json.load(open(prof)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "DDP iters/sec (batch=%d per GPU, %d knots)" % (B, d.T),
+            "value": value,
+            "unit": "batched DDP iterations/s (trajectory-iterations/s / %d)" % B,
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "%s dt=%dms T=%d batch=%d/GPU SolverSbFDDP.solve(maxiter=%d), perturbed x0" %
+                                   (rel, dt, d.T, B, args.maxiter),
+                       "nx": d.nx, "ndx": d.ndx, "nu": d.nu, "parallelism": "batch-sharded x%d" % world},
+            "trajectory_iters_per_s": iters_total / elapsed,
+            "mean_iters_per_trajectory": iters_total / (B * world * args.steps),
+            "sweeps_per_solve": agg["sweeps"] / args.steps,
+            "kernel_ms_per_solve": {k: kern[k][0] / args.steps for k in kern},
+            "roofline": {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_unit": words[dom] * 8, "units_per_launch": units / max(nlaunch, 1),
+                         "avg_launch_ms": avg_ms},
+            "iteration_roofline": {"algorithmic_bytes_per_traj_knot_iter": words["iteration"] * 8,
+                                   "achieved_GBs": iters_total * d.T * words["iteration"] * 8 / elapsed / 1e9 / world,
+                                   "frac_of_8TBs": iters_total * d.T * words["iteration"] * 8 / elapsed / 1e9 / world / HBM_PEAK_GBS},
+        }
+        if not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_binding as ob  # the oracle timed as the CPU baseline ("port"), never part of the product path
+            cores = os.cpu_count() or 1
+            n_sample = int(min(B, max(cores * 4, 8)))
+            r = ob.solve_batch(d, x0s[:n_sample], args.maxiter, nthreads=cores, want_traj=False)
+            cpu_iters = float((r["iter"] + 1).sum())
+            out["cpu_baseline"] = {"value": cpu_iters / B / r["seconds"], "unit": out["unit"], "cores": cores, "kind": "port",
+                                   "sample": "%d of the %d rollouts of rank 0, OpenMP over rollouts, oracle/liboracle.so "
+                                             "(FP64 C++ restatement, not Crocoddyl)" % (n_sample, B),
+                                   "trajectory_iters_per_s": cpu_iters / r["seconds"], "seconds": r["seconds"]}
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,364 @@
+"""eagle-mpc_amd: MI355X-native batched Squash-box FDDP (the hot path of PepMS/eagle-mpc).
+
+Python is plumbing only: this package binds the C ABI of ``libempc.so`` (include/empc.h) with ctypes and mirrors the
+names of the reference's Python bindings (bindings/python/eagle_mpc/{trajectory,sbfddp}.hpp).  There is no CPU
+implementation of the solver here: constructing a solver without the HIP library or without a GPU raises.
+
+The directory name contains a hyphen, so import it through ``load()`` in the repository-root helper
+``empc_loader.py`` (``import empc_loader; empc = empc_loader.load()``).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import ctypes_defs as T
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "libempc.so")
+YAML_DIR = os.path.join(os.path.dirname(_PKG_DIR), "tests", "golden", "yaml")
+ROBOT_DIR = os.path.join(_PKG_DIR, "data", "robots")
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+
+class EmpcError(RuntimeError):
+    pass
+
+
+def _ptr(a, dtype=np.float64):
+    if a is None:
+        return None
+    assert a.dtype == dtype and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_dp if dtype == np.float64 else _ip)
+
+
+_lib = None
+
+
+def lib():
+    """Load libempc.so (built by __graft_entry__.build() / `make -C eagle-mpc_amd`). Fails loudly if missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EmpcError("libempc.so not found at %s: build it first (python -c 'import __graft_entry__ as g; g.build()'); "
+                        "there is no Python/CPU fallback for the solver" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    L.empc_last_error.restype = C.c_char_p
+    L.empc_version.restype = C.c_char_p
+    L.empc_trajectory_create.restype = C.c_void_p
+    L.empc_trajectory_create.argtypes = [C.c_char_p]
+    L.empc_trajectory_destroy.argtypes = [C.c_void_p]
+    L.empc_trajectory_dims.argtypes = [C.c_void_p] + [_ip] * 6
+    L.empc_trajectory_stage_info.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int, _ip, _ip, _ip, _ip]
+    L.empc_trajectory_get_initial_state.argtypes = [C.c_void_p, _dp]
+    L.empc_trajectory_set_initial_state.argtypes = [C.c_void_p, _dp]
+    L.empc_trajectory_get_platform.argtypes = [C.c_void_p, _dp, _dp, _dp, _ip]
+    L.empc_trajectory_create_problem.restype = C.c_void_p
+    L.empc_trajectory_create_problem.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p]
+    L.empc_trajectory_get_param.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int]
+    L.empc_problem_destroy.argtypes = [C.c_void_p]
+    L.empc_problem_desc.restype = C.POINTER(T.ProblemDesc)
+    L.empc_problem_desc.argtypes = [C.c_void_p]
+    L.empc_problem_set_x0.argtypes = [C.c_void_p, _dp]
+    L.empc_solver_params_default.argtypes = [C.POINTER(T.SolverParams)]
+    L.empc_solver_create.restype = C.c_void_p
+    L.empc_solver_create.argtypes = [C.POINTER(T.ProblemDesc), C.POINTER(T.SolverParams), C.c_int, C.c_int]
+    L.empc_solver_destroy.argtypes = [C.c_void_p]
+    L.empc_solver_update_problem.argtypes = [C.c_void_p, C.POINTER(T.ProblemDesc)]
+    L.empc_solver_set_x0.argtypes = [C.c_void_p, _dp]
+    L.empc_solver_set_warmstart.argtypes = [C.c_void_p, _dp, _dp]
+    L.empc_solver_set_convergence_init.argtypes = [C.c_void_p, C.c_double]
+    L.empc_solver_solve.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    for name in ("xs", "us", "us_squash", "cost", "stop"):
+        getattr(L, "empc_solver_get_" + name).argtypes = [C.c_void_p, _dp]
+    L.empc_solver_get_iters.argtypes = [C.c_void_p, _ip]
+    L.empc_solver_get_status.argtypes = [C.c_void_p, _ip]
+    L.empc_solver_get_stats.argtypes = [C.c_void_p, C.POINTER(T.SolveStats)]
+    L.empc_solver_dims.argtypes = [C.c_void_p] + [_ip] * 6
+    L.empc_tape_layout.argtypes = [C.c_void_p, C.POINTER(T.TapeLayout)]
+    L.empc_linearize_batch.argtypes = [C.c_void_p, _dp, _dp, C.c_double, C.c_int, _dp, _dp, _dp]
+    L.empc_backward_batch.argtypes = [C.c_void_p, C.c_double, C.c_int, _dp, _dp, _dp, _dp, _ip]
+    L.empc_rollout_batch.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int, _dp, _dp, _dp, _ip]
+    L.empc_set_data_dirs(YAML_DIR.encode(), ROBOT_DIR.encode())
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise EmpcError(lib().empc_last_error().decode())
+
+
+def device_count():
+    return lib().empc_device_count()
+
+
+def yaml_path(rel):
+    return os.path.join(YAML_DIR, rel)
+
+
+class Problem:
+    """ShootingProblem handle (flat EmpcProblemDesc)."""
+
+    def __init__(self, handle, owner):
+        self._h = C.c_void_p(handle)
+        self._owner = owner
+
+    @property
+    def desc(self):
+        p = lib().empc_problem_desc(self._h)
+        if not p:
+            raise EmpcError(lib().empc_last_error().decode())
+        return p.contents
+
+    @property
+    def T(self):
+        return self.desc.T
+
+    @property
+    def x0(self):
+        d = self.desc
+        return np.array([d.x0[i] for i in range(d.nx)])
+
+    @x0.setter
+    def x0(self, value):
+        v = np.ascontiguousarray(value, dtype=np.float64)
+        _check(lib().empc_problem_set_x0(self._h, _ptr(v)))
+
+    def __del__(self):
+        try:
+            lib().empc_problem_destroy(self._h)
+        except Exception:
+            pass
+
+
+class Trajectory:
+    """Mirror of eagle_mpc.Trajectory (bindings/python/eagle_mpc/trajectory.hpp:24-63)."""
+
+    def __init__(self):
+        self._h = None
+
+    def autoSetup(self, yaml_file):
+        h = lib().empc_trajectory_create(os.fspath(yaml_file).encode())
+        if not h:
+            raise EmpcError(lib().empc_last_error().decode())
+        self._h = C.c_void_p(h)
+        v = [C.c_int() for _ in range(6)]
+        _check(lib().empc_trajectory_dims(self._h, *[C.byref(x) for x in v]))
+        self.nx, self.ndx, self.nu, self.n_stages, hc, self.duration = [x.value for x in v]
+        self.has_contact = bool(hc)
+
+    def createProblem(self, dt=0, squash=True, integration_method="IntegratedActionModelEuler"):
+        h = lib().empc_trajectory_create_problem(self._h, int(dt), int(bool(squash)), integration_method.encode())
+        if not h:
+            raise EmpcError(lib().empc_last_error().decode())
+        return Problem(h, self)
+
+    @property
+    def initial_state(self):
+        x = np.zeros(self.nx)
+        _check(lib().empc_trajectory_get_initial_state(self._h, _ptr(x)))
+        return x
+
+    @initial_state.setter
+    def initial_state(self, value):
+        v = np.ascontiguousarray(value, dtype=np.float64)
+        assert v.shape == (self.nx,)
+        _check(lib().empc_trajectory_set_initial_state(self._h, _ptr(v)))
+
+    def platform(self):
+        n = C.c_int()
+        _check(lib().empc_trajectory_get_platform(self._h, None, None, None, C.byref(n)))
+        tau_f = np.zeros((6, n.value))
+        lb = np.zeros(self.nu)
+        ub = np.zeros(self.nu)
+        _check(lib().empc_trajectory_get_platform(self._h, _ptr(tau_f), _ptr(lb), _ptr(ub), C.byref(n)))
+        return tau_f, lb, ub
+
+    def stage_info(self, i):
+        name = C.create_string_buffer(64)
+        v = [C.c_int() for _ in range(4)]
+        _check(lib().empc_trajectory_stage_info(self._h, i, name, 64, *[C.byref(x) for x in v]))
+        return dict(name=name.value.decode(), duration=v[0].value, is_transition=bool(v[1].value), n_costs=v[2].value,
+                    n_contacts=v[3].value)
+
+    def get_param(self, key):
+        buf = C.create_string_buffer(4096)
+        n = lib().empc_trajectory_get_param(self._h, key.encode(), buf, 4096)
+        if n < 0:
+            raise KeyError(lib().empc_last_error().decode())
+        return buf.value.decode()
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().empc_trajectory_destroy(self._h)
+        except Exception:
+            pass
+
+
+def default_params():
+    p = T.SolverParams()
+    lib().empc_solver_params_default(C.byref(p))
+    return p
+
+
+class SolverSbFDDP:
+    """Batched mirror of eagle_mpc.SolverSbFDDP (bindings/python/eagle_mpc/sbfddp.hpp:24-80).
+
+    ``solve`` follows the reference signature; results are exposed both per batch (``xs_batch`` ...) and, for
+    trajectory 0, under the reference's property names (``xs``, ``us``, ``us_squash``, ``iter``, ``cost``).
+    """
+
+    def __init__(self, problem, batch=1, device=0, params=None):
+        self.problem = problem
+        self.batch = int(batch)
+        prm = params if params is not None else default_params()
+        h = lib().empc_solver_create(C.byref(problem.desc), C.byref(prm), self.batch, int(device))
+        if not h:
+            raise EmpcError(lib().empc_last_error().decode())
+        self._h = C.c_void_p(h)
+        v = [C.c_int() for _ in range(6)]
+        _check(lib().empc_solver_dims(self._h, *[C.byref(x) for x in v]))
+        _, self.T, self.nx, self.ndx, self.nu, self.rec = [x.value for x in v]
+        self._convergence_init = prm.convergence_init
+
+    # -- reference API -------------------------------------------------------------------------------------
+    def solve(self, init_xs=None, init_us=None, maxiter=100, is_feasible=False, regInit=1e-9, x0s=None):
+        B, T_, nx, nu = self.batch, self.T, self.nx, self.nu
+        if x0s is not None:
+            x0s = np.ascontiguousarray(x0s, dtype=np.float64).reshape(B, nx)
+        _check(lib().empc_solver_set_x0(self._h, _ptr(x0s)))
+        xs = us = None
+        if init_xs is not None and len(init_xs):
+            xs = np.ascontiguousarray(init_xs, dtype=np.float64)
+            if xs.shape == (T_ + 1, nx):
+                xs = np.ascontiguousarray(np.broadcast_to(xs, (B, T_ + 1, nx)))
+            assert xs.shape == (B, T_ + 1, nx)
+        if init_us is not None and len(init_us):
+            us = np.ascontiguousarray(init_us, dtype=np.float64)
+            if us.shape == (T_, nu):
+                us = np.ascontiguousarray(np.broadcast_to(us, (B, T_, nu)))
+            assert us.shape == (B, T_, nu)
+        _check(lib().empc_solver_set_warmstart(self._h, _ptr(xs), _ptr(us)))
+        _check(lib().empc_solver_solve(self._h, int(maxiter), int(bool(is_feasible))))
+        return True
+
+    @property
+    def convergence_init(self):
+        return self._convergence_init
+
+    @convergence_init.setter
+    def convergence_init(self, v):
+        _check(lib().empc_solver_set_convergence_init(self._h, float(v)))
+        self._convergence_init = float(v)
+
+    def update_problem(self):
+        _check(lib().empc_solver_update_problem(self._h, C.byref(self.problem.desc)))
+
+    def _get(self, name, shape):
+        a = np.zeros(shape)
+        _check(getattr(lib(), "empc_solver_get_" + name)(self._h, _ptr(a)))
+        return a
+
+    @property
+    def xs_batch(self):
+        return self._get("xs", (self.batch, self.T + 1, self.nx))
+
+    @property
+    def us_batch(self):
+        return self._get("us", (self.batch, self.T, self.nu))
+
+    @property
+    def us_squash_batch(self):
+        return self._get("us_squash", (self.batch, self.T, self.nu))
+
+    @property
+    def cost_batch(self):
+        return self._get("cost", (self.batch,))
+
+    @property
+    def stop_batch(self):
+        return self._get("stop", (self.batch,))
+
+    @property
+    def iter_batch(self):
+        a = np.zeros(self.batch, dtype=np.int32)
+        _check(lib().empc_solver_get_iters(self._h, _ptr(a, np.int32)))
+        return a
+
+    @property
+    def status_batch(self):
+        a = np.zeros(self.batch, dtype=np.int32)
+        _check(lib().empc_solver_get_status(self._h, _ptr(a, np.int32)))
+        return a
+
+    xs = property(lambda self: list(self.xs_batch[0]))
+    us = property(lambda self: list(self.us_batch[0]))
+    us_squash = property(lambda self: list(self.us_squash_batch[0]))
+    iter = property(lambda self: int(self.iter_batch[0]))
+    cost = property(lambda self: float(self.cost_batch[0]))
+    stop = property(lambda self: float(self.stop_batch[0]))
+
+    def stats(self):
+        s = T.SolveStats()
+        _check(lib().empc_solver_get_stats(self._h, C.byref(s)))
+        return {n: getattr(s, n) for n, _ in T.SolveStats._fields_}
+
+    # -- phase-level kernels (parity tests, roofline) -------------------------------------------------------
+    def tape_layout(self):
+        l = T.TapeLayout()
+        _check(lib().empc_tape_layout(self._h, C.byref(l)))
+        return {n: getattr(l, n) for n, _ in T.TapeLayout._fields_}
+
+    def linearize(self, xs, us, smooth=0.1, is_feasible=False, x0s=None, fetch=True):
+        B = self.batch
+        if x0s is not None:
+            _check(lib().empc_solver_set_x0(self._h, _ptr(np.ascontiguousarray(x0s, dtype=np.float64))))
+        xs = None if xs is None else np.ascontiguousarray(xs, dtype=np.float64)
+        us = None if us is None else np.ascontiguousarray(us, dtype=np.float64)
+        tape = np.zeros((B, self.T + 1, self.rec)) if fetch else None
+        _check(lib().empc_linearize_batch(self._h, _ptr(xs), _ptr(us), float(smooth), int(is_feasible), _ptr(tape), None, None))
+        return tape
+
+    def backward(self, xreg=1e-9, is_feasible=False):
+        B, T_, n, m = self.batch, self.T, self.ndx, self.nu
+        K = np.zeros((B, T_, m, n))
+        k = np.zeros((B, T_, m))
+        Vx = np.zeros((B, T_ + 1, n))
+        dgdq = np.zeros((B, 2))
+        ok = np.zeros(B, dtype=np.int32)
+        _check(lib().empc_backward_batch(self._h, float(xreg), int(is_feasible), _ptr(K), _ptr(k), _ptr(Vx), _ptr(dgdq),
+                                         _ptr(ok, np.int32)))
+        return K, k, Vx, dgdq, ok
+
+    def rollout(self, alpha, ddp=False, is_feasible=False):
+        B, T_ = self.batch, self.T
+        xs = np.zeros((B, T_ + 1, self.nx))
+        us = np.zeros((B, T_, self.nu))
+        cost = np.zeros(B)
+        ok = np.zeros(B, dtype=np.int32)
+        _check(lib().empc_rollout_batch(self._h, float(alpha), int(ddp), int(is_feasible), _ptr(xs), _ptr(us), _ptr(cost),
+                                        _ptr(ok, np.int32)))
+        return xs, us, cost, ok
+
+    def __del__(self):
+        try:
+            lib().empc_solver_destroy(self._h)
+        except Exception:
+            pass
+
+
+def perturbed_x0s(x0, batch, nq, seed=0, amplitude=0.05, joint_lb=None, joint_ub=None):
+    """Batch of initial states: element 0 is x0, elements b >= 1 follow the reference's perturbation recipe
+    x0 += 0.05 U(-1,1), quaternion renormalised (benchmark/utils/utils.hpp:15-27)."""
+    x0 = np.asarray(x0, dtype=np.float64)
+    out = np.tile(x0, (batch, 1))
+    for b in range(1, batch):
+        rng = np.random.default_rng(seed * 1000003 + b)
+        out[b] += amplitude * rng.uniform(-1, 1, size=x0.shape)
+        out[b, 3:7] /= np.linalg.norm(out[b, 3:7])
+    return out

@@ -87,7 +87,7 @@ EMPC_HD void inertia_apply(const EmpcModelDesc& m, int b, const S* mot, S* out) 
 
 // Operational-frame capture: placement and LOCAL velocity / acceleration of up to NCAP frames, filled during the
 // forward recursion when the recursion reaches the frame's body.
-constexpr int NCAP = 3;
+constexpr int NCAP = 2;
 template <class S>
 struct FrameCap {
   S R[9], p[3];  // world placement
@@ -192,8 +192,9 @@ EMPC_HD void rnea_chain(const EmpcModelDesc& m, const S* R0, const S* p0, const 
       }
     }
     // frame captures on this body
-    for (int c = 0; c < ncap; ++c)
-      if (m.frame_body[cap_frames[c]] == b) frame_capture<S>(m, cap_frames[c], Rw, pw, vb, ab, caps[c]);
+#pragma unroll
+    for (int c = 0; c < NCAP; ++c)
+      if (c < ncap && m.frame_body[cap_frames[c]] == b) frame_capture<S>(m, cap_frames[c], Rw, pw, vb, ab, caps[c]);
     // f_b = I a + v x* (I v) - fext
     S Ia[6], Iv[6], c1[3], c2[3], c3[3];
     inertia_apply<S>(m, b, ab, Ia);
@@ -531,14 +532,20 @@ EMPC_HD void node_nominal(const DevProblem& P, const EmpcCostSet& set, double sm
     cs[b - 1] = cos(q[7 + b - 1]);
   }
   // frames referenced by this node's costs / contacts
-  int capf[NCAP];
+  int capf[NCAP] = {0, 0};
   int ncap = 0;
   for (int ci = 0; ci < set.ncosts; ++ci) {
     const EmpcCost& c = set.costs[ci];
     if (!c.active || c.frame < 0 || c.type == EMPC_COST_CONTACT_FRICTION_CONE) continue;
     bool seen = false;
-    for (int k = 0; k < ncap; ++k) seen = seen || (capf[k] == c.frame);
-    if (!seen && ncap < NCAP) capf[ncap++] = c.frame;
+#pragma unroll
+    for (int k = 0; k < NCAP; ++k) seen = seen || (k < ncap && capf[k] == c.frame);
+    if (!seen) {
+#pragma unroll
+      for (int k = 0; k < NCAP; ++k)
+        if (k == ncap) capf[k] = c.frame;
+      ncap = (ncap < NCAP) ? ncap + 1 : ncap;
+    }
   }
   FrameCap<double> caps[NCAP];
   // bias forces h = RNEA(q, v, 0)
@@ -669,10 +676,10 @@ EMPC_HD void node_nominal(const DevProblem& P, const EmpcCostSet& set, double sm
         cval += av;
       }
     } else {
-      int k = 0;
-      for (int kk = 0; kk < ncap; ++kk)
-        if (capf[kk] == c.frame) k = kk;
-      const FrameCap<double>& fk = caps[k];
+      FrameCap<double> fk = caps[0];
+#pragma unroll
+      for (int kk = 1; kk < NCAP; ++kk)
+        if (kk < ncap && capf[kk] == c.frame) fk = caps[kk];
       double r[6];
       int nr = 6;
       if (c.type == EMPC_COST_FRAME_PLACEMENT) {

@@ -1,0 +1,144 @@
+// empc_prep.hpp -- host-side preparation of the device problem image (pure C++, no HIP).
+//   * copies the flat descriptor into DevProblem + cost-set table + knot table
+//   * SolverSbFDDP::barrierInit (src/sbfddp.cpp:169-190): adds the "barrier" cost to the cost table of every distinct
+//     running model, keeping the table in std::map (alphabetical) order
+//   * validates that the problem fits what the kernels are built for
+#pragma once
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "empc_kernels.hpp"
+
+namespace empc {
+
+struct HostProblem {
+  DevProblem P;
+  std::vector<EmpcCostSet> sets;
+  std::vector<int> knot_set;
+  std::vector<double> x0;
+};
+
+inline void insert_barrier(EmpcCostSet& s, const DevProblem& P) {
+  for (int i = 0; i < s.ncosts; ++i)
+    if (std::strcmp(s.costs[i].name, "barrier") == 0) return;
+  if (s.ncosts >= EMPC_MAX_COSTS) throw std::runtime_error("no room for the barrier cost in a cost set");
+  EmpcCost c;
+  std::memset(&c, 0, sizeof(c));
+  std::strcpy(c.name, "barrier");
+  c.type = EMPC_COST_CONTROL;
+  c.activation = EMPC_ACT_WEIGHTED_QUADRATIC_BARRIER;
+  c.active = 1;
+  c.frame = -1;
+  c.nr = P.nu;
+  c.is_barrier = 1;
+  c.weight = P.prm.barrier_weight;
+  for (int i = 0; i < P.nu; ++i) {
+    c.lb[i] = P.u_lb[i];  // s_lb = u_lb, s_ub = u_ub (SquashingModelSmoothSat)
+    c.ub[i] = P.u_ub[i];
+    c.act_w[i] = 1.0;     // replaced on the device by 1/(smooth (ub-lb))^2 of the trajectory's current pass
+  }
+  int pos = 0;
+  while (pos < s.ncosts && std::strcmp(s.costs[pos].name, "barrier") < 0) ++pos;
+  for (int i = s.ncosts; i > pos; --i) s.costs[i] = s.costs[i - 1];
+  s.costs[pos] = c;
+  s.ncosts++;
+}
+
+inline void prepare_problem(const EmpcProblemDesc& d, const EmpcSolverParams& prm, HostProblem& H) {
+  if (!d.sets || !d.knot_set) throw std::invalid_argument("problem descriptor has no cost-set / knot tables");
+  if (d.T < 1) throw std::invalid_argument("problem needs at least one running knot");
+  if (d.integrator != EMPC_INTEGRATOR_EULER)
+    throw std::runtime_error("only IntegratedActionModelEuler is implemented on the device");
+  const EmpcModelDesc& m = d.model;
+  for (int b = 1; b < m.nbodies; ++b)
+    if (m.parent[b] != b - 1) throw std::runtime_error("the device kernels need a serial kinematic chain");
+  if (d.nu != d.n_rotors + m.nv - 6 || d.nx != m.nq + m.nv || d.ndx != 2 * m.nv)
+    throw std::invalid_argument("inconsistent problem dimensions");
+  if (d.nu > m.nv) throw std::runtime_error("more controls than velocity dimensions is not supported by the kernels");
+  if (prm.n_alphas < 1 || prm.n_alphas > MAX_ALPHAS) throw std::invalid_argument("n_alphas out of range");
+  std::memset(&H.P, 0, sizeof(H.P));
+  H.P.model = m;
+  H.P.nx = d.nx;
+  H.P.ndx = d.ndx;
+  H.P.nu = d.nu;
+  H.P.n_rotors = d.n_rotors;
+  H.P.T = d.T;
+  H.P.n_sets = d.n_sets;
+  H.P.has_contact = d.has_contact;
+  H.P.use_squash = d.use_squash;
+  H.P.dt = d.dt;
+  std::memcpy(H.P.tau_f, d.tau_f, sizeof(d.tau_f));
+  std::memcpy(H.P.u_lb, d.u_lb, sizeof(d.u_lb));
+  std::memcpy(H.P.u_ub, d.u_ub, sizeof(d.u_ub));
+  H.P.prm = prm;
+  H.sets.assign(d.sets, d.sets + d.n_sets);
+  H.knot_set.assign(d.knot_set, d.knot_set + d.T + 1);
+  H.x0.assign(d.x0, d.x0 + d.nx);
+  for (int t = 0; t <= d.T; ++t)
+    if (H.knot_set[t] < 0 || H.knot_set[t] >= d.n_sets) throw std::invalid_argument("knot table references a missing cost set");
+  // barrierInit: once per distinct running model
+  {
+    std::vector<char> done(H.sets.size(), 0);
+    for (int t = 0; t < d.T; ++t) {
+      const int si = H.knot_set[t];
+      if (done[si]) continue;
+      done[si] = 1;
+      insert_barrier(H.sets[si], H.P);
+    }
+  }
+  // frame-capture capacity per cost set
+  for (const auto& s : H.sets) {
+    int frames[EMPC_MAX_COSTS], nf = 0;
+    for (int i = 0; i < s.ncosts; ++i) {
+      const EmpcCost& c = s.costs[i];
+      if (!c.active || c.frame < 0 || c.type == EMPC_COST_CONTACT_FRICTION_CONE) continue;
+      if (c.frame >= m.nframes) throw std::invalid_argument("cost references a frame outside the model's frame table");
+      bool seen = false;
+      for (int k = 0; k < nf; ++k) seen = seen || frames[k] == c.frame;
+      if (!seen) frames[nf++] = c.frame;
+    }
+    if (nf > NCAP) throw std::runtime_error("a cost set references more distinct frames than the kernels capture");
+    if (s.ncontacts > 1) throw std::runtime_error("more than one contact per stage is not supported by the kernels");
+  }
+}
+
+}  // namespace empc
+
+namespace empc {
+// State of one trajectory at the start of SolverSbFDDP::solve (src/sbfddp.cpp:198-210).  `prev` carries the members
+// that the reference keeps across solve() calls (cost_, cost_prev_, stop_).
+inline void init_traj_state(TrajState& s, const EmpcSolverParams& prm, int maxiter, bool is_feasible_arg,
+                            const TrajState* prev) {
+  TrajState z;
+  std::memset(&z, 0, sizeof(z));
+  if (prev) {
+    z.cost = prev->cost;
+    z.cost_prev = prev->cost_prev;
+    z.stop = prev->stop;
+    z.gapnorm = prev->gapnorm;
+  }
+  z.maxiter = maxiter;
+  z.smooth = z.smooth_next = prm.smooth_init;
+  z.convergence = prm.convergence_init;
+  z.th_stop = prm.convergence_init;
+  z.xreg = z.ureg = prm.reg_init;
+  z.steplength = 1.0;
+  z.need_calc = 1;
+  z.need_lin = 1;
+  if (prm.convergence_init >= prm.convergence_stop) {
+    z.phase = 0;
+    z.is_feasible = 0;  // solveFDDP(maxiter, false, reg_init_)
+  } else if (!is_feasible_arg) {
+    z.phase = PHASE_DDP;
+    z.is_feasible = 0;
+    z.status |= EMPC_STATUS_DDP_CLEANUP;
+  } else {
+    z.phase = PHASE_DONE;
+    z.is_feasible = 1;
+    z.iter = -1;
+  }
+  s = z;
+}
+}  // namespace empc

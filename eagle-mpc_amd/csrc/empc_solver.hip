@@ -1,0 +1,683 @@
+// empc_solver.hip -- HIP kernels (gfx950) + host driver + solver part of the C ABI (include/empc.h).
+//
+// One solve = a sequence of "sweeps"; in every sweep each still-active trajectory advances by exactly one DDP
+// iteration of its current pass (FDDP pass, or the DDP clean-up):
+//     calc (phase starts only) -> linearize -> backward -> rollout (all step lengths at once) -> select
+// All per-trajectory solver state lives on the device (TrajState); the host only reads back the number of
+// trajectories that are still active after each sweep.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/empc.h"
+#include "empc_internal.hpp"
+#include "empc_prep.hpp"
+
+using namespace empc;
+
+#define HIP_CHECK(expr)                                                                                   \
+  do {                                                                                                    \
+    hipError_t _e = (expr);                                                                               \
+    if (_e != hipSuccess)                                                                                 \
+      throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(_e) + " at " #expr);        \
+  } while (0)
+
+// --------------------------------------------------------------------------------------------------------------------
+// kernels
+// --------------------------------------------------------------------------------------------------------------------
+template <class DM>
+__global__ void __launch_bounds__(64) k_calc(DevBuffers D) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = D.B * (D.T + 1);
+  if (idx >= n) return;
+  // consecutive lanes = consecutive trajectories of the same node (same cost set -> no divergence)
+  const int t = idx / D.B, b = idx % D.B;
+  calc_thread<DM>(D, b, t);
+}
+
+template <class DM>
+__global__ void __launch_bounds__(64) k_rollout(DevBuffers D) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= D.B * D.NA) return;
+  const int b = idx / D.NA, ai = idx % D.NA;
+  rollout_thread<DM>(D, b, ai);
+}
+
+template <class DM, int LPU>
+__global__ void __launch_bounds__(128) k_linearize(DevBuffers D) {
+  extern __shared__ double smem_lin[];
+  constexpr int UPB = 128 / LPU;  // units per block
+  const int unit = blockIdx.x * UPB + threadIdx.x / LPU;
+  const int lane = threadIdx.x % LPU;
+  const int n_units = D.B * (D.T + 1);
+  if (unit >= n_units) return;
+  const int t = unit / D.B, b = unit % D.B;
+  const TrajState& st = D.st[b];
+  if (st.phase == PHASE_DONE || !st.need_lin) return;
+  LaneExec ex{lane};
+  linearize_unit<DM>(ex, D, b, t, LPU, smem_lin + (size_t)(threadIdx.x / LPU) * LinSmem<DM>::SIZE);
+}
+
+template <class DM>
+__global__ void __launch_bounds__(64) k_backward(DevBuffers D) {
+  extern __shared__ double smem_bwd[];
+  const int b = blockIdx.x;
+  LaneExec ex{(int)threadIdx.x};
+  backward_traj<DM>(ex, D, b, smem_bwd);
+}
+
+template <class DM>
+__global__ void __launch_bounds__(64) k_select(DevBuffers D) {
+  __shared__ int sh[2];
+  const int b = blockIdx.x;
+  if (threadIdx.x == 0) {
+    int acc_ai, last_ai;
+    select_decide<DM>(D, b, acc_ai, last_ai);
+    sh[0] = acc_ai;
+    sh[1] = last_ai;
+    if (D.st[b].phase != PHASE_DONE) atomicAdd(D.n_active, 1);
+  }
+  __syncthreads();
+  select_copy<DM>(D, b, sh[0], sh[1], threadIdx.x, blockDim.x);
+}
+
+// us_squash[b][t] = sigma(us_last[b][t]) with the trajectory's final smooth (fillSquashedOutputs, src/sbfddp.cpp:479-486)
+template <class DM>
+__global__ void k_squash_out(DevBuffers D, double* out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = D.B * D.T * DM::NU;
+  if (idx >= n) return;
+  const int b = idx / (D.T * DM::NU), i = idx % DM::NU;
+  const DevProblem& P = *D.P;
+  double u = D.us_last[idx], du;
+  if (P.use_squash) squash1(D.us_last[idx], P.u_lb[i], P.u_ub[i], D.st[b].smooth, P.prm.smoothsat_power, u, du);
+  out[idx] = u;
+}
+
+// --------------------------------------------------------------------------------------------------------------------
+// solver object
+// --------------------------------------------------------------------------------------------------------------------
+struct KernelTable {
+  void (*calc)(DevBuffers, hipStream_t);
+  void (*linearize)(DevBuffers, hipStream_t);
+  void (*backward)(DevBuffers, hipStream_t);
+  void (*rollout)(DevBuffers, hipStream_t);
+  void (*select)(DevBuffers, hipStream_t);
+  void (*squash_out)(DevBuffers, double*, hipStream_t);
+  int nx, ndx, nu, nv, rec;
+  int off[9];
+};
+
+template <class DM>
+static void launch_calc(DevBuffers D, hipStream_t s) {
+  const int n = D.B * (D.T + 1);
+  hipLaunchKernelGGL(k_calc<DM>, dim3((n + 63) / 64), dim3(64), 0, s, D);
+}
+template <class DM>
+static void launch_linearize(DevBuffers D, hipStream_t s) {
+  constexpr int LPU = (3 * DM::NV <= 32) ? 32 : 64;
+  constexpr int UPB = 128 / LPU;
+  const int n = D.B * (D.T + 1);
+  const size_t smem = sizeof(double) * LinSmem<DM>::SIZE * UPB;
+  hipLaunchKernelGGL((k_linearize<DM, LPU>), dim3((n + UPB - 1) / UPB), dim3(128), smem, s, D);
+}
+template <class DM>
+static void launch_backward(DevBuffers D, hipStream_t s) {
+  hipLaunchKernelGGL(k_backward<DM>, dim3(D.B), dim3(64), sizeof(double) * BwdSmem<DM>::SIZE, s, D);
+}
+template <class DM>
+static void launch_rollout(DevBuffers D, hipStream_t s) {
+  const int n = D.B * D.NA;
+  hipLaunchKernelGGL(k_rollout<DM>, dim3((n + 63) / 64), dim3(64), 0, s, D);
+}
+template <class DM>
+static void launch_select(DevBuffers D, hipStream_t s) {
+  hipLaunchKernelGGL(k_select<DM>, dim3(D.B), dim3(64), 0, s, D);
+}
+template <class DM>
+static void launch_squash_out(DevBuffers D, double* out, hipStream_t s) {
+  const int n = D.B * D.T * DM::NU;
+  hipLaunchKernelGGL(k_squash_out<DM>, dim3((n + 255) / 256), dim3(256), 0, s, D, out);
+}
+template <class DM>
+static KernelTable make_table() {
+  KernelTable k;
+  k.calc = launch_calc<DM>;
+  k.linearize = launch_linearize<DM>;
+  k.backward = launch_backward<DM>;
+  k.rollout = launch_rollout<DM>;
+  k.select = launch_select<DM>;
+  k.squash_out = launch_squash_out<DM>;
+  k.nx = DM::NX;
+  k.ndx = DM::NDX;
+  k.nu = DM::NU;
+  k.nv = DM::NV;
+  k.rec = DM::REC;
+  const int off[9] = {DM::OFF_FX, DM::OFF_FU, DM::OFF_LXX, DM::OFF_LXU, DM::OFF_LUU, DM::OFF_LX, DM::OFF_LU, DM::OFF_GAP, DM::OFF_COST};
+  std::memcpy(k.off, off, sizeof(off));
+  return k;
+}
+static bool find_table(int nb, int nrot, KernelTable& k) {
+  if (nb == 1 && nrot == 4) k = make_table<Dims<1, 4>>();
+  else if (nb == 1 && nrot == 6) k = make_table<Dims<1, 6>>();
+  else if (nb == 3 && nrot == 6) k = make_table<Dims<3, 6>>();
+  else if (nb == 4 && nrot == 6) k = make_table<Dims<4, 6>>();
+  else if (nb == 6 && nrot == 6) k = make_table<Dims<6, 6>>();
+  else return false;
+  return true;
+}
+
+struct EmpcSolver {
+  HostProblem H;
+  KernelTable kt;
+  int device = 0, B = 0, T = 0, NA = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[8] = {};
+  DevBuffers D;
+  DevProblem* dP = nullptr;
+  EmpcCostSet* dsets = nullptr;
+  int* dknot = nullptr;
+  double* dscratch = nullptr;  // output staging (squashed controls)
+  int* h_active = nullptr;     // pinned
+  std::vector<TrajState> h_st;
+  bool have_state = false;
+  EmpcSolveStats stats;
+  std::vector<void*> allocs;
+
+  template <class Tt>
+  Tt* dalloc(size_t n) {
+    void* p = nullptr;
+    HIP_CHECK(hipMalloc(&p, n * sizeof(Tt)));
+    allocs.push_back(p);
+    return static_cast<Tt*>(p);
+  }
+  void use() { HIP_CHECK(hipSetDevice(device)); }
+  ~EmpcSolver() {
+    if (hipSetDevice(device) != hipSuccess) return;
+    for (void* p : allocs) (void)hipFree(p);
+    if (h_active) (void)hipHostFree(h_active);
+    for (auto& e : ev)
+      if (e) (void)hipEventDestroy(e);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+static void upload_problem(EmpcSolver* s) {
+  HIP_CHECK(hipMemcpyAsync(s->dP, &s->H.P, sizeof(DevProblem), hipMemcpyHostToDevice, s->stream));
+  HIP_CHECK(hipMemcpyAsync(s->dsets, s->H.sets.data(), sizeof(EmpcCostSet) * s->H.sets.size(), hipMemcpyHostToDevice, s->stream));
+  HIP_CHECK(hipMemcpyAsync(s->dknot, s->H.knot_set.data(), sizeof(int) * s->H.knot_set.size(), hipMemcpyHostToDevice, s->stream));
+  HIP_CHECK(hipStreamSynchronize(s->stream));
+}
+
+static void upload_states(EmpcSolver* s) {
+  HIP_CHECK(hipMemcpyAsync(s->D.st, s->h_st.data(), sizeof(TrajState) * s->B, hipMemcpyHostToDevice, s->stream));
+}
+static void download_states(EmpcSolver* s) {
+  HIP_CHECK(hipMemcpyAsync(s->h_st.data(), s->D.st, sizeof(TrajState) * s->B, hipMemcpyDeviceToHost, s->stream));
+  HIP_CHECK(hipStreamSynchronize(s->stream));
+}
+
+#define EMPC_TRY try {
+#define EMPC_CATCH(ret)                          \
+  }                                              \
+  catch (const std::invalid_argument& e) {       \
+    empc::set_last_error(e.what());              \
+    return ret(EMPC_ERR_INVALID);                \
+  }                                              \
+  catch (const std::exception& e) {              \
+    empc::set_last_error(e.what());              \
+    return ret(EMPC_ERR_RUNTIME);                \
+  }                                              \
+  catch (...) {                                  \
+    empc::set_last_error("unknown exception");   \
+    return ret(EMPC_ERR_RUNTIME);                \
+  }
+#define RET_INT(x) (x)
+#define RET_NULL(x) nullptr
+
+extern "C" {
+
+int empc_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+EmpcSolver* empc_solver_create(const EmpcProblemDesc* problem, const EmpcSolverParams* params, int batch, int device) {
+  EmpcSolver* s = nullptr;
+  EMPC_TRY
+  if (!problem) throw std::invalid_argument("problem is NULL");
+  if (batch < 1) throw std::invalid_argument("batch must be >= 1");
+  EmpcSolverParams prm;
+  if (params)
+    prm = *params;
+  else
+    empc_solver_params_default(&prm);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    throw std::runtime_error("no HIP device available: the batched SbFDDP solver has no CPU fallback");
+  if (device < 0 || device >= ndev) throw std::invalid_argument("device index out of range");
+  s = new EmpcSolver();
+  s->device = device;
+  prepare_problem(*problem, prm, s->H);
+  if (!find_table(problem->model.nbodies, problem->n_rotors, s->kt)) {
+    delete s;
+    empc::set_last_error("no kernel instantiation for this (bodies, rotors) combination");
+    return nullptr;
+  }
+  s->use();
+  s->B = batch;
+  s->T = problem->T;
+  s->NA = prm.n_alphas;
+  HIP_CHECK(hipStreamCreate(&s->stream));
+  for (auto& e : s->ev) HIP_CHECK(hipEventCreate(&e));
+  HIP_CHECK(hipHostMalloc((void**)&s->h_active, sizeof(int)));
+  const size_t B = batch, T = s->T, NA = s->NA;
+  const KernelTable& k = s->kt;
+  s->dP = s->dalloc<DevProblem>(1);
+  s->dsets = s->dalloc<EmpcCostSet>(s->H.sets.size());
+  s->dknot = s->dalloc<int>(T + 1);
+  DevBuffers& D = s->D;
+  D.P = s->dP;
+  D.sets = s->dsets;
+  D.knot_set = s->dknot;
+  D.st = s->dalloc<TrajState>(B);
+  D.x0 = s->dalloc<double>(B * k.nx);
+  D.xs = s->dalloc<double>(B * (T + 1) * k.nx);
+  D.us = s->dalloc<double>(B * T * k.nu);
+  D.acc = s->dalloc<double>(B * (T + 1) * k.nv);
+  D.tape = s->dalloc<double>(B * (T + 1) * k.rec);
+  D.K = s->dalloc<double>(B * T * k.nu * k.ndx);
+  D.kff = s->dalloc<double>(B * T * k.nu);
+  D.Vx = s->dalloc<double>(B * (T + 1) * k.ndx);
+  D.Vf = s->dalloc<double>(B * (T + 1) * k.ndx);
+  D.xs_try = s->dalloc<double>(B * NA * (T + 1) * k.nx);
+  D.us_try = s->dalloc<double>(B * NA * T * k.nu);
+  D.acc_try = s->dalloc<double>(B * NA * (T + 1) * k.nv);
+  D.try_cost = s->dalloc<double>(B * NA);
+  D.try_dv = s->dalloc<double>(B * NA);
+  D.try_ok = s->dalloc<int>(B * NA);
+  D.us_last = s->dalloc<double>(B * T * k.nu);
+  D.n_active = s->dalloc<int>(1);
+  D.B = batch;
+  D.T = s->T;
+  D.NA = s->NA;
+  D.gaptol = std::max(prm.th_gaptol, 1e-13);
+  s->dscratch = s->dalloc<double>(B * T * k.nu);
+  HIP_CHECK(hipMemsetAsync(D.tape, 0, sizeof(double) * B * (T + 1) * k.rec, s->stream));
+  HIP_CHECK(hipMemsetAsync(D.us_last, 0, sizeof(double) * B * T * k.nu, s->stream));
+  HIP_CHECK(hipMemsetAsync(D.acc, 0, sizeof(double) * B * (T + 1) * k.nv, s->stream));
+  upload_problem(s);
+  s->h_st.assign(B, TrajState());
+  std::memset(s->h_st.data(), 0, sizeof(TrajState) * B);
+  std::memset(&s->stats, 0, sizeof(s->stats));
+  if (empc_solver_set_x0(s, nullptr) != EMPC_OK || empc_solver_set_warmstart(s, nullptr, nullptr) != EMPC_OK)
+    throw std::runtime_error(empc_last_error());
+  return s;
+  }
+  catch (const std::exception& e) {
+    empc::set_last_error(e.what());
+    delete s;
+    return nullptr;
+  }
+}
+
+void empc_solver_destroy(EmpcSolver* s) { delete s; }
+
+int empc_solver_dims(const EmpcSolver* s, int* batch, int* T, int* nx, int* ndx, int* nu, int* rec_doubles) {
+  if (!s) return EMPC_ERR_INVALID;
+  if (batch) *batch = s->B;
+  if (T) *T = s->T;
+  if (nx) *nx = s->kt.nx;
+  if (ndx) *ndx = s->kt.ndx;
+  if (nu) *nu = s->kt.nu;
+  if (rec_doubles) *rec_doubles = s->kt.rec;
+  return EMPC_OK;
+}
+int empc_tape_layout(const EmpcSolver* s, EmpcTapeLayout* l) {
+  if (!s || !l) return EMPC_ERR_INVALID;
+  l->rec = s->kt.rec;
+  l->off_fx = s->kt.off[0];
+  l->off_fu = s->kt.off[1];
+  l->off_lxx = s->kt.off[2];
+  l->off_lxu = s->kt.off[3];
+  l->off_luu = s->kt.off[4];
+  l->off_lx = s->kt.off[5];
+  l->off_lu = s->kt.off[6];
+  l->off_gap = s->kt.off[7];
+  l->off_cost = s->kt.off[8];
+  return EMPC_OK;
+}
+
+int empc_solver_update_problem(EmpcSolver* s, const EmpcProblemDesc* problem) {
+  EMPC_TRY
+  if (!s || !problem) throw std::invalid_argument("NULL argument");
+  if (problem->T != s->T || problem->nx != s->kt.nx || problem->nu != s->kt.nu || problem->n_sets != (int)s->H.sets.size())
+    throw std::invalid_argument("update_problem: shapes differ from the problem the solver was created with");
+  s->use();
+  const EmpcSolverParams prm = s->H.P.prm;
+  prepare_problem(*problem, prm, s->H);
+  upload_problem(s);
+  return EMPC_OK;
+  EMPC_CATCH(RET_INT)
+}
+
+int empc_solver_set_x0(EmpcSolver* s, const double* x0s) {
+  EMPC_TRY
+  if (!s) throw std::invalid_argument("solver is NULL");
+  s->use();
+  const size_t nx = s->kt.nx;
+  if (x0s) {
+    HIP_CHECK(hipMemcpyAsync(s->D.x0, x0s, sizeof(double) * s->B * nx, hipMemcpyHostToDevice, s->stream));
+  } else {
+    std::vector<double> tmp((size_t)s->B * nx);
+    for (int b = 0; b < s->B; ++b) std::memcpy(&tmp[b * nx], s->H.x0.data(), sizeof(double) * nx);
+    HIP_CHECK(hipMemcpyAsync(s->D.x0, tmp.data(), sizeof(double) * tmp.size(), hipMemcpyHostToDevice, s->stream));
+  }
+  HIP_CHECK(hipStreamSynchronize(s->stream));
+  return EMPC_OK;
+  EMPC_CATCH(RET_INT)
+}
+
+int empc_solver_set_warmstart(EmpcSolver* s, const double* xs, const double* us) {
+  EMPC_TRY
+  if (!s) throw std::invalid_argument("solver is NULL");
+  s->use();
+  const size_t nx = s->kt.nx, nu = s->kt.nu, T = s->T, B = s->B;
+  if (xs) {
+    HIP_CHECK(hipMemcpyAsync(s->D.xs, xs, sizeof(double) * B * (T + 1) * nx, hipMemcpyHostToDevice, s->stream));
+  } else {
+    std::vector<double> tmp(B * (T + 1) * nx, 0.0);  // state->zero() at every node (crocoddyl setCandidate)
+    for (size_t i = 0; i < B * (T + 1); ++i) tmp[i * nx + 6] = 1.0;
+    HIP_CHECK(hipMemcpyAsync(s->D.xs, tmp.data(), sizeof(double) * tmp.size(), hipMemcpyHostToDevice, s->stream));
+    HIP_CHECK(hipStreamSynchronize(s->stream));
+  }
+  if (us)
+    HIP_CHECK(hipMemcpyAsync(s->D.us, us, sizeof(double) * B * T * nu, hipMemcpyHostToDevice, s->stream));
+  else
+    HIP_CHECK(hipMemsetAsync(s->D.us, 0, sizeof(double) * B * T * nu, s->stream));
+  HIP_CHECK(hipStreamSynchronize(s->stream));
+  return EMPC_OK;
+  EMPC_CATCH(RET_INT)
+}
+
+int empc_solver_set_convergence_init(EmpcSolver* s, double c) {
+  EMPC_TRY
+  if (!s) throw std::invalid_argument("solver is NULL");
+  s->use();
+  s->H.P.prm.convergence_init = c;
+  HIP_CHECK(hipMemcpyAsync(s->dP, &s->H.P, sizeof(DevProblem), hipMemcpyHostToDevice, s->stream));
+  HIP_CHECK(hipStreamSynchronize(s->stream));
+  return EMPC_OK;
+  EMPC_CATCH(RET_INT)
+}
+
+static void timed(EmpcSolver* s, int slot, double& acc_ms) {
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, s->ev[slot], s->ev[slot + 1]) == hipSuccess) acc_ms += ms;
+}
+
+int empc_solver_solve(EmpcSolver* s, int maxiter, int is_feasible) {
+  EMPC_TRY
+  if (!s) throw std::invalid_argument("solver is NULL");
+  if (maxiter < 1) throw std::invalid_argument("maxiter must be >= 1");
+  s->use();
+  for (int b = 0; b < s->B; ++b) {
+    TrajState prev = s->h_st[b];
+    init_traj_state(s->h_st[b], s->H.P.prm, maxiter, is_feasible != 0, s->have_state ? &prev : nullptr);
+  }
+  upload_states(s);
+  EmpcSolveStats& S = s->stats;
+  std::memset(&S, 0, sizeof(S));
+  hipEvent_t t_begin, t_end;
+  HIP_CHECK(hipEventCreate(&t_begin));
+  HIP_CHECK(hipEventCreate(&t_end));
+  HIP_CHECK(hipEventRecord(t_begin, s->stream));
+  const DevBuffers& D = s->D;
+  const KernelTable& k = s->kt;
+  const int hard_cap = 3 * (maxiter + 1) + 8;  // (passes + clean-up) x maxiter can never be exceeded
+  int active = s->B;
+  bool first = true;
+  while (active > 0 && S.sweeps < hard_cap * 4) {
+    HIP_CHECK(hipMemsetAsync(D.n_active, 0, sizeof(int), s->stream));
+    HIP_CHECK(hipEventRecord(s->ev[0], s->stream));
+    k.calc(D, s->stream);
+    HIP_CHECK(hipEventRecord(s->ev[1], s->stream));
+    k.linearize(D, s->stream);
+    HIP_CHECK(hipEventRecord(s->ev[2], s->stream));
+    k.backward(D, s->stream);
+    HIP_CHECK(hipEventRecord(s->ev[3], s->stream));
+    k.rollout(D, s->stream);
+    HIP_CHECK(hipEventRecord(s->ev[4], s->stream));
+    k.select(D, s->stream);
+    HIP_CHECK(hipEventRecord(s->ev[5], s->stream));
+    HIP_CHECK(hipMemcpyAsync(s->h_active, D.n_active, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    HIP_CHECK(hipStreamSynchronize(s->stream));
+    HIP_CHECK(hipGetLastError());
+    timed(s, 0, S.ms_calc);
+    timed(s, 1, S.ms_linearize);
+    timed(s, 2, S.ms_backward);
+    timed(s, 3, S.ms_rollout);
+    timed(s, 4, S.ms_select);
+    S.n_calc++;
+    S.n_linearize++;
+    S.n_backward++;
+    S.n_rollout++;
+    S.n_select++;
+    S.backward_units += (long long)active * s->T;
+    S.rollout_units += (long long)active * s->NA * (s->T + 1);
+    S.linearize_units += (long long)active * (s->T + 1);  // upper bound: trajectories that re-linearize this sweep
+    S.sweeps++;
+    active = *s->h_active;
+    first = false;
+  }
+  (void)first;
+  HIP_CHECK(hipEventRecord(t_end, s->stream));
+  download_states(s);
+  float ms = 0;
+  HIP_CHECK(hipEventElapsedTime(&ms, t_begin, t_end));
+  S.ms_total = ms;
+  (void)hipEventDestroy(t_begin);
+  (void)hipEventDestroy(t_end);
+  s->have_state = true;
+  for (int b = 0; b < s->B; ++b) {
+    S.total_iters += s->h_st[b].total_iters;
+    S.max_iters = std::max(S.max_iters, s->h_st[b].total_iters);
+  }
+  if (active > 0) throw std::runtime_error("solve did not terminate within the sweep cap (internal error)");
+  return EMPC_OK;
+  EMPC_CATCH(RET_INT)
+}
+
+static int copy_out(EmpcSolver* s, const void* dsrc, void* hdst, size_t bytes) {
+  EMPC_TRY
+  if (!s || !hdst) throw std::invalid_argument("NULL argument");
+  s->use();
+  HIP_CHECK(hipMemcpyAsync(hdst, dsrc, bytes, hipMemcpyDeviceToHost, s->stream));
+  HIP_CHECK(hipStreamSynchronize(s->stream));
+  return EMPC_OK;
+  EMPC_CATCH(RET_INT)
+}
+int empc_solver_get_xs(EmpcSolver* s, double* xs) {
+  if (!s) return EMPC_ERR_INVALID;
+  return copy_out(s, s->D.xs, xs, sizeof(double) * s->B * (s->T + 1) * s->kt.nx);
+}
+int empc_solver_get_us(EmpcSolver* s, double* us) {
+  if (!s) return EMPC_ERR_INVALID;
+  return copy_out(s, s->D.us, us, sizeof(double) * s->B * s->T * s->kt.nu);
+}
+int empc_solver_get_us_squash(EmpcSolver* s, double* out) {
+  EMPC_TRY
+  if (!s || !out) throw std::invalid_argument("NULL argument");
+  s->use();
+  s->kt.squash_out(s->D, s->dscratch, s->stream);
+  HIP_CHECK(hipMemcpyAsync(out, s->dscratch, sizeof(double) * s->B * s->T * s->kt.nu, hipMemcpyDeviceToHost, s->stream));
+  HIP_CHECK(hipStreamSynchronize(s->stream));
+  return EMPC_OK;
+  EMPC_CATCH(RET_INT)
+}
+int empc_solver_get_cost(EmpcSolver* s, double* cost) {
+  if (!s || !cost) return EMPC_ERR_INVALID;
+  for (int b = 0; b < s->B; ++b) cost[b] = s->h_st[b].cost;
+  return EMPC_OK;
+}
+int empc_solver_get_stop(EmpcSolver* s, double* stop) {
+  if (!s || !stop) return EMPC_ERR_INVALID;
+  for (int b = 0; b < s->B; ++b) stop[b] = s->h_st[b].stop;
+  return EMPC_OK;
+}
+int empc_solver_get_iters(EmpcSolver* s, int* iters) {
+  if (!s || !iters) return EMPC_ERR_INVALID;
+  for (int b = 0; b < s->B; ++b) iters[b] = s->h_st[b].iter;
+  return EMPC_OK;
+}
+int empc_solver_get_status(EmpcSolver* s, int* status) {
+  if (!s || !status) return EMPC_ERR_INVALID;
+  for (int b = 0; b < s->B; ++b) status[b] = s->h_st[b].status;
+  return EMPC_OK;
+}
+int empc_solver_get_stats(EmpcSolver* s, EmpcSolveStats* stats) {
+  if (!s || !stats) return EMPC_ERR_INVALID;
+  *stats = s->stats;
+  return EMPC_OK;
+}
+
+// ---- phase-level entry points --------------------------------------------------------------------------------
+static void phase_setup(EmpcSolver* s, double smooth, int is_feasible, double xreg, bool ddp, bool need_lin) {
+  for (int b = 0; b < s->B; ++b) {
+    TrajState& st = s->h_st[b];
+    init_traj_state(st, s->H.P.prm, 100, false, nullptr);
+    st.smooth = smooth;
+    st.is_feasible = is_feasible;
+    st.xreg = st.ureg = xreg;
+    st.phase = ddp ? PHASE_DDP : 0;
+    st.need_lin = need_lin ? 1 : 0;
+    st.need_calc = need_lin ? 1 : 0;
+  }
+  upload_states(s);
+}
+
+int empc_linearize_batch(EmpcSolver* s, const double* xs, const double* us, double smooth, int is_feasible, double* tape,
+                         double* cost, double* xnext) {
+  EMPC_TRY
+  if (!s) throw std::invalid_argument("solver is NULL");
+  (void)xnext;
+  s->use();
+  if (xs || us) {
+    if (empc_solver_set_warmstart(s, xs, us) != EMPC_OK) throw std::runtime_error(empc_last_error());
+  }
+  phase_setup(s, smooth, is_feasible, s->H.P.prm.reg_init, false, true);
+  HIP_CHECK(hipEventRecord(s->ev[0], s->stream));
+  s->kt.calc(s->D, s->stream);
+  HIP_CHECK(hipEventRecord(s->ev[1], s->stream));
+  s->kt.linearize(s->D, s->stream);
+  HIP_CHECK(hipEventRecord(s->ev[2], s->stream));
+  HIP_CHECK(hipStreamSynchronize(s->stream));
+  HIP_CHECK(hipGetLastError());
+  std::memset(&s->stats, 0, sizeof(s->stats));
+  timed(s, 0, s->stats.ms_calc);
+  timed(s, 1, s->stats.ms_linearize);
+  s->stats.n_linearize = 1;
+  s->stats.linearize_units = (long long)s->B * (s->T + 1);
+  const size_t n = (size_t)s->B * (s->T + 1) * s->kt.rec;
+  if (tape) {
+    HIP_CHECK(hipMemcpyAsync(tape, s->D.tape, sizeof(double) * n, hipMemcpyDeviceToHost, s->stream));
+    HIP_CHECK(hipStreamSynchronize(s->stream));
+  }
+  if (cost) {
+    std::vector<double> h(n);
+    HIP_CHECK(hipMemcpy(h.data(), s->D.tape, sizeof(double) * n, hipMemcpyDeviceToHost));
+    for (int b = 0; b < s->B; ++b) {
+      double c = 0;
+      for (int t = 0; t <= s->T; ++t) c += h[((size_t)b * (s->T + 1) + t) * s->kt.rec + s->kt.off[8]];
+      cost[b] = c;
+    }
+  }
+  return EMPC_OK;
+  EMPC_CATCH(RET_INT)
+}
+
+int empc_backward_batch(EmpcSolver* s, double xreg, int is_feasible, double* K, double* k, double* Vx, double* dgdq, int* ok) {
+  EMPC_TRY
+  if (!s) throw std::invalid_argument("solver is NULL");
+  s->use();
+  const double smooth = s->h_st.empty() ? s->H.P.prm.smooth_init : s->h_st[0].smooth;
+  phase_setup(s, smooth > 0 ? smooth : s->H.P.prm.smooth_init, is_feasible, xreg, false, true);
+  HIP_CHECK(hipEventRecord(s->ev[0], s->stream));
+  s->kt.backward(s->D, s->stream);
+  HIP_CHECK(hipEventRecord(s->ev[1], s->stream));
+  download_states(s);
+  HIP_CHECK(hipGetLastError());
+  std::memset(&s->stats, 0, sizeof(s->stats));
+  timed(s, 0, s->stats.ms_backward);
+  s->stats.n_backward = 1;
+  s->stats.backward_units = (long long)s->B * s->T;
+  const size_t B = s->B, T = s->T, n = s->kt.ndx, m = s->kt.nu;
+  if (K) HIP_CHECK(hipMemcpy(K, s->D.K, sizeof(double) * B * T * m * n, hipMemcpyDeviceToHost));
+  if (k) HIP_CHECK(hipMemcpy(k, s->D.kff, sizeof(double) * B * T * m, hipMemcpyDeviceToHost));
+  if (Vx) HIP_CHECK(hipMemcpy(Vx, s->D.Vx, sizeof(double) * B * (T + 1) * n, hipMemcpyDeviceToHost));
+  for (int b = 0; b < s->B; ++b) {
+    const TrajState& st = s->h_st[b];
+    if (dgdq) {
+      dgdq[2 * b] = st.dg_u + (st.is_feasible ? 0.0 : st.dg_f);
+      dgdq[2 * b + 1] = st.dq_u + (st.is_feasible ? 0.0 : st.dq_f);
+    }
+    if (ok) ok[b] = st.bwd_failed ? 0 : 1;
+  }
+  return EMPC_OK;
+  EMPC_CATCH(RET_INT)
+}
+
+int empc_rollout_batch(EmpcSolver* s, double alpha, int ddp, int is_feasible, double* xs_try, double* us_try,
+                       double* cost_try, int* ok) {
+  EMPC_TRY
+  if (!s) throw std::invalid_argument("solver is NULL");
+  s->use();
+  int ai = -1;
+  for (int i = 0; i < s->NA; ++i)
+    if (std::ldexp(1.0, -i) == alpha) ai = i;
+  if (ai < 0) throw std::invalid_argument("alpha must be one of 2^-n, n < n_alphas");
+  // keep the scalars the backward pass left on the device; only flip the flags the rollout reads
+  download_states(s);
+  for (int b = 0; b < s->B; ++b) {
+    TrajState& st = s->h_st[b];
+    st.phase = ddp ? PHASE_DDP : 0;
+    st.is_feasible = is_feasible;
+    st.need_lin = 0;
+    st.need_calc = 0;
+    st.bwd_failed = 0;
+  }
+  upload_states(s);
+  HIP_CHECK(hipEventRecord(s->ev[0], s->stream));
+  s->kt.rollout(s->D, s->stream);
+  HIP_CHECK(hipEventRecord(s->ev[1], s->stream));
+  HIP_CHECK(hipStreamSynchronize(s->stream));
+  HIP_CHECK(hipGetLastError());
+  std::memset(&s->stats, 0, sizeof(s->stats));
+  timed(s, 0, s->stats.ms_rollout);
+  s->stats.n_rollout = 1;
+  s->stats.rollout_units = (long long)s->B * s->NA * (s->T + 1);
+  const size_t B = s->B, T = s->T, NA = s->NA, nx = s->kt.nx, nu = s->kt.nu;
+  std::vector<double> c(B * NA);
+  std::vector<int> o(B * NA);
+  HIP_CHECK(hipMemcpy(c.data(), s->D.try_cost, sizeof(double) * B * NA, hipMemcpyDeviceToHost));
+  HIP_CHECK(hipMemcpy(o.data(), s->D.try_ok, sizeof(int) * B * NA, hipMemcpyDeviceToHost));
+  for (size_t b = 0; b < B; ++b) {
+    const size_t slot = b * NA + ai;
+    if (xs_try)
+      HIP_CHECK(hipMemcpy(xs_try + b * (T + 1) * nx, s->D.xs_try + slot * (T + 1) * nx, sizeof(double) * (T + 1) * nx, hipMemcpyDeviceToHost));
+    if (us_try)
+      HIP_CHECK(hipMemcpy(us_try + b * T * nu, s->D.us_try + slot * T * nu, sizeof(double) * T * nu, hipMemcpyDeviceToHost));
+    if (cost_try) cost_try[b] = c[slot];
+    if (ok) ok[b] = o[slot];
+  }
+  return EMPC_OK;
+  EMPC_CATCH(RET_INT)
+}
+
+}  // extern "C"

@@ -1,0 +1,261 @@
+// TEST INFRASTRUCTURE: CPU lane emulator for the HIP kernel bodies of eagle-mpc_amd/csrc/empc_kernels.hpp.
+// It executes exactly the code the GPU executes (same templates), one lane after another, so that the kernels' index
+// arithmetic and staging logic can be checked against the oracle on machines without a GPU.  It is NOT a product path:
+// nothing in the package loads it, and libempc.so never falls back to it.
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../eagle-mpc_amd/csrc/empc_prep.hpp"
+
+using namespace empc;
+
+template <int NL>
+struct CpuExec {
+  static constexpr int SLOTS = NL;
+  int nl;
+  template <class F>
+  void each(F&& f) {
+    for (int l = 0; l < nl; ++l) f(l, l);
+  }
+  void sync() {}
+};
+
+struct Emu {
+  HostProblem H;
+  int B, T, NA, nb, nrot;
+  std::vector<TrajState> st;
+  std::vector<double> x0, xs, us, acc, tape, K, kff, Vx, Vf, xs_try, us_try, acc_try, try_cost, try_dv, us_last;
+  std::vector<int> try_ok;
+  int n_active;
+  int rec, nx, ndx, nu, nv;
+  DevBuffers D;
+  int sweeps;
+};
+
+template <class DM>
+static void emu_alloc(Emu& e) {
+  const int B = e.B, T = e.T, NA = e.NA;
+  e.rec = DM::REC;
+  e.nx = DM::NX;
+  e.ndx = DM::NDX;
+  e.nu = DM::NU;
+  e.nv = DM::NV;
+  e.st.resize(B);
+  e.x0.assign((size_t)B * DM::NX, 0);
+  e.xs.assign((size_t)B * (T + 1) * DM::NX, 0);
+  e.us.assign((size_t)B * T * DM::NU, 0);
+  e.acc.assign((size_t)B * (T + 1) * DM::NV, 0);
+  e.tape.assign((size_t)B * (T + 1) * DM::REC, 0);
+  e.K.assign((size_t)B * T * DM::NU * DM::NDX, 0);
+  e.kff.assign((size_t)B * T * DM::NU, 0);
+  e.Vx.assign((size_t)B * (T + 1) * DM::NDX, 0);
+  e.Vf.assign((size_t)B * (T + 1) * DM::NDX, 0);
+  e.xs_try.assign((size_t)B * NA * (T + 1) * DM::NX, 0);
+  e.us_try.assign((size_t)B * NA * T * DM::NU, 0);
+  e.acc_try.assign((size_t)B * NA * (T + 1) * DM::NV, 0);
+  e.try_cost.assign((size_t)B * NA, 0);
+  e.try_dv.assign((size_t)B * NA, 0);
+  e.try_ok.assign((size_t)B * NA, 0);
+  e.us_last.assign((size_t)B * T * DM::NU, 0);
+  DevBuffers& D = e.D;
+  D.P = &e.H.P;
+  D.sets = e.H.sets.data();
+  D.knot_set = e.H.knot_set.data();
+  D.st = e.st.data();
+  D.x0 = e.x0.data();
+  D.xs = e.xs.data();
+  D.us = e.us.data();
+  D.acc = e.acc.data();
+  D.tape = e.tape.data();
+  D.K = e.K.data();
+  D.kff = e.kff.data();
+  D.Vx = e.Vx.data();
+  D.Vf = e.Vf.data();
+  D.xs_try = e.xs_try.data();
+  D.us_try = e.us_try.data();
+  D.acc_try = e.acc_try.data();
+  D.try_cost = e.try_cost.data();
+  D.try_dv = e.try_dv.data();
+  D.try_ok = e.try_ok.data();
+  D.us_last = e.us_last.data();
+  D.n_active = &e.n_active;
+  D.B = B;
+  D.T = T;
+  D.NA = NA;
+  D.gaptol = e.H.P.prm.th_gaptol > 1e-13 ? e.H.P.prm.th_gaptol : 1e-13;
+  for (int b = 0; b < B; ++b) std::memcpy(&e.x0[(size_t)b * DM::NX], e.H.x0.data(), sizeof(double) * DM::NX);
+}
+
+template <class DM>
+static void emu_calc(Emu& e) {
+  for (int b = 0; b < e.B; ++b)
+    for (int t = 0; t <= e.T; ++t) calc_thread<DM>(e.D, b, t);
+}
+template <class DM>
+static void emu_linearize(Emu& e) {
+  constexpr int LPU = (3 * DM::NV <= 32) ? 32 : 64;
+  std::vector<double> smem(LinSmem<DM>::SIZE);
+  for (int t = 0; t <= e.T; ++t)
+    for (int b = 0; b < e.B; ++b) {
+      const TrajState& st = e.st[b];
+      if (st.phase == PHASE_DONE || !st.need_lin) continue;
+      CpuExec<64> ex{LPU};
+      linearize_unit<DM>(ex, e.D, b, t, LPU, smem.data());
+    }
+}
+template <class DM>
+static void emu_backward(Emu& e) {
+  std::vector<double> smem(BwdSmem<DM>::SIZE);
+  for (int b = 0; b < e.B; ++b) {
+    CpuExec<64> ex{64};
+    backward_traj<DM>(ex, e.D, b, smem.data());
+  }
+}
+template <class DM>
+static void emu_rollout(Emu& e) {
+  for (int b = 0; b < e.B; ++b)
+    for (int ai = 0; ai < e.NA; ++ai) rollout_thread<DM>(e.D, b, ai);
+}
+template <class DM>
+static void emu_select(Emu& e) {
+  e.n_active = 0;
+  for (int b = 0; b < e.B; ++b) {
+    int acc_ai, last_ai;
+    select_decide<DM>(e.D, b, acc_ai, last_ai);
+    select_copy<DM>(e.D, b, acc_ai, last_ai, 0, 1);
+    if (e.st[b].phase != PHASE_DONE) e.n_active++;
+  }
+}
+template <class DM>
+static void emu_solve(Emu& e, int maxiter, int is_feasible) {
+  for (int b = 0; b < e.B; ++b) {
+    TrajState prev = e.st[b];
+    init_traj_state(e.st[b], e.H.P.prm, maxiter, is_feasible != 0, &prev);
+  }
+  e.sweeps = 0;
+  while (true) {
+    emu_calc<DM>(e);
+    emu_linearize<DM>(e);
+    emu_backward<DM>(e);
+    emu_rollout<DM>(e);
+    emu_select<DM>(e);
+    e.sweeps++;
+    if (e.n_active == 0 || e.sweeps > 10000) break;
+  }
+}
+
+#define DISPATCH(e, FN, ...)                                                    \
+  do {                                                                          \
+    if (e->nb == 1 && e->nrot == 6) FN<Dims<1, 6>>(__VA_ARGS__);                \
+    else if (e->nb == 1 && e->nrot == 4) FN<Dims<1, 4>>(__VA_ARGS__);           \
+    else if (e->nb == 4 && e->nrot == 6) FN<Dims<4, 6>>(__VA_ARGS__);           \
+    else if (e->nb == 6 && e->nrot == 6) FN<Dims<6, 6>>(__VA_ARGS__);           \
+    else { std::fprintf(stderr, "emulator: unsupported dims\n"); }             \
+  } while (0)
+
+extern "C" {
+void* emu_create(const EmpcProblemDesc* d, const EmpcSolverParams* prm, int B) {
+  Emu* e = new Emu();
+  try {
+    prepare_problem(*d, *prm, e->H);
+  } catch (const std::exception& ex) {
+    std::fprintf(stderr, "emu_create: %s\n", ex.what());
+    delete e;
+    return nullptr;
+  }
+  e->B = B;
+  e->T = d->T;
+  e->NA = prm->n_alphas;
+  e->nb = d->model.nbodies;
+  e->nrot = d->n_rotors;
+  DISPATCH(e, emu_alloc, *e);
+  std::memset(e->st.data(), 0, sizeof(TrajState) * B);
+  return e;
+}
+void emu_destroy(void* h) { delete static_cast<Emu*>(h); }
+int emu_rec(void* h) { return static_cast<Emu*>(h)->rec; }
+void emu_set_x0(void* h, const double* x0s) {
+  Emu* e = static_cast<Emu*>(h);
+  std::memcpy(e->x0.data(), x0s, sizeof(double) * e->x0.size());
+}
+void emu_set_warmstart(void* h, const double* xs, const double* us) {
+  Emu* e = static_cast<Emu*>(h);
+  if (xs)
+    std::memcpy(e->xs.data(), xs, sizeof(double) * e->xs.size());
+  else {
+    std::fill(e->xs.begin(), e->xs.end(), 0.0);
+    for (size_t i = 0; i < (size_t)e->B * (e->T + 1); ++i) e->xs[i * e->nx + 6] = 1.0;
+  }
+  if (us)
+    std::memcpy(e->us.data(), us, sizeof(double) * e->us.size());
+  else
+    std::fill(e->us.begin(), e->us.end(), 0.0);
+}
+int emu_solve_c(void* h, int maxiter, int is_feasible) {
+  Emu* e = static_cast<Emu*>(h);
+  DISPATCH(e, emu_solve, *e, maxiter, is_feasible);
+  return e->sweeps;
+}
+void emu_get(void* h, double* xs, double* us, double* us_last, double* cost, int* iters, int* status) {
+  Emu* e = static_cast<Emu*>(h);
+  if (xs) std::memcpy(xs, e->xs.data(), sizeof(double) * e->xs.size());
+  if (us) std::memcpy(us, e->us.data(), sizeof(double) * e->us.size());
+  if (us_last) std::memcpy(us_last, e->us_last.data(), sizeof(double) * e->us_last.size());
+  for (int b = 0; b < e->B; ++b) {
+    if (cost) cost[b] = e->st[b].cost;
+    if (iters) iters[b] = e->st[b].iter;
+    if (status) status[b] = e->st[b].status;
+  }
+}
+// phase level: state is set up the way the solver would have it inside a pass
+void emu_phase_setup(void* h, double smooth, int is_feasible, double xreg, int ddp) {
+  Emu* e = static_cast<Emu*>(h);
+  for (int b = 0; b < e->B; ++b) {
+    TrajState& s = e->st[b];
+    init_traj_state(s, e->H.P.prm, 100, false, nullptr);
+    s.smooth = smooth;
+    s.is_feasible = is_feasible;
+    s.xreg = s.ureg = xreg;
+    s.phase = ddp ? PHASE_DDP : 0;
+  }
+}
+void emu_phase_linearize(void* h, double* tape, double* acc) {
+  Emu* e = static_cast<Emu*>(h);
+  DISPATCH(e, emu_calc, *e);
+  DISPATCH(e, emu_linearize, *e);
+  if (tape) std::memcpy(tape, e->tape.data(), sizeof(double) * e->tape.size());
+  if (acc) std::memcpy(acc, e->acc.data(), sizeof(double) * e->acc.size());
+}
+void emu_phase_backward(void* h, double* K, double* k, double* Vx, double* dgdq, int* ok, int* feas, double* cost) {
+  Emu* e = static_cast<Emu*>(h);
+  DISPATCH(e, emu_backward, *e);
+  if (K) std::memcpy(K, e->K.data(), sizeof(double) * e->K.size());
+  if (k) std::memcpy(k, e->kff.data(), sizeof(double) * e->kff.size());
+  if (Vx) std::memcpy(Vx, e->Vx.data(), sizeof(double) * e->Vx.size());
+  for (int b = 0; b < e->B; ++b) {
+    const TrajState& s = e->st[b];
+    if (dgdq) {
+      dgdq[2 * b] = s.dg_u + (s.is_feasible ? 0.0 : s.dg_f);
+      dgdq[2 * b + 1] = s.dq_u + (s.is_feasible ? 0.0 : s.dq_f);
+    }
+    if (ok) ok[b] = !s.bwd_failed;
+    if (feas) feas[b] = s.is_feasible;
+    if (cost) cost[b] = s.cost;
+  }
+}
+void emu_phase_rollout(void* h, int ai, double* xs_try, double* us_try, double* cost_try, double* dv, int* ok) {
+  Emu* e = static_cast<Emu*>(h);
+  for (int b = 0; b < e->B; ++b) e->st[b].need_lin = 0;
+  DISPATCH(e, emu_rollout, *e);
+  const int T = e->T, NA = e->NA;
+  for (int b = 0; b < e->B; ++b) {
+    const size_t slot = (size_t)b * NA + ai;
+    if (xs_try) std::memcpy(xs_try + (size_t)b * (T + 1) * e->nx, &e->xs_try[slot * (T + 1) * e->nx], sizeof(double) * (T + 1) * e->nx);
+    if (us_try) std::memcpy(us_try + (size_t)b * T * e->nu, &e->us_try[slot * T * e->nu], sizeof(double) * T * e->nu);
+    if (cost_try) cost_try[b] = e->try_cost[slot];
+    if (dv) dv[b] = e->try_dv[slot];
+    if (ok) ok[b] = e->try_ok[slot];
+  }
+}
+}

@@ -1,0 +1,196 @@
+"""ctypes binding of the ORACLE (oracle/liboracle.so).  Test infrastructure: imported only by tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg -- never by the product package."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import empc_loader  # noqa: E402
+
+empc = empc_loader.load()
+T = empc.T
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_LIB = os.path.join(ORACLE_DIR, "liboracle.so")
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+
+def build_oracle():
+    subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+
+
+_orc = None
+
+
+def orc():
+    global _orc
+    if _orc is None:
+        if not os.path.exists(ORACLE_LIB):
+            build_oracle()
+        L = C.CDLL(ORACLE_LIB)
+        L.oracle_solver_create.restype = C.c_void_p
+        L.oracle_solver_create.argtypes = [C.POINTER(T.ProblemDesc), C.POINTER(T.SolverParams)]
+        L.oracle_solver_destroy.argtypes = [C.c_void_p]
+        L.oracle_solver_set_x0.argtypes = [C.c_void_p, _dp]
+        L.oracle_solver_set_convergence_init.argtypes = [C.c_void_p, C.c_double]
+        L.oracle_solver_solve.argtypes = [C.c_void_p, _dp, _dp, C.c_int, C.c_int]
+        L.oracle_solver_get.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _ip, _ip, _dp]
+        L.oracle_solver_trace.argtypes = [C.c_void_p, _dp, C.c_int]
+        L.oracle_solver_set_smooth.argtypes = [C.c_void_p, C.c_double]
+        L.oracle_node_calc.argtypes = [C.c_void_p, C.c_int, _dp, _dp, C.c_int] + [_dp] * 12
+        L.oracle_phase_calcdiff.restype = C.c_double
+        L.oracle_phase_calcdiff.argtypes = [C.c_void_p, _dp, _dp, C.c_int, C.c_int, _dp, _ip]
+        L.oracle_phase_backward.argtypes = [C.c_void_p, C.c_double, _dp, _dp, _dp, _dp, _dp]
+        L.oracle_phase_forward.argtypes = [C.c_void_p, C.c_double, C.c_int, _dp, _dp, _dp, _dp]
+        L.oracle_phase_tape.argtypes = [C.c_void_p, C.c_int] + [_dp] * 9
+        L.oracle_solve_batch.restype = C.c_double
+        L.oracle_solve_batch.argtypes = [C.POINTER(T.ProblemDesc), C.POINTER(T.SolverParams), C.c_int, _dp, C.c_int, C.c_int,
+                                         _dp, _dp, _dp, _dp, _ip, _ip]
+        L.oracle_state_integrate.argtypes = [C.c_void_p, _dp, _dp, _dp]
+        L.oracle_state_diff.argtypes = [C.c_void_p, _dp, _dp, _dp]
+        L.oracle_rnea.argtypes = [C.POINTER(T.ModelDesc), _dp, _dp, _dp, _dp]
+        L.oracle_crba.argtypes = [C.POINTER(T.ModelDesc), _dp, _dp]
+        L.oracle_energy.restype = C.c_double
+        L.oracle_energy.argtypes = [C.POINTER(T.ModelDesc), _dp, _dp]
+        for f in ("exp6", "log6"):
+            getattr(L, "oracle_" + f).argtypes = [_dp, _dp, _dp]
+        for f in ("Jexp6", "Jlog6", "exp3", "log3", "Jexp3", "Jlog3"):
+            getattr(L, "oracle_" + f).argtypes = [_dp, _dp]
+        _orc = L
+    return _orc
+
+
+def P(a):
+    if a is None:
+        return None
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_dp)
+
+
+def default_params():
+    p = T.SolverParams()
+    orc().oracle_solver_params_default(C.byref(p))
+    return p
+
+
+class OracleSolver:
+    def __init__(self, desc, params=None):
+        self.d = desc
+        self.prm = params if params is not None else default_params()
+        self.h = C.c_void_p(orc().oracle_solver_create(C.byref(desc), C.byref(self.prm)))
+        self.nx, self.ndx, self.nu, self.nv, self.T = desc.nx, desc.ndx, desc.nu, desc.model.nv, desc.T
+
+    def __del__(self):
+        try:
+            orc().oracle_solver_destroy(self.h)
+        except Exception:
+            pass
+
+    def set_x0(self, x0):
+        orc().oracle_solver_set_x0(self.h, P(np.ascontiguousarray(x0, dtype=np.float64)))
+
+    def set_smooth(self, s):
+        orc().oracle_solver_set_smooth(self.h, float(s))
+
+    def solve(self, xs=None, us=None, maxiter=100, is_feasible=False):
+        xs = None if xs is None else np.ascontiguousarray(xs, dtype=np.float64)
+        us = None if us is None else np.ascontiguousarray(us, dtype=np.float64)
+        return orc().oracle_solver_solve(self.h, P(xs), P(us), int(maxiter), int(is_feasible))
+
+    def result(self):
+        xs = np.zeros((self.T + 1, self.nx))
+        us = np.zeros((self.T, self.nu))
+        usq = np.zeros((self.T, self.nu))
+        cost = C.c_double()
+        it = C.c_int()
+        st = C.c_int()
+        stop = C.c_double()
+        orc().oracle_solver_get(self.h, P(xs), P(us), P(usq), C.cast(C.byref(cost), _dp), C.byref(it), C.byref(st),
+                                C.cast(C.byref(stop), _dp))
+        return dict(xs=xs, us=us, us_squash=usq, cost=cost.value, iter=it.value, status=st.value, stop=stop.value)
+
+    def trace(self):
+        n = orc().oracle_solver_trace(self.h, None, 0)
+        tr = np.zeros((n, 12))
+        orc().oracle_solver_trace(self.h, P(tr), n)
+        return tr
+
+    def node_calc(self, t, x, u, diff=True):
+        n, m = self.ndx, self.nu
+        out = dict(xnext=np.zeros(self.nx), Fx=np.zeros((n, n)), Fu=np.zeros((n, m)), Lx=np.zeros(n), Lu=np.zeros(m),
+                   Lxx=np.zeros((n, n)), Lxu=np.zeros((n, m)), Luu=np.zeros((m, m)), acc=np.zeros(self.nv),
+                   u_squash=np.zeros(m), lam=np.zeros(6))
+        c = C.c_double()
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        u = None if u is None else np.ascontiguousarray(u, dtype=np.float64)
+        orc().oracle_node_calc(self.h, t, P(x), P(u), int(diff), P(out["xnext"]), C.cast(C.byref(c), _dp), P(out["Fx"]),
+                               P(out["Fu"]), P(out["Lx"]), P(out["Lu"]), P(out["Lxx"]), P(out["Lxu"]), P(out["Luu"]),
+                               P(out["acc"]), P(out["u_squash"]), P(out["lam"]))
+        out["cost"] = c.value
+        return out
+
+    def integrate(self, x, dx):
+        o = np.zeros(self.nx)
+        orc().oracle_state_integrate(self.h, P(np.ascontiguousarray(x)), P(np.ascontiguousarray(dx)), P(o))
+        return o
+
+    def diff(self, a, b):
+        o = np.zeros(self.ndx)
+        orc().oracle_state_diff(self.h, P(np.ascontiguousarray(a)), P(np.ascontiguousarray(b)), P(o))
+        return o
+
+    def phase_calcdiff(self, xs, us, is_feasible=False, was_feasible=False):
+        fs = np.zeros((self.T + 1, self.ndx))
+        feas = C.c_int()
+        xs = np.ascontiguousarray(xs, dtype=np.float64)
+        us = np.ascontiguousarray(us, dtype=np.float64)
+        cost = orc().oracle_phase_calcdiff(self.h, P(xs), P(us), int(is_feasible), int(was_feasible), P(fs), C.byref(feas))
+        return cost, fs, bool(feas.value)
+
+    def phase_tape(self, t):
+        n, m = self.ndx, self.nu
+        o = dict(Fx=np.zeros((n, n)), Fu=np.zeros((n, m)), Lx=np.zeros(n), Lu=np.zeros(m), Lxx=np.zeros((n, n)),
+                 Lxu=np.zeros((n, m)), Luu=np.zeros((m, m)), xnext=np.zeros(self.nx))
+        c = C.c_double()
+        orc().oracle_phase_tape(self.h, t, P(o["Fx"]), P(o["Fu"]), P(o["Lx"]), P(o["Lu"]), P(o["Lxx"]), P(o["Lxu"]), P(o["Luu"]),
+                                P(o["xnext"]), C.cast(C.byref(c), _dp))
+        o["cost"] = c.value
+        return o
+
+    def phase_backward(self, xreg=1e-9):
+        n, m, T_ = self.ndx, self.nu, self.T
+        K = np.zeros((T_, m, n))
+        k = np.zeros((T_, m))
+        Vx = np.zeros((T_ + 1, n))
+        Vxx = np.zeros((T_ + 1, n, n))
+        dgdq = np.zeros(2)
+        ok = orc().oracle_phase_backward(self.h, float(xreg), P(K), P(k), P(Vx), P(Vxx), P(dgdq))
+        return bool(ok), K, k, Vx, Vxx, dgdq
+
+    def phase_forward(self, alpha, ddp=False):
+        xs = np.zeros((self.T + 1, self.nx))
+        us = np.zeros((self.T, self.nu))
+        c = C.c_double()
+        d01 = np.zeros(2)
+        ok = orc().oracle_phase_forward(self.h, float(alpha), int(ddp), P(xs), P(us), C.cast(C.byref(c), _dp), P(d01))
+        return bool(ok), xs, us, c.value, d01
+
+
+def solve_batch(desc, x0s, maxiter=100, nthreads=1, params=None, want_traj=True):
+    prm = params if params is not None else default_params()
+    x0s = np.ascontiguousarray(x0s, dtype=np.float64)
+    B = x0s.shape[0]
+    T_, nx, nu = desc.T, desc.nx, desc.nu
+    xs = np.zeros((B, T_ + 1, nx)) if want_traj else None
+    us = np.zeros((B, T_, nu)) if want_traj else None
+    usq = np.zeros((B, T_, nu)) if want_traj else None
+    cost = np.zeros(B)
+    iters = np.zeros(B, dtype=np.int32)
+    status = np.zeros(B, dtype=np.int32)
+    secs = orc().oracle_solve_batch(C.byref(desc), C.byref(prm), B, P(x0s), int(maxiter), int(nthreads), P(xs), P(us), P(usq),
+                                    P(cost), iters.ctypes.data_as(_ip), status.ctypes.data_as(_ip))
+    return dict(xs=xs, us=us, us_squash=usq, cost=cost, iter=iters, status=status, seconds=secs)

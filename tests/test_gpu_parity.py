@@ -1,0 +1,199 @@
+"""GPU parity tests: the HIP path (through the C ABI of libempc.so) against the oracle on identical inputs.
+
+Tolerances (FP64 everywhere):
+  * per-kernel outputs (tape, gains, rollouts): 1e-9 relative (scaled by 1 + max|reference|)
+  * converged trajectories xs / us: 1e-4 absolute (BASELINE.json north star), cost 1e-6 relative, identical
+    iteration counts
+The oracle itself is checked by finite differences / identities in test_oracle_math.py (parity vs the reference is
+UNPINNED: the reference's arithmetic lives in the un-vendored Crocoddyl fork).
+"""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-9
+
+
+def rel(a, b):
+    return np.abs(a - b).max() / (1.0 + np.abs(b).max())
+
+
+def random_candidate(d, B, seed):
+    rng = np.random.default_rng(seed)
+    T, nx, nu = d.T, d.nx, d.nu
+    xs = np.zeros((B, T + 1, nx))
+    xs[..., :3] = rng.normal(size=(B, T + 1, 3)) * 0.3
+    q = np.array([0, 0, 0, 1.0]) + rng.normal(size=(B, T + 1, 4)) * 0.2
+    xs[..., 3:7] = q / np.linalg.norm(q, axis=-1, keepdims=True)
+    xs[..., 7:] = rng.normal(size=(B, T + 1, nx - 7)) * 0.3
+    us = rng.uniform(2, 6, size=(B, T, nu))
+    us[..., d.n_rotors:] = rng.normal(size=(B, T, nu - d.n_rotors)) * 0.2
+    return xs, us
+
+
+def tape_blocks(solver):
+    lay = solver.tape_layout()
+    n, m = solver.ndx, solver.nu
+    return {"Fx": (lay["off_fx"], n * n), "Fu": (lay["off_fu"], n * m), "Lxx": (lay["off_lxx"], n * n),
+            "Lxu": (lay["off_lxu"], n * m), "Luu": (lay["off_luu"], m * m), "Lx": (lay["off_lx"], n),
+            "Lu": (lay["off_lu"], m), "gap": (lay["off_gap"], n), "cost": (lay["off_cost"], 1)}
+
+
+@pytest.mark.parametrize("name", ["hover", "displacement", "push_slide"])
+def test_phase_parity(empc, problems, name):
+    """linearize (HOT-A), backward (HOT-B) and rollout (HOT-C) kernels against the oracle's calcDiff / backwardPass /
+    forwardPass on random candidates (seeded), one trajectory of the batch at a time."""
+    _, problem = problems[name]
+    d = problem.desc
+    B = 3
+    xs, us = random_candidate(d, B, seed=11)
+    x0s = empc.perturbed_x0s(problem.x0, B, nq=d.model.nq, seed=5)
+    solver = empc.SolverSbFDDP(problem, batch=B)
+    smooth = 0.1
+    tape = solver.linearize(xs, us, smooth=smooth, is_feasible=False, x0s=x0s)
+    K, k, Vx, dgdq, ok = solver.backward(xreg=1e-9, is_feasible=False)
+    blocks = tape_blocks(solver)
+    for b in range(B):
+        o = ob.OracleSolver(d)
+        o.set_x0(x0s[b])
+        o.set_smooth(smooth)
+        cost, fs, feas = o.phase_calcdiff(xs[b], us[b])
+        for t in range(d.T + 1):
+            ref = o.phase_tape(t)
+            ref["gap"] = fs[t]
+            ref["cost"] = np.array([ref["cost"]])
+            for key, (off, sz) in blocks.items():
+                if t == d.T and key in ("Fx", "Fu", "Lxu", "Luu", "Lu"):
+                    continue
+                got = tape[b, t, off:off + sz]
+                assert rel(got, np.asarray(ref[key]).ravel()) < REL, (name, b, t, key)
+        okb, Ko, ko, Vxo, _, dgo = o.phase_backward(1e-9)
+        assert okb and ok[b] == 1
+        # gains amplify rounding through the LLT of Quu at xreg = 1e-9: compare relative to the largest gain
+        assert rel(K[b], Ko) < 1e-6 and rel(k[b], ko) < 1e-6 and rel(Vx[b], Vxo) < 1e-7
+        assert np.allclose(dgdq[b], dgo, rtol=1e-6)
+    # rollouts for a short step (a full step from a random candidate diverges on both sides)
+    for alpha in (0.25, 0.0625):
+        xt, ut, ct, okr = solver.rollout(alpha, ddp=False, is_feasible=False)
+        for b in range(B):
+            o = ob.OracleSolver(d)
+            o.set_x0(x0s[b])
+            o.set_smooth(smooth)
+            o.phase_calcdiff(xs[b], us[b])
+            o.phase_backward(1e-9)
+            oko, xo, uo, co, _ = o.phase_forward(alpha)
+            assert bool(okr[b]) == oko
+            if oko and np.isfinite(co) and abs(co) < 1e12:
+                assert rel(xt[b], xo) < 1e-6 and rel(ut[b], uo) < 1e-6
+                assert abs(ct[b] - co) < 1e-6 * (1 + abs(co))
+
+
+@pytest.mark.parametrize("name,B,amp", [("hover", 4, 0.0), ("displacement", 16, 0.05), ("push_slide", 4, 0.05)])
+def test_solve_parity(empc, problems, name, B, amp):
+    """SolverSbFDDP.solve on the GPU vs the oracle, same YAML, same perturbed initial states, empty initial guess.
+    (hover is solved from the YAML state only: from perturbed states this OCP -- 1e-5 state regularisation -- needs
+    ~100 iterations of accepted ascent steps and amplifies rounding chaotically on the CPU as well, see
+    test_hover_perturbed_first_iterations.)"""
+    _, problem = problems[name]
+    d = problem.desc
+    x0s = empc.perturbed_x0s(problem.x0, B, nq=d.model.nq, amplitude=amp)
+    solver = empc.SolverSbFDDP(problem, batch=B)
+    assert solver.solve([], [], 100, x0s=x0s) is True
+    ref = ob.solve_batch(d, x0s, 100, nthreads=4)
+    xs, us, usq = solver.xs_batch, solver.us_batch, solver.us_squash_batch
+    assert (solver.iter_batch == ref["iter"]).all(), (solver.iter_batch, ref["iter"])
+    assert (solver.status_batch == ref["status"]).all()
+    assert np.abs(xs - ref["xs"]).max() < 1e-4
+    assert np.abs(us - ref["us"]).max() < 1e-4
+    assert np.abs(usq - ref["us_squash"]).max() < 1e-4
+    assert np.all(np.abs(solver.cost_batch - ref["cost"]) < 1e-6 * (1 + np.abs(ref["cost"])))
+    # reference-style getters expose trajectory 0
+    assert np.allclose(np.array(solver.xs), xs[0]) and solver.iter == int(ref["iter"][0])
+
+
+def test_hover_perturbed_first_iterations(empc, problems):
+    """Perturbed hover: compare the first iterations only (maxiter small), before rounding differences are amplified."""
+    _, problem = problems["hover"]
+    d = problem.desc
+    B = 8
+    x0s = empc.perturbed_x0s(problem.x0, B, nq=d.model.nq)
+    solver = empc.SolverSbFDDP(problem, batch=B)
+    solver.solve([], [], 2, x0s=x0s)
+    ref = ob.solve_batch(d, x0s, 2, nthreads=4)
+    assert (solver.iter_batch == ref["iter"]).all()
+    assert np.abs(solver.xs_batch - ref["xs"]).max() < 1e-6 * (1 + np.abs(ref["xs"]).max())
+    assert np.all(np.abs(solver.cost_batch - ref["cost"]) < 1e-6 * (1 + np.abs(ref["cost"])))
+
+
+def test_warm_start_and_feasible_flag(empc, problems):
+    """solve(init_xs, init_us) from a previous solution: same result as the oracle's warm-started solve."""
+    _, problem = problems["displacement"]
+    d = problem.desc
+    B = 4
+    x0s = empc.perturbed_x0s(problem.x0, B, nq=d.model.nq, seed=3)
+    solver = empc.SolverSbFDDP(problem, batch=B)
+    solver.solve([], [], 3, x0s=x0s)  # stop early: maxiter hit
+    xs1, us1 = solver.xs_batch, solver.us_batch
+    assert (solver.status_batch & empc.T.STATUS_MAXITER).any()
+    solver.solve(xs1, us1, 100, x0s=x0s)
+    for b in range(B):
+        o = ob.OracleSolver(d)
+        o.set_x0(x0s[b])
+        o.solve(None, None, 3)
+        r1 = o.result()
+        assert np.abs(r1["xs"] - xs1[b]).max() < 1e-6
+        o.solve(r1["xs"], r1["us"], 100)
+        r2 = o.result()
+        assert np.abs(solver.xs_batch[b] - r2["xs"]).max() < 1e-4
+        assert solver.iter_batch[b] == r2["iter"]
+
+
+def test_full_size_properties(empc, problems):
+    """BASELINE config 2 at full size (batch 1024, 100 knots): properties that do not need the oracle on every
+    trajectory -- (1) a trajectory's solution does not depend on its neighbours in the batch (bitwise), (2) the
+    solution is dynamically feasible: rolling the controls out from x0 (step length 0 gains-free re-rollout through
+    the oracle on a sample) reproduces xs, (3) every trajectory converged, (4) oracle parity on a random sample."""
+    _, problem = problems["displacement"]
+    d = problem.desc
+    B = 1024
+    x0s = empc.perturbed_x0s(problem.x0, B, nq=d.model.nq)
+    solver = empc.SolverSbFDDP(problem, batch=B)
+    solver.solve([], [], 100, x0s=x0s)
+    xs, us, cost, iters, status = solver.xs_batch, solver.us_batch, solver.cost_batch, solver.iter_batch, solver.status_batch
+    assert np.isfinite(xs).all() and np.isfinite(us).all()
+    assert ((status & empc.T.STATUS_CONVERGED) != 0).all()
+    # (1) batch independence: re-solve a subset in a different batch arrangement
+    idx = np.array([0, 1, 17, 511, 1023])
+    small = empc.SolverSbFDDP(problem, batch=len(idx))
+    small.solve([], [], 100, x0s=np.ascontiguousarray(x0s[idx]))
+    assert np.array_equal(small.xs_batch, xs[idx]) and np.array_equal(small.us_batch, us[idx])
+    assert np.array_equal(small.iter_batch, iters[idx])
+    # (2) + (4) on a sample
+    for b in idx:
+        o = ob.OracleSolver(d)
+        o.set_x0(x0s[b])
+        o.set_smooth(0.05)
+        x = x0s[b].copy()
+        for t in range(d.T):
+            assert np.abs(o.diff(xs[b, t], x)).max() < 1e-7
+            x = o.node_calc(t, x, us[b, t], diff=False)["xnext"]
+        o2 = ob.OracleSolver(d)
+        o2.set_x0(x0s[b])
+        o2.solve(None, None, 100)
+        r = o2.result()
+        assert np.abs(r["xs"] - xs[b]).max() < 1e-4 and np.abs(r["us"] - us[b]).max() < 1e-4
+        assert r["iter"] == iters[b] and abs(r["cost"] - cost[b]) < 1e-6 * (1 + abs(cost[b]))
+
+
+def test_error_paths(empc, problems):
+    _, problem = problems["hover"]
+    with pytest.raises(empc.EmpcError):
+        empc.SolverSbFDDP(problem, batch=0)
+    with pytest.raises(empc.EmpcError):
+        empc.SolverSbFDDP(problem, batch=1, device=99)
+    s = empc.SolverSbFDDP(problem, batch=1)
+    with pytest.raises(empc.EmpcError):
+        s.solve([], [], 0)

@@ -1,0 +1,221 @@
+"""Host-side problem factory: YAML grammar / flat keys, knot-expansion rule, platform matrices, quirks of the
+reference that must be reproduced (SURVEY.md section 8(a) 'quirks', Appendix B/C)."""
+import ctypes as C
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import CONFIGS
+
+
+def knot_runs(d):
+    ks = [d.knot_set[i] for i in range(d.T + 1)]
+    runs = []
+    for k in ks:
+        if runs and runs[-1][0] == k:
+            runs[-1][1] += 1
+        else:
+            runs.append([k, 1])
+    return [tuple(r) for r in runs]
+
+
+def test_knot_expansion(empc, problems):
+    # Trajectory::createProblem rule (src/trajectory.cpp:117-127); expected counts from SURVEY.md section 3.4 / App. C
+    assert problems["hover"][1].T == 50
+    assert knot_runs(problems["hover"][1].desc) == [(0, 50), (1, 1)]
+    assert problems["displacement"][1].T == 100
+    assert knot_runs(problems["displacement"][1].desc) == [(0, 25), (1, 1), (2, 24), (3, 1), (4, 24), (5, 1), (6, 24), (7, 1)]
+    assert problems["eagle_catch"][1].T == 99
+    assert knot_runs(problems["eagle_catch"][1].desc) == [(0, 43), (1, 1), (2, 5), (3, 50), (4, 1)]
+    assert problems["push_slide"][1].T == 153
+    # other dt values quoted in the survey
+    t = problems["eagle_catch"][0]
+    assert t.createProblem(20, True, "IntegratedActionModelEuler").T == 160
+    assert problems["displacement"][0].createProblem(20, True, "IntegratedActionModelEuler").T == 400
+    assert problems["hover"][0].createProblem(20, True, "IntegratedActionModelEuler").T == 100
+
+
+def test_dimensions_and_flags(problems):
+    d = problems["displacement"][1].desc
+    assert (d.nx, d.ndx, d.nu, d.n_rotors, d.has_contact) == (19, 18, 9, 6, 0)
+    d = problems["eagle_catch"][1].desc
+    assert d.has_contact == 1 and abs(d.dt - 0.032) < 1e-15
+    assert [d.x0[i] for i in range(3)] == [-5.0, 0.0, 1.0] and d.x0[6] == 1.0
+    d = problems["push_slide"][1].desc
+    assert (d.nx, d.ndx, d.nu) == (23, 22, 11)
+    d = problems["hover"][1].desc
+    assert (d.nx, d.ndx, d.nu) == (13, 12, 6)
+    assert [d.x0[i] for i in range(13)] == [0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0]  # no initial_state -> zero state
+
+
+def test_tau_f_known_answer(problems):
+    """tau_f of hexacopter370 from yaml/hexacopter370/platform/hexacopter370.yaml:8-31: thrust rows [0,0,1], torque
+    rows p x e3 + spin cm/cf e3 (src/multicopter-base-params.cpp:71-78)."""
+    t = problems["hover"][0]
+    tau_f, lb, ub = t.platform()
+    cf, cm = 4.138394792004922e-06, 6.991478005829954e-08
+    pos = [(0.1602147, 0.0925), (0.0, 0.185), (-0.1602147, 0.0925), (-0.1602147, -0.0925), (0.0, -0.185), (0.1602147, -0.0925)]
+    spin = [-1, 1, -1, 1, -1, 1]
+    exp = np.zeros((6, 6))
+    for i, ((x, y), s) in enumerate(zip(pos, spin)):
+        exp[2, i] = 1.0
+        exp[3, i] = y      # (p x e3)_x = p_y
+        exp[4, i] = -x     # (p x e3)_y = -p_x
+        exp[5, i] = s * cm / cf
+    assert np.abs(tau_f - exp).max() < 1e-12
+    assert np.all(lb == 0.0) and np.all(ub == 20.6991)
+    tau_f3, lb3, ub3 = problems["displacement"][0].platform()
+    assert np.abs(tau_f3 - exp).max() < 1e-12
+    assert list(lb3[6:]) == [-1.0, -1.0, -1.0] and list(ub3[6:]) == [1.0, 1.0, 1.0]  # URDF effort limits
+
+
+def test_cost_tables(empc, problems):
+    T = empc.T
+    d = problems["displacement"][1].desc
+    s0 = d.sets[0]
+    names = [s0.costs[i].name.decode() for i in range(s0.ncosts)]
+    assert names == sorted(names) == ["limits_state", "reg_control", "reg_state"]  # std::map order
+    lim = s0.costs[0]
+    assert lim.type == T.COST_STATE and lim.activation == T.ACT_WEIGHTED_QUADRATIC_BARRIER and lim.weight == 100
+    assert lim.ub[6] == 1.5 and lim.lb[15] == -3 and lim.act_w[0] == 0 and lim.act_w[6] == 1
+    wp = d.sets[3]  # wp_2: orientation [0,0,1,1] is normalised -> yaw 90 deg
+    pl = [wp.costs[i] for i in range(wp.ncosts) if wp.costs[i].name == b"placement_base_link"][0]
+    R = np.array(pl.ref[3:12]).reshape(3, 3)
+    assert np.abs(R - np.array([[0, -1, 0], [1, 0, 0], [0, 0, 1.0]])).max() < 1e-12
+    assert [pl.ref[i] for i in range(3)] == [1, 0, 2] and pl.activation == T.ACT_QUAD and pl.nr == 6
+    ec = problems["eagle_catch"][1].desc
+    g = ec.sets[2]
+    assert g.ncontacts == 1 and g.contacts[0].type == 0
+    cone = [g.costs[i] for i in range(g.ncosts) if g.costs[i].name == b"friction_cone"][0]
+    assert cone.nr == 5 and cone.ref[3] == 0.7 and cone.ub[0] == 0 and cone.lb[4] == 0 and np.isinf(cone.lb[0])
+    # gripper and base link frames resolved
+    m = ec.model
+    fn = [m.frame_name[i].value.decode() for i in range(m.nframes)]
+    assert "flying_arm_3__gripper" in fn and "hexacopter370__base_link" in fn
+
+
+def test_stage_quirks(empc, problems):
+    t = problems["displacement"][0]
+    info = [t.stage_info(i) for i in range(t.n_stages)]
+    assert [s["name"] for s in info] == ["nav_wp1", "wp_1", "nav_wp2", "wp_2", "nav_wp3", "wp_3", "nav_wp4", "wp_4"]
+    # 'transition' is true iff the key exists (src/utils/parser_yaml.cpp:274-278)
+    assert [s["is_transition"] for s in info] == [True, False] * 4
+    assert t.duration == 8000
+    assert t.get_param("stages/nav_wp1/costs/reg_state/weight") == "1e-1"
+    assert t.get_param("robot/platform/n_rotors") == "6"
+    with pytest.raises(KeyError):
+        t.get_param("stages/nav_wp1/costs/nope/weight")
+
+
+def test_yaml_edge_cases(empc, tmp_path):
+    """active-key quirk (src/stage.cpp:55-61), transition quirk, exponent inside a vector rejected
+    (src/utils/converter_utils.cpp:39-40), two consecutive zero-duration stages rejected (src/trajectory.cpp:74-76)."""
+    base = """trajectory:
+  robot:
+    name: "hexacopter370"
+    urdf: "hexacopter370_description/urdf/hexacopter370.urdf"
+    follow: "hexacopter370/platform/hexacopter370.yaml"
+  stages:
+    - name: "a"
+      duration: 400
+      transition: false
+      costs:
+        - name: "c_on"
+          type: "CostModelControl"
+          weight: 1
+          active: false
+        - name: "c_off"
+          type: "CostModelControl"
+          weight: 2
+          active: 1
+        - name: "c_def"
+          type: "CostModelState"
+          weight: 3
+%s
+"""
+    p = tmp_path / "t.yaml"
+    p.write_text(base % "")
+    t = empc.Trajectory()
+    t.autoSetup(str(p))
+    assert t.stage_info(0)["is_transition"] is True  # key present, value ignored
+    prob = t.createProblem(40, True, "IntegratedActionModelEuler")
+    s = prob.desc.sets[0]
+    act = {s.costs[i].name.decode(): s.costs[i].active for i in range(s.ncosts)}
+    assert act == {"c_def": 1, "c_off": 0, "c_on": 1}  # inactive only when 'active' parses as a number
+    assert prob.T == 10 and prob.desc.sets[0].costs[0].activation == empc.T.ACT_QUAD
+    # exponent inside a vector: a malformed 'reference' is swallowed and replaced by the zero state
+    # (try/catch at src/factory/cost.cpp:41-47) ...
+    p.write_text(base % "          reference: [0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 1e-3]")
+    t2 = empc.Trajectory()
+    t2.autoSetup(str(p))
+    prob2 = t2.createProblem(40, True, "IntegratedActionModelEuler")
+    c = [c for c in prob2.desc.sets[0].costs if c.name == b"c_def"][0]
+    assert [c.ref[i] for i in range(13)] == [0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0]
+    # ... but barrier bounds are read outside any try block (src/factory/activation.cpp:52-55) and must throw
+    bounds = ("          activation: \"ActivationModelQuadraticBarrier\"\n"
+              "          l_bound: [0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1e-3]\n"
+              "          u_bound: [0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1]")
+    p.write_text(base % bounds)
+    with pytest.raises(empc.EmpcError, match="Invalid string representation of a Matrix"):
+        empc.Trajectory().autoSetup(str(p))
+    # wrong reference dimension
+    p.write_text(base % "          reference: [0, 0, 0, 0, 0, 0, 1]")
+    with pytest.raises(empc.EmpcError, match="has dimension 7"):
+        empc.Trajectory().autoSetup(str(p))
+    # two consecutive zero-duration stages
+    two = base % "" + """    - name: "b"
+      duration: 0
+      costs:
+        - name: "x"
+          type: "CostModelControl"
+          weight: 1
+    - name: "c"
+      duration: 0
+      costs:
+        - name: "x"
+          type: "CostModelControl"
+          weight: 1
+"""
+    p.write_text(two)
+    with pytest.raises(empc.EmpcError, match="Two consecutives stages"):
+        empc.Trajectory().autoSetup(str(p))
+    with pytest.raises(empc.EmpcError, match="Couldn't load file"):
+        empc.Trajectory().autoSetup(str(tmp_path / "missing.yaml"))
+    p.write_text("something_else:\n  a: 1\n")
+    with pytest.raises(empc.EmpcError, match="neither a trajectory or an mpc_controller"):
+        empc.Trajectory().autoSetup(str(p))
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/yaml"), reason="reference tree not mounted")
+def test_all_reference_trajectory_yamls_parse(empc):
+    """Every trajectory YAML the reference ships goes through the parser + factories whenever its robot model is one of
+    the build-authored URDFs (the reference tree is read here only in this container, never on the GPU box)."""
+    parsed = 0
+    for f in sorted(glob.glob("/root/reference/yaml/*/trajectories/*.yaml")):
+        robot = f.split("/")[-3]
+        if robot.startswith(("iris", "hexacopter680")):
+            continue  # URDFs not authored in this round (iris has no arm; 680 has a 2-dof arm)
+        import empc_loader  # data dir must point at the reference tree for the 'follow:' includes
+        empc.lib().empc_set_data_dirs(b"/root/reference/yaml", empc.ROBOT_DIR.encode())
+        try:
+            t = empc.Trajectory()
+            t.autoSetup(f)
+            assert t.n_stages >= 1
+            parsed += 1
+        finally:
+            empc.lib().empc_set_data_dirs(empc.YAML_DIR.encode(), empc.ROBOT_DIR.encode())
+    assert parsed >= 9
+
+
+def test_robot_models(problems):
+    m = problems["displacement"][1].desc.model
+    assert m.nbodies == 4 and m.nq == 10 and m.nv == 9
+    assert [m.parent[i] for i in range(4)] == [-1, 0, 1, 2]
+    # fixed rotor links are merged into the base: 1.52 + 6 * 0.025
+    assert abs(m.mass[0] - 1.67) < 1e-12
+    total = sum(m.mass[i] for i in range(4))
+    assert 6 * 20.6991 > 2.5 * total * 9.81  # hovers comfortably (SURVEY 8(c) fixture 1)
+    mt = problems["push_slide"][1].desc.model
+    assert mt.nbodies == 6 and [tuple(mt.axis[i]) for i in range(1, 6)] == [(0, 0, 1), (0, 1, 0), (0, 1, 0), (0, 1, 0), (1, 0, 0)]
