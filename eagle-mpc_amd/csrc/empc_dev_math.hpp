@@ -16,6 +16,19 @@
 #define EMPC_HD inline
 #endif
 
+// Read-only problem data (model, cost tables, solver constants) is addressed through the AMDGPU constant address
+// space on the device: wave-uniform loads then become scalar (s_load) instructions and the values live in SGPRs
+// instead of occupying vector registers and the vector-memory pipeline.
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+#define EMPC_K __attribute__((address_space(4)))
+#define EMPC_KREF(T, ptr) (*(const EMPC_K T*)(unsigned long long)(ptr))
+#define EMPC_KPTR(T, ptr) ((const EMPC_K T*)(unsigned long long)(ptr))
+#else
+#define EMPC_K
+#define EMPC_KREF(T, ptr) (*(ptr))
+#define EMPC_KPTR(T, ptr) (ptr)
+#endif
+
 namespace empc {
 
 // ---- one-direction dual number -------------------------------------------------------------------

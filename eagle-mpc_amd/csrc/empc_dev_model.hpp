@@ -71,7 +71,7 @@ EMPC_HD void axis_rot(const double* ax, const S& c, const S& s, S* R) {
 
 // spatial inertia of body b applied to a motion (body frame): [m (v + w x c); Ic w + c x m (v + w x c)]
 template <class S>
-EMPC_HD void inertia_apply(const EmpcModelDesc& m, int b, const S* mot, S* out) {
+EMPC_HD void inertia_apply(const EMPC_K EmpcModelDesc& m, int b, const S* mot, S* out) {
   S wxc[3], lin[3], Iw[3], cxl[3];
   cross3<S>(mot + 3, m.com[b], wxc);
 #pragma unroll
@@ -95,7 +95,7 @@ struct FrameCap {
   S a[6];        // LOCAL spatial acceleration (of the recursion's a, i.e. including the gravity offset if enabled)
 };
 template <class S>
-EMPC_HD void frame_capture(const EmpcModelDesc& m, int f, const S* Rb, const S* pb, const S* vb, const S* ab,
+EMPC_HD void frame_capture(const EMPC_K EmpcModelDesc& m, int f, const S* Rb, const S* pb, const S* vb, const S* ab,
                            FrameCap<S>& fk) {
   matmul3<S>(Rb, m.frame_R[f], fk.R);
   S Rp[3];
@@ -123,7 +123,7 @@ EMPC_HD void frame_capture(const EmpcModelDesc& m, int f, const S* Rb, const S* 
 // Register discipline: only the per-body forces survive the forward sweep; joint rotations are rebuilt from cs/sn
 // in the backward sweep.
 template <int NB, class S>
-EMPC_HD void rnea_chain(const EmpcModelDesc& m, const S* R0, const S* p0, const S* cs, const S* sn, const S* v,
+EMPC_HD void rnea_chain(const EMPC_K EmpcModelDesc& m, const S* R0, const S* p0, const S* cs, const S* sn, const S* v,
                         const S* a, bool gravity, int fext_b, const S* fext, S* tau, int ncap, const int* cap_frames,
                         FrameCap<S>* caps) {
   S f[NB][6];
@@ -235,7 +235,7 @@ EMPC_HD void rnea_chain(const EmpcModelDesc& m, const S* R0, const S* p0, const 
 // Composite-rigid-body algorithm on a serial chain; output: packed lower triangle of M (idx(i,j) = i(i+1)/2 + j).
 // Composite inertias are carried as (mass, COM, rotational inertia about the COM) in body axes.
 template <int NB>
-EMPC_HD void crba_chain(const EmpcModelDesc& m, const double* cs, const double* sn, double* Mp) {
+EMPC_HD void crba_chain(const EMPC_K EmpcModelDesc& m, const double* cs, const double* sn, double* Mp) {
   constexpr int NV = 6 + NB - 1;
   double XR[NB][9];
   double cm[NB], cc[NB][3], cI[NB][9];
@@ -409,7 +409,7 @@ EMPC_HD void activation1(int act, double r, double w, double lb, double ub, doub
 }
 // weight of component i of cost c, with the barrier cost's weights derived from the trajectory's current smooth
 // (SolverSbFDDP::barrierUpdate, src/sbfddp.cpp:464-477)
-EMPC_HD double act_weight(const EmpcCost& c, int i, double smooth, const DevProblem& P) {
+EMPC_HD double act_weight(const EMPC_K EmpcCost& c, int i, double smooth, const EMPC_K DevProblem& P) {
   if (c.is_barrier) {
     const double aux = smooth * (P.u_ub[i] - P.u_lb[i]);
     return 1.0 / (aux * aux);
@@ -419,15 +419,17 @@ EMPC_HD double act_weight(const EmpcCost& c, int i, double smooth, const DevProb
 
 // StateMultibody::diff(x0, x1) for the free-flyer + joints layout; also returns the translation part of
 // M0^-1 M1 (needed by Jlog6)
-template <class DM>
-EMPC_HD void state_diff(const double* x0, const double* x1, double* dx, double* dpl_out) {
+template <class DM, class X0, class X1>
+EMPC_HD void state_diff(const X0* x0, const X1* x1, double* dx, double* dpl_out) {
   double qc[4] = {-x0[3], -x0[4], -x0[5], x0[6]};
+  double q0[4] = {x0[3], x0[4], x0[5], x0[6]};
+  double q1[4] = {x1[3], x1[4], x1[5], x1[6]};
   double qd[4], R0[9], dp[3], dpl[3];
-  quat_mul(qc, x1 + 3, qd);
+  quat_mul(qc, q1, qd);
   quat_normalize(qd);
 #pragma unroll
   for (int i = 0; i < 3; ++i) dp[i] = x1[i] - x0[i];
-  quat_to_R(x0 + 3, R0);
+  quat_to_R(q0, R0);
   matTvec3<double>(R0, dp, dpl);
   log6_quat(qd, dpl, dx);
 #pragma unroll
@@ -441,13 +443,14 @@ EMPC_HD void state_diff(const double* x0, const double* x1, double* dx, double* 
   }
 }
 // StateMultibody::integrate(x, dx); optionally returns the translation of exp6(dx[0:6]) (for Jexp6)
-template <class DM>
-EMPC_HD void state_integrate(const double* x, const double* dx, double* xout, double* pe_out) {
+template <class DM, class X0>
+EMPC_HD void state_integrate(const X0* x, const double* dx, double* xout, double* pe_out) {
   double qe[4], pe[3], R0[9], Rp[3], qn[4];
+  double q0[4] = {x[3], x[4], x[5], x[6]};
   exp6_quat(dx, qe, pe);
-  quat_to_R(x + 3, R0);
+  quat_to_R(q0, R0);
   matvec3<double>(R0, pe, Rp);
-  quat_mul(x + 3, qe, qn);
+  quat_mul(q0, qe, qn);
   quat_normalize(qn);
 #pragma unroll
   for (int i = 0; i < 3; ++i) xout[i] = x[i] + Rp[i];
@@ -492,11 +495,11 @@ EMPC_HD void cone_rows(const double* nsurf, double mu, double AR[5][3]) {
 // Outputs: xnext[NX], acc[NV] (generalized acceleration, reused by linearize), cost, usq[NU] (squashed control),
 //          lam[6] (contact force).
 // ---------------------------------------------------------------------------------------------------------
-template <class DM>
-EMPC_HD void node_nominal(const DevProblem& P, const EmpcCostSet& set, double smooth, const double* x, const double* s_in,
+template <class DM, bool CT>
+EMPC_HD void node_nominal(const EMPC_K DevProblem& P, const EMPC_K EmpcCostSet& set, double smooth, const double* x, const double* s_in,
                           bool terminal, double* xnext, double* acc, double& cost_out, double* usq, double* lam_out) {
   constexpr int NB = DM::NB, NV = DM::NV, NQ = DM::NQ, NU = DM::NU, NROT = DM::NROT;
-  const EmpcModelDesc& m = P.model;
+  const EMPC_K EmpcModelDesc& m = P.model;
   const double dt = P.dt;
   double s[NU], u[NU];
 #pragma unroll
@@ -535,7 +538,7 @@ EMPC_HD void node_nominal(const DevProblem& P, const EmpcCostSet& set, double sm
   int capf[NCAP] = {0, 0};
   int ncap = 0;
   for (int ci = 0; ci < set.ncosts; ++ci) {
-    const EmpcCost& c = set.costs[ci];
+    const EMPC_K EmpcCost& c = set.costs[ci];
     if (!c.active || c.frame < 0 || c.type == EMPC_COST_CONTACT_FRICTION_CONE) continue;
     bool seen = false;
 #pragma unroll
@@ -562,10 +565,10 @@ EMPC_HD void node_nominal(const DevProblem& P, const EmpcCostSet& set, double sm
   for (int i = 0; i < NV; ++i) a[i] = tau[i] - h[i];
   chol_solve_packed<NV>(L, a);
   double lam[6] = {0, 0, 0, 0, 0, 0};
-  const bool use_contact = P.has_contact && set.ncontacts > 0;
-  if (use_contact) {
+  const bool use_contact = CT && P.has_contact && set.ncontacts > 0;
+  if constexpr (CT) if (use_contact) {
     // ContactModel3D/6D: [M Jc^T; Jc 0][a; -lam] = [tau - h; -a0]
-    const EmpcContact& ct = set.contacts[0];
+    const EMPC_K EmpcContact& ct = set.contacts[0];
     const int nc = (ct.type == EMPC_CONTACT_3D) ? 3 : 6;
     int cf[1] = {ct.frame};
     FrameCap<double> ck[1];
@@ -647,7 +650,7 @@ EMPC_HD void node_nominal(const DevProblem& P, const EmpcCostSet& set, double sm
   // costs (A.6)
   double ell = 0;
   for (int ci = 0; ci < set.ncosts; ++ci) {
-    const EmpcCost& c = set.costs[ci];
+    const EMPC_K EmpcCost& c = set.costs[ci];
     if (!c.active) continue;
     double cval = 0;
     if (c.type == EMPC_COST_STATE) {
@@ -668,7 +671,8 @@ EMPC_HD void node_nominal(const DevProblem& P, const EmpcCostSet& set, double sm
       }
     } else if (c.type == EMPC_COST_CONTACT_FRICTION_CONE) {
       double AR[5][3];
-      cone_rows(c.ref, c.ref[3], AR);
+      double nsf[3] = {c.ref[0], c.ref[1], c.ref[2]};
+      cone_rows(nsf, c.ref[3], AR);
       for (int i = 0; i < 5; ++i) {
         double r = use_contact ? (AR[i][0] * lam[0] + AR[i][1] * lam[1] + AR[i][2] * lam[2]) : 0.0;
         double av, Ar, Arr;

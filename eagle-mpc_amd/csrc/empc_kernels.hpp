@@ -83,7 +83,7 @@ struct LaneExec {
 // =====================================================================================================================
 // calc: IAM.calc at (xs[t], us[t]) -> acc (and the last-calc control).  One lane per (b, t).
 // =====================================================================================================================
-template <class DM>
+template <class DM, bool CT>
 EMPC_HD void calc_thread(const DevBuffers& D, int b, int t) {
   const TrajState& st = D.st[b];
   if (st.phase == PHASE_DONE || !st.need_calc) return;
@@ -91,7 +91,7 @@ EMPC_HD void calc_thread(const DevBuffers& D, int b, int t) {
   const double* x = D.xs + ((size_t)b * (T + 1) + t) * DM::NX;
   const double* u = (t < T) ? D.us + ((size_t)b * T + t) * DM::NU : nullptr;
   double xnext[DM::NX], acc[DM::NV], usq[DM::NU], cost;
-  node_nominal<DM>(*D.P, D.sets[D.knot_set[t]], st.smooth, x, u, t == T, xnext, acc, cost, usq, nullptr);
+  node_nominal<DM, CT>(EMPC_KREF(DevProblem, D.P), EMPC_KPTR(EmpcCostSet, D.sets)[EMPC_KPTR(int, D.knot_set)[t]], st.smooth, x, u, t == T, xnext, acc, cost, usq, nullptr);
   double* ao = D.acc + ((size_t)b * (T + 1) + t) * DM::NV;
   for (int i = 0; i < DM::NV; ++i) ao[i] = acc[i];
   if (t < T) {
@@ -103,7 +103,7 @@ EMPC_HD void calc_thread(const DevBuffers& D, int b, int t) {
 // =====================================================================================================================
 // rollout: SolverFDDP::forwardPass(alpha) / SolverSbFDDP::forwardPassDDP(alpha).  One lane per (b, alpha index).
 // =====================================================================================================================
-template <class DM>
+template <class DM, bool CT>
 EMPC_HD void rollout_thread(const DevBuffers& D, int b, int ai) {
   const TrajState& st = D.st[b];
   if (st.phase == PHASE_DONE || st.bwd_failed) return;
@@ -147,11 +147,11 @@ EMPC_HD void rollout_thread(const DevBuffers& D, int b, int ai) {
         for (int j = 0; j < NDX; ++j) a_ -= KK[i * NDX + j] * dx[j];
         utry[i] = a_;
       }
-      node_nominal<DM>(*D.P, D.sets[D.knot_set[t]], smooth, xtry, utry, false, xnext, acc, cost, usq, nullptr);
+      node_nominal<DM, CT>(EMPC_KREF(DevProblem, D.P), EMPC_KPTR(EmpcCostSet, D.sets)[EMPC_KPTR(int, D.knot_set)[t]], smooth, xtry, utry, false, xnext, acc, cost, usq, nullptr);
       for (int i = 0; i < NU; ++i) us_o[(size_t)t * NU + i] = utry[i];
     } else {
       double xn2[NX];
-      node_nominal<DM>(*D.P, D.sets[D.knot_set[t]], smooth, xtry, nullptr, true, xn2, acc, cost, usq, nullptr);
+      node_nominal<DM, CT>(EMPC_KREF(DevProblem, D.P), EMPC_KPTR(EmpcCostSet, D.sets)[EMPC_KPTR(int, D.knot_set)[t]], smooth, xtry, nullptr, true, xn2, acc, cost, usq, nullptr);
     }
     for (int i = 0; i < NX; ++i) xs_o[(size_t)t * NX + i] = xtry[i];
     for (int i = 0; i < NV; ++i) ac_o[(size_t)t * NV + i] = acc[i];
@@ -211,12 +211,12 @@ EMPC_HD void linearize_unit(Exec& ex, const DevBuffers& D, int b, int t, int lpu
   constexpr int REC = DM::REC;
   static_assert(NU <= NV, "control columns reuse the NV inertia-column lanes");
   typedef LinSmem<DM> SM;
-  const DevProblem& P = *D.P;
-  const EmpcModelDesc& m = P.model;
+  const EMPC_K DevProblem& P = EMPC_KREF(DevProblem, D.P);
+  const EMPC_K EmpcModelDesc& m = P.model;
   const TrajState& st = D.st[b];
   const int T = D.T;
   const bool terminal = (t == T);
-  const EmpcCostSet& set = D.sets[D.knot_set[t]];
+  const EMPC_K EmpcCostSet& set = EMPC_KPTR(EmpcCostSet, D.sets)[EMPC_KPTR(int, D.knot_set)[t]];
   const double dt = P.dt;
   const double smooth = st.smooth;
   double* rec = smem + SM::OFF_REC;
@@ -254,7 +254,7 @@ EMPC_HD void linearize_unit(Exec& ex, const DevBuffers& D, int b, int t, int lpu
 #pragma unroll
     for (int k = 0; k < NCAP; ++k) L.capf[k] = 0;
     for (int ci = 0; ci < set.ncosts; ++ci) {
-      const EmpcCost& c = set.costs[ci];
+      const EMPC_K EmpcCost& c = set.costs[ci];
       if (!c.active || c.frame < 0 || c.type == EMPC_COST_CONTACT_FRICTION_CONE) continue;
       bool seen = false;
 #pragma unroll
@@ -455,7 +455,7 @@ EMPC_HD void linearize_unit(Exec& ex, const DevBuffers& D, int b, int t, int lpu
 
   // ---- stage C: costs (Gauss-Newton), CostModelSum order ------------------------------------------------------
   for (int ci = 0; ci < set.ncosts; ++ci) {
-    const EmpcCost& c = set.costs[ci];
+    const EMPC_K EmpcCost& c = set.costs[ci];
     if (!c.active) continue;
     const double w = c.weight;
     if (c.type == EMPC_COST_STATE) {
@@ -657,7 +657,7 @@ EMPC_HD void backward_traj(Exec& ex, const DevBuffers& D, int b, double* smem) {
   constexpr int NH = NL / CW;                // row halves handled in parallel
   TrajState& st = D.st[b];
   if (st.phase == PHASE_DONE) return;
-  const DevProblem& P = *D.P;
+  const EMPC_K DevProblem& P = EMPC_KREF(DevProblem, D.P);
   const int T = D.T;
   double* rec = smem + SM::OFF_REC;
   double* V = smem + SM::OFF_V;
@@ -967,8 +967,8 @@ EMPC_HD void backward_traj(Exec& ex, const DevBuffers& D, int b, double* smem) {
 template <class DM>
 EMPC_HD void select_decide(const DevBuffers& D, int b, int& accepted_ai, int& last_ai) {
   TrajState& st = D.st[b];
-  const DevProblem& P = *D.P;
-  const EmpcSolverParams& prm = P.prm;
+  const EMPC_K DevProblem& P = EMPC_KREF(DevProblem, D.P);
+  const EMPC_K EmpcSolverParams& prm = P.prm;
   const int NA = D.NA;
   accepted_ai = -1;
   last_ai = -1;

@@ -37,7 +37,7 @@ __global__ void __launch_bounds__(64) k_calc(DevBuffers D) {
   if (idx >= n) return;
   // consecutive lanes = consecutive trajectories of the same node (same cost set -> no divergence)
   const int t = idx / D.B, b = idx % D.B;
-  calc_thread<DM>(D, b, t);
+  calc_thread<DM, false>(D, b, t);
 }
 
 template <class DM>
@@ -45,7 +45,7 @@ __global__ void __launch_bounds__(64) k_rollout(DevBuffers D) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= D.B * D.NA) return;
   const int b = idx / D.NA, ai = idx % D.NA;
-  rollout_thread<DM>(D, b, ai);
+  rollout_thread<DM, false>(D, b, ai);
 }
 
 template <class DM, int LPU>
@@ -93,7 +93,7 @@ __global__ void k_squash_out(DevBuffers D, double* out) {
   const int n = D.B * D.T * DM::NU;
   if (idx >= n) return;
   const int b = idx / (D.T * DM::NU), i = idx % DM::NU;
-  const DevProblem& P = *D.P;
+  const EMPC_K DevProblem& P = EMPC_KREF(DevProblem, D.P);
   double u = D.us_last[idx], du;
   if (P.use_squash) squash1(D.us_last[idx], P.u_lb[i], P.u_ub[i], D.st[b].smooth, P.prm.smoothsat_power, u, du);
   out[idx] = u;
@@ -163,9 +163,7 @@ static KernelTable make_table() {
   return k;
 }
 static bool find_table(int nb, int nrot, KernelTable& k) {
-  if (nb == 1 && nrot == 4) k = make_table<Dims<1, 4>>();
-  else if (nb == 1 && nrot == 6) k = make_table<Dims<1, 6>>();
-  else if (nb == 3 && nrot == 6) k = make_table<Dims<3, 6>>();
+  if (nb == 1 && nrot == 6) k = make_table<Dims<1, 6>>();
   else if (nb == 4 && nrot == 6) k = make_table<Dims<4, 6>>();
   else if (nb == 6 && nrot == 6) k = make_table<Dims<6, 6>>();
   else return false;
@@ -265,6 +263,8 @@ EmpcSolver* empc_solver_create(const EmpcProblemDesc* problem, const EmpcSolverP
   s = new EmpcSolver();
   s->device = device;
   prepare_problem(*problem, prm, s->H);
+  if (problem->has_contact)
+    throw std::runtime_error("contact forward dynamics (ContactModel3D/6D) is not implemented on the device yet");
   if (!find_table(problem->model.nbodies, problem->n_rotors, s->kt)) {
     delete s;
     empc::set_last_error("no kernel instantiation for this (bodies, rotors) combination");

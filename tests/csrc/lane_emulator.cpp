@@ -90,7 +90,7 @@ static void emu_alloc(Emu& e) {
 template <class DM>
 static void emu_calc(Emu& e) {
   for (int b = 0; b < e.B; ++b)
-    for (int t = 0; t <= e.T; ++t) calc_thread<DM>(e.D, b, t);
+    for (int t = 0; t <= e.T; ++t) calc_thread<DM, false>(e.D, b, t);
 }
 template <class DM>
 static void emu_linearize(Emu& e) {
@@ -115,7 +115,7 @@ static void emu_backward(Emu& e) {
 template <class DM>
 static void emu_rollout(Emu& e) {
   for (int b = 0; b < e.B; ++b)
-    for (int ai = 0; ai < e.NA; ++ai) rollout_thread<DM>(e.D, b, ai);
+    for (int ai = 0; ai < e.NA; ++ai) rollout_thread<DM, false>(e.D, b, ai);
 }
 template <class DM>
 static void emu_select(Emu& e) {
