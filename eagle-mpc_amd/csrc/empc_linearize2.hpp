@@ -1,0 +1,893 @@
+// empc_linearize2.hpp -- HOT-A kernel body, second generation.
+//
+// One (trajectory, node) unit is handled by LPU lanes (32 or 64, never crossing a wavefront):
+//   * every lane-invariant ("nominal") quantity is computed ONCE and kept in LDS: squashed controls, joint rotations,
+//     body velocities / accelerations / momenta / subtree forces, the Cholesky factor of the joint-space inertia, the
+//     Euler step, its Lie Jacobians, cost residuals and their activation derivatives;
+//   * lane j carries only TANGENT quantities of direction j (dq_j, dv_j or da_j) through a hand-derived tangent
+//     recursion of the body-frame Newton-Euler equations, reading nominals from LDS with broadcast reads;
+//   * columns of Fx, Fu, Lxx, Lxu, Luu are produced in registers and stored straight to the tape record.
+// Lanes [0,NV): dq_j   [NV,2NV): dv_j   [2NV,3NV): da_j (-> joint-space inertia columns), then reused as control columns.
+//
+// Semantics: identical to linearize_unit (v1) and to the oracle: crocoddyl IntegratedActionModelEuler::calcDiff over
+// DifferentialActionModelFreeFwdDynamics with ActuationSquashingModel and CostModelSum.
+#pragma once
+#include "empc_kernels.hpp"
+
+namespace empc {
+
+template <class DM>
+struct Lin2Smem {
+  static constexpr int NB = DM::NB, NV = DM::NV, NX = DM::NX, NU = DM::NU, NDX = DM::NDX, NJ = DM::NJ;
+  static constexpr int OFF_X = 0;                   // x | s | a
+  static constexpr int OFF_S = OFF_X + NX;
+  static constexpr int OFF_A = OFF_S + NU;
+  static constexpr int OFF_USQ = OFF_A + NV;        // sigma(s), sigma'(s)
+  static constexpr int OFF_DUS = OFF_USQ + NU;
+  static constexpr int OFF_CS = OFF_DUS + NU;       // cos / sin of the joint angles
+  static constexpr int OFF_SN = OFF_CS + (NJ > 0 ? NJ : 1);
+  static constexpr int OFF_R0 = OFF_SN + (NJ > 0 ? NJ : 1);
+  static constexpr int OFF_GL = OFF_R0 + 9;         // R0^T (-g)
+  static constexpr int OFF_BODY = OFF_GL + 3;       // per body: XR 9 | Rw 9 | pw 3 | VX 6 | AX 6 | vb 6 | Iv 6 | fsub 6
+  static constexpr int BODY = 51;
+  static constexpr int B_XR = 0, B_RW = 9, B_PW = 18, B_VX = 21, B_AX = 27, B_VB = 33, B_IV = 39, B_FS = 45;
+  static constexpr int OFF_M = OFF_BODY + NB * BODY;  // NV x NV: inertia columns, then the Cholesky factor (recip. diagonal)
+  static constexpr int OFF_DXE = OFF_M + NV * NV;     // Euler step dx (NDX), J2 = Jexp6 (36), J1 (36), xnext (NX)
+  static constexpr int OFF_J2 = OFF_DXE + NDX;
+  static constexpr int OFF_J1 = OFF_J2 + 36;
+  static constexpr int OFF_XN = OFF_J1 + 36;
+  static constexpr int OFF_GAP = OFF_XN + NX;         // gap written to the next record (NDX) and, for t = 0, fs[0] (NDX)
+  static constexpr int OFF_FR = OFF_GAP + 2 * NDX;    // per captured frame: R 9 | p 3 | v 6
+  static constexpr int OFF_CST = OFF_FR + NCAP * 18;  // cost nominal slots
+  static constexpr int NSLOT = 4;
+  static constexpr int SLOT = 3 * NDX + 36 + 4;       // r | Ar | Arr | J6 | value
+  static constexpr int OFF_RSH = OFF_CST + NSLOT * SLOT;  // residual-Jacobian exchange 6 x NDX
+  static constexpr int OFF_RED = OFF_RSH + 6 * NDX;   // small reduction area (cost partial sums) 64
+  static constexpr int SIZE = (OFF_RED + 64 + 1) / 2 * 2;
+};
+
+// forward kinematics + nominal Newton-Euler quantities of one unit, executed by ONE lane
+template <class DM>
+EMPC_HD void lin2_nominal_chain(const EMPC_K EmpcModelDesc& m, double* N) {
+  typedef Lin2Smem<DM> SM;
+  constexpr int NB = DM::NB, NQ = DM::NQ, NX = DM::NX;
+  const double* x = N + SM::OFF_X;
+  const double* acc = N + SM::OFF_A;
+  const double* R0 = N + SM::OFF_R0;
+  double* gl = N + SM::OFF_GL;
+  {
+    double ng[3] = {-m.gravity[0], -m.gravity[1], -m.gravity[2]};
+    matTvec3<double>(R0, ng, gl);
+  }
+  // body 0
+  {
+    double* B0 = N + SM::OFF_BODY;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) B0[SM::B_RW + i] = R0[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) B0[SM::B_PW + i] = x[i];
+    double vb[6], ab[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      vb[i] = x[NQ + i];
+      ab[i] = acc[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) ab[i] += gl[i];
+    double Iv[6], Ia[6], c1[3], c2[3], c3[3];
+    inertia_apply<double>(m, 0, vb, Iv);
+    inertia_apply<double>(m, 0, ab, Ia);
+    cross3<double>(vb + 3, Iv, c1);
+    cross3<double>(vb + 3, Iv + 3, c2);
+    cross3<double>(vb, Iv, c3);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      B0[SM::B_VB + i] = vb[i];
+      B0[SM::B_IV + i] = Iv[i];
+      B0[SM::B_VX + i] = 0.0;
+      B0[SM::B_AX + i] = ab[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      B0[SM::B_FS + i] = Ia[i] + c1[i];
+      B0[SM::B_FS + 3 + i] = Ia[3 + i] + c2[i] + c3[i];
+    }
+  }
+#pragma unroll
+  for (int b = 1; b < NB; ++b) {
+    double* Bb = N + SM::OFF_BODY + b * SM::BODY;
+    const double* Bp = N + SM::OFF_BODY + (b - 1) * SM::BODY;
+    double Rj[9], XR[9];
+    axis_rot<double>(m.axis[b], N[SM::OFF_CS + b - 1], N[SM::OFF_SN + b - 1], Rj);
+    matmul3<double>(m.jplace_R[b], Rj, XR);
+    double Rw[9], Rr[3];
+    matmul3<double>(Bp + SM::B_RW, XR, Rw);
+    matvec3<double>(Bp + SM::B_RW, m.jplace_p[b], Rr);
+    const double* vp = Bp + SM::B_VB;
+    // parent acceleration (full, including joint terms) is reconstructed below and kept in `ap`
+    double ap[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) ap[i] = Bp[SM::B_AX + i];  // for body 0 AX holds the full base acceleration
+    if (b > 1) {
+      // full acceleration of the parent = AX + S qdd + v x (S qd)
+      const double qd = x[NQ + 6 + (b - 1) - 1], qdd = acc[6 + (b - 1) - 1];
+      double sv[3], c1[3], c2[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) sv[i] = m.axis[b - 1][i] * qd;
+      cross3<double>(vp, sv, c1);
+      cross3<double>(vp + 3, sv, c2);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        ap[i] += c1[i];
+        ap[3 + i] += m.axis[b - 1][i] * qdd + c2[i];
+      }
+    }
+    double wxr[3], tmp[3], VX[6], AX[6];
+    cross3<double>(vp + 3, m.jplace_p[b], wxr);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) tmp[i] = vp[i] + wxr[i];
+    matTvec3<double>(XR, tmp, VX);
+    matTvec3<double>(XR, vp + 3, VX + 3);
+    cross3<double>(ap + 3, m.jplace_p[b], wxr);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) tmp[i] = ap[i] + wxr[i];
+    matTvec3<double>(XR, tmp, AX);
+    matTvec3<double>(XR, ap + 3, AX + 3);
+    const double qd = x[NQ + 6 + b - 1], qdd = acc[6 + b - 1];
+    double vb[6], ab[6], sv[3], c1[3], c2[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) sv[i] = m.axis[b][i] * qd;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      vb[i] = VX[i];
+      vb[3 + i] = VX[3 + i] + sv[i];
+    }
+    cross3<double>(vb, sv, c1);
+    cross3<double>(vb + 3, sv, c2);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      ab[i] = AX[i] + c1[i];
+      ab[3 + i] = AX[3 + i] + m.axis[b][i] * qdd + c2[i];
+    }
+    double Iv[6], Ia[6], d1[3], d2[3], d3[3];
+    inertia_apply<double>(m, b, vb, Iv);
+    inertia_apply<double>(m, b, ab, Ia);
+    cross3<double>(vb + 3, Iv, d1);
+    cross3<double>(vb + 3, Iv + 3, d2);
+    cross3<double>(vb, Iv, d3);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      Bb[SM::B_XR + i] = XR[i];
+      Bb[SM::B_RW + i] = Rw[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) Bb[SM::B_PW + i] = Bp[SM::B_PW + i] + Rr[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      Bb[SM::B_VX + i] = VX[i];
+      Bb[SM::B_AX + i] = AX[i];
+      Bb[SM::B_VB + i] = vb[i];
+      Bb[SM::B_IV + i] = Iv[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      Bb[SM::B_FS + i] = Ia[i] + d1[i];
+      Bb[SM::B_FS + 3 + i] = Ia[3 + i] + d2[i] + d3[i];
+    }
+  }
+  // subtree forces
+#pragma unroll
+  for (int b = NB - 1; b >= 1; --b) {
+    double* Bb = N + SM::OFF_BODY + b * SM::BODY;
+    double* Bp = N + SM::OFF_BODY + (b - 1) * SM::BODY;
+    double fl[3], fn[3], rxf[3];
+    matvec3<double>(Bb + SM::B_XR, Bb + SM::B_FS, fl);
+    matvec3<double>(Bb + SM::B_XR, Bb + SM::B_FS + 3, fn);
+    cross3<double>(m.jplace_p[b], fl, rxf);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      Bp[SM::B_FS + i] += fl[i];
+      Bp[SM::B_FS + 3 + i] += fn[i] + rxf[i];
+    }
+  }
+}
+
+// tangent of the inertia-weighted force: dF = I da + dv x* (I v) + v x* (I dv)
+template <class DM>
+EMPC_HD void lin2_dforce(const EMPC_K EmpcModelDesc& m, int b, const double* Bb, const double* dv, const double* da,
+                         double* df) {
+  typedef Lin2Smem<DM> SM;
+  double Ida[6], Idv[6], c1[3], c2[3], c3[3], e1[3], e2[3], e3[3];
+  inertia_apply<double>(m, b, da, Ida);
+  inertia_apply<double>(m, b, dv, Idv);
+  const double* Iv = Bb + SM::B_IV;
+  const double* vb = Bb + SM::B_VB;
+  cross3<double>(dv + 3, Iv, c1);
+  cross3<double>(dv + 3, Iv + 3, c2);
+  cross3<double>(dv, Iv, c3);
+  cross3<double>(vb + 3, Idv, e1);
+  cross3<double>(vb + 3, Idv + 3, e2);
+  cross3<double>(vb, Idv, e3);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    df[i] = Ida[i] + c1[i] + e1[i];
+    df[3 + i] = Ida[3 + i] + c2[i] + c3[i] + e2[i] + e3[i];
+  }
+}
+
+// Tangent recursion of RNEA(q, v, a) for the direction owned by `lane`. Outputs dtau[NV]; capdv[c] = d(body velocity)
+// of the body carrying captured frame c.
+template <class DM>
+EMPC_HD void lin2_tangent(const EMPC_K EmpcModelDesc& m, const double* N, int lane, double* dtau, int ncap,
+                          const int* capf, double (*capdv)[6]) {
+  typedef Lin2Smem<DM> SM;
+  constexpr int NB = DM::NB, NV = DM::NV, NQ = DM::NQ, NX = DM::NX;
+  const double* x = N + SM::OFF_X;
+  const bool jq = lane < NV, jv = lane >= NV && lane < 2 * NV, ja = lane >= 2 * NV && lane < 3 * NV;
+  const int kq = lane, kv = lane - NV, ka = lane - 2 * NV;
+  double df[NB][6];
+  double dv[6], da[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    dv[i] = (jv && kv == i) ? 1.0 : 0.0;
+    da[i] = (ja && ka == i) ? 1.0 : 0.0;
+  }
+  if (jq && kq >= 3 && kq < 6) {
+    // d(R0^T (-g)) for a rotation of the base about body axis e: -e x (R0^T (-g))
+    const double* gl = N + SM::OFF_GL;
+    double e[3] = {0, 0, 0}, c[3];
+    e[kq - 3] = 1.0;
+    cross3<double>(e, gl, c);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) da[i] = -c[i];
+  }
+#pragma unroll
+  for (int c = 0; c < NCAP; ++c)
+    if (c < ncap && m.frame_body[capf[c]] == 0) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) capdv[c][i] = dv[i];
+    }
+  lin2_dforce<DM>(m, 0, N + SM::OFF_BODY, dv, da, df[0]);
+#pragma unroll
+  for (int b = 1; b < NB; ++b) {
+    const double* Bb = N + SM::OFF_BODY + b * SM::BODY;
+    const double* XR = Bb + SM::B_XR;
+    const double dth = (jq && kq == 6 + b - 1) ? 1.0 : 0.0;
+    const double dqd = (jv && kv == 6 + b - 1) ? 1.0 : 0.0;
+    const double dqdd = (ja && ka == 6 + b - 1) ? 1.0 : 0.0;
+    const double qd = x[NQ + 6 + b - 1];
+    double ax[3] = {m.axis[b][0], m.axis[b][1], m.axis[b][2]};
+    double t[3], wxr[3], nv[6], na[6], c[3];
+    // velocity
+    cross3<double>(dv + 3, m.jplace_p[b], wxr);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t[i] = dv[i] + wxr[i];
+    matTvec3<double>(XR, t, nv);
+    matTvec3<double>(XR, dv + 3, nv + 3);
+    cross3<double>(ax, Bb + SM::B_VX, c);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) nv[i] -= dth * c[i];
+    cross3<double>(ax, Bb + SM::B_VX + 3, c);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) nv[3 + i] += ax[i] * dqd - dth * c[i];
+    // acceleration
+    cross3<double>(da + 3, m.jplace_p[b], wxr);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t[i] = da[i] + wxr[i];
+    matTvec3<double>(XR, t, na);
+    matTvec3<double>(XR, da + 3, na + 3);
+    cross3<double>(ax, Bb + SM::B_AX, c);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) na[i] -= dth * c[i];
+    cross3<double>(ax, Bb + SM::B_AX + 3, c);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) na[3 + i] += ax[i] * dqdd - dth * c[i];
+    // d( v x (S qd) ) = dv x (ax qd) + v x (ax dqd)
+    {
+      double c1[3], c2[3], c3[3], c4[3];
+      cross3<double>(nv, ax, c1);
+      cross3<double>(nv + 3, ax, c2);
+      cross3<double>(Bb + SM::B_VB, ax, c3);
+      cross3<double>(Bb + SM::B_VB + 3, ax, c4);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        na[i] += c1[i] * qd + c3[i] * dqd;
+        na[3 + i] += c2[i] * qd + c4[i] * dqd;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      dv[i] = nv[i];
+      da[i] = na[i];
+    }
+#pragma unroll
+    for (int cc = 0; cc < NCAP; ++cc)
+      if (cc < ncap && m.frame_body[capf[cc]] == b) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) capdv[cc][i] = dv[i];
+      }
+    lin2_dforce<DM>(m, b, Bb, dv, da, df[b]);
+  }
+#pragma unroll
+  for (int b = NB - 1; b >= 1; --b) {
+    const double* Bb = N + SM::OFF_BODY + b * SM::BODY;
+    const double dth = (jq && kq == 6 + b - 1) ? 1.0 : 0.0;
+    double ax[3] = {m.axis[b][0], m.axis[b][1], m.axis[b][2]};
+    dtau[6 + b - 1] = dot3<double>(ax, df[b] + 3);
+    double c1[3], c2[3], gl_[3], ga[3], pl[3], pa[3], rxf[3];
+    cross3<double>(ax, Bb + SM::B_FS, c1);
+    cross3<double>(ax, Bb + SM::B_FS + 3, c2);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      gl_[i] = df[b][i] + dth * c1[i];
+      ga[i] = df[b][3 + i] + dth * c2[i];
+    }
+    matvec3<double>(Bb + SM::B_XR, gl_, pl);
+    matvec3<double>(Bb + SM::B_XR, ga, pa);
+    cross3<double>(m.jplace_p[b], pl, rxf);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      df[b - 1][i] += pl[i];
+      df[b - 1][3 + i] += pa[i] + rxf[i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) dtau[i] = df[0][i];
+}
+
+// LOCAL frame Jacobian column of generalized velocity `j` for a frame with world placement (Rf, pf) on body bf
+template <class DM>
+EMPC_HD void lin2_frame_jcol(const EMPC_K EmpcModelDesc& m, const double* N, int j, int bf, const double* Rf,
+                             const double* pf, double* col) {
+  typedef Lin2Smem<DM> SM;
+  constexpr int NB = DM::NB, NV = DM::NV;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) col[i] = 0.0;
+  if (j >= NV) return;
+  const double* R0 = N + SM::OFF_R0;
+  if (j < 3) {
+    double w[3] = {R0[j], R0[3 + j], R0[6 + j]};
+    matTvec3<double>(Rf, w, col);
+    return;
+  }
+  double z[3], org[3];
+  if (j < 6) {
+    const int k = j - 3;
+    z[0] = R0[k];
+    z[1] = R0[3 + k];
+    z[2] = R0[6 + k];
+    const double* p0 = N + SM::OFF_BODY + SM::B_PW;
+    org[0] = p0[0];
+    org[1] = p0[1];
+    org[2] = p0[2];
+  } else {
+    const int b = j - 6 + 1;
+    if (b > bf) return;
+    bool found = false;
+#pragma unroll
+    for (int bb = 1; bb < NB; ++bb)
+      if (bb == b) {
+        const double* Bb = N + SM::OFF_BODY + bb * SM::BODY;
+        double ax[3] = {m.axis[bb][0], m.axis[bb][1], m.axis[bb][2]};
+        matvec3<double>(Bb + SM::B_RW, ax, z);
+        org[0] = Bb[SM::B_PW];
+        org[1] = Bb[SM::B_PW + 1];
+        org[2] = Bb[SM::B_PW + 2];
+        found = true;
+      }
+    if (!found) return;
+  }
+  double d[3] = {pf[0] - org[0], pf[1] - org[1], pf[2] - org[2]}, zxd[3];
+  cross3<double>(z, d, zxd);
+  matTvec3<double>(Rf, zxd, col);
+  matTvec3<double>(Rf, z, col + 3);
+}
+
+template <class DM, class Exec>
+EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lpu, double* N) {
+  typedef Lin2Smem<DM> SM;
+  constexpr int NB = DM::NB, NV = DM::NV, NQ = DM::NQ, NX = DM::NX, NDX = DM::NDX, NU = DM::NU, NROT = DM::NROT;
+  constexpr int REC = DM::REC;
+  static_assert(NU <= NV, "control columns reuse the NV inertia-column lanes");
+  const EMPC_K DevProblem& P = EMPC_KREF(DevProblem, D.P);
+  const EMPC_K EmpcModelDesc& m = P.model;
+  const TrajState& st = D.st[b];
+  const int T = D.T;
+  const bool terminal = (t == T);
+  const EMPC_K EmpcCostSet& set = EMPC_KPTR(EmpcCostSet, D.sets)[EMPC_KPTR(int, D.knot_set)[t]];
+  const double dt = P.dt;
+  const double smooth = st.smooth;
+  const bool feas = st.is_feasible != 0;
+  double* out = D.tape + ((size_t)b * (T + 1) + t) * REC;
+
+  // captured frames (uniform over the unit)
+  int capf[NCAP] = {0, 0};
+  int ncap = 0;
+  for (int ci = 0; ci < set.ncosts; ++ci) {
+    const EMPC_K EmpcCost& c = set.costs[ci];
+    if (!c.active || c.frame < 0 || c.type == EMPC_COST_CONTACT_FRICTION_CONE) continue;
+    bool seen = false;
+#pragma unroll
+    for (int k = 0; k < NCAP; ++k) seen = seen || (k < ncap && capf[k] == c.frame);
+    if (!seen) {
+#pragma unroll
+      for (int k = 0; k < NCAP; ++k)
+        if (k == ncap) capf[k] = c.frame;
+      ncap = (ncap < NCAP) ? ncap + 1 : ncap;
+    }
+  }
+
+  // ---- S0: load x, s, a ------------------------------------------------------------------------------------
+  ex.each([&](int lane, int sl) {
+    const double* xg = D.xs + ((size_t)b * (T + 1) + t) * NX;
+    const double* ag = D.acc + ((size_t)b * (T + 1) + t) * NV;
+    const double* ug = D.us + ((size_t)b * T + (terminal ? 0 : t)) * NU;
+    for (int i = lane; i < NX; i += lpu) N[SM::OFF_X + i] = xg[i];
+    for (int i = lane; i < NV; i += lpu) N[SM::OFF_A + i] = ag[i];
+    for (int i = lane; i < NU; i += lpu) N[SM::OFF_S + i] = terminal ? 0.0 : ug[i];
+    if (lane == 0) N[SM::OFF_RED] = 0.0;  // cost accumulator
+  });
+  ex.sync();
+  // ---- S1: squash (lanes < NU), joint sin/cos (next NJ lanes), base rotation (last lane) -------------------------
+  ex.each([&](int lane, int sl) {
+    if (lane < NU) {
+      double u = N[SM::OFF_S + lane], du = 1.0;
+      if (P.use_squash) squash1(N[SM::OFF_S + lane], P.u_lb[lane], P.u_ub[lane], smooth, P.prm.smoothsat_power, u, du);
+      N[SM::OFF_USQ + lane] = u;
+      N[SM::OFF_DUS + lane] = du;
+    } else if (lane < NU + DM::NJ) {
+      const int j = lane - NU;
+      const double th = N[SM::OFF_X + 7 + j];
+      N[SM::OFF_CS + j] = cos(th);
+      N[SM::OFF_SN + j] = sin(th);
+    } else if (lane == lpu - 1) {
+      double q[4] = {N[SM::OFF_X + 3], N[SM::OFF_X + 4], N[SM::OFF_X + 5], N[SM::OFF_X + 6]};
+      double R0[9];
+      quat_to_R(q, R0);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) N[SM::OFF_R0 + i] = R0[i];
+    }
+  });
+  ex.sync();
+  // ---- S2: nominal chain (lane 0) || Euler step and its Lie Jacobians (lane 1) ----------------------------------
+  ex.each([&](int lane, int sl) {
+    if (lane == 0) {
+      lin2_nominal_chain<DM>(m, N);
+      // nominal frame data
+#pragma unroll
+      for (int c = 0; c < NCAP; ++c) {
+        if (c >= ncap) continue;
+        const int f = capf[c];
+        const int bf = m.frame_body[f];
+        double Rb[9], pb[3], vb[6];
+#pragma unroll
+        for (int bb = 0; bb < NB; ++bb)
+          if (bb == bf) {
+            const double* Bb = N + SM::OFF_BODY + bb * SM::BODY;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) Rb[i] = Bb[SM::B_RW + i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) pb[i] = Bb[SM::B_PW + i];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) vb[i] = Bb[SM::B_VB + i];
+          }
+        double* F = N + SM::OFF_FR + c * 18;
+        double Rf[9], Rp[3], wxr[3], tmp[3], fv[6];
+        matmul3<double>(Rb, m.frame_R[f], Rf);
+        matvec3<double>(Rb, m.frame_p[f], Rp);
+        cross3<double>(vb + 3, m.frame_p[f], wxr);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) tmp[i] = vb[i] + wxr[i];
+        matTvec3<double>(m.frame_R[f], tmp, fv);
+        matTvec3<double>(m.frame_R[f], vb + 3, fv + 3);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) F[i] = Rf[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) F[9 + i] = pb[i] + Rp[i];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) F[12 + i] = fv[i];
+      }
+    } else if (lane == 1) {
+      double x[NX], dxe[NDX], xnext[NX], pe[3], J2[36];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) x[i] = N[SM::OFF_X + i];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const double ai = N[SM::OFF_A + i];
+        dxe[i] = x[NQ + i] * dt + ai * dt * dt;
+        dxe[NV + i] = ai * dt;
+      }
+      state_integrate<DM>(x, dxe, xnext, pe);
+      Jexp6(dxe, pe, J2);
+      double qe[4], pe2[3], Re[9], Px[9], RtP[9];
+      exp6_quat(dxe, qe, pe2);
+      quat_to_R(qe, Re);
+      skew3(pe2, Px);
+      matTmul3<double>(Re, Px, RtP);
+      // J1 = Ad(exp6(xi)^-1) = [[R^T, -R^T [p]x],[0, R^T]]
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          N[SM::OFF_J1 + r * 6 + c] = Re[3 * c + r];
+          N[SM::OFF_J1 + r * 6 + 3 + c] = -RtP[3 * r + c];
+          N[SM::OFF_J1 + (3 + r) * 6 + c] = 0.0;
+          N[SM::OFF_J1 + (3 + r) * 6 + 3 + c] = Re[3 * c + r];
+        }
+#pragma unroll
+      for (int i = 0; i < 36; ++i) N[SM::OFF_J2 + i] = J2[i];
+#pragma unroll
+      for (int i = 0; i < NDX; ++i) N[SM::OFF_DXE + i] = dxe[i];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) N[SM::OFF_XN + i] = xnext[i];
+      // gaps: fs[t+1] = xnext (-) xs[t+1];  fs[0] = x0 (-) xs[0]
+      if (!terminal) {
+        double gap[NDX];
+        if (!feas) {
+          const double* xn = D.xs + ((size_t)b * (T + 1) + t + 1) * NX;
+          state_diff<DM>(xn, xnext, gap, nullptr);
+        }
+#pragma unroll
+        for (int i = 0; i < NDX; ++i) N[SM::OFF_GAP + i] = feas ? 0.0 : gap[i];
+      }
+      if (t == 0) {
+        double gap[NDX];
+        if (!feas) state_diff<DM>(x, D.x0 + (size_t)b * NX, gap, nullptr);
+#pragma unroll
+        for (int i = 0; i < NDX; ++i) N[SM::OFF_GAP + NDX + i] = feas ? 0.0 : gap[i];
+      }
+    }
+  });
+  ex.sync();
+  // ---- S3: tangent recursion; inertia columns to LDS ---------------------------------------------------------
+  double dtau_l[Exec::SLOTS][NV];
+  double jc_l[Exec::SLOTS][NCAP][6], dvc_l[Exec::SLOTS][NCAP][6];
+  ex.each([&](int lane, int sl) {
+    double capdv[NCAP][6];
+#pragma unroll
+    for (int c = 0; c < NCAP; ++c)
+#pragma unroll
+      for (int i = 0; i < 6; ++i) capdv[c][i] = 0.0;
+    lin2_tangent<DM>(m, N, lane, dtau_l[sl], ncap, capf, capdv);
+    if (lane >= 2 * NV && lane < 3 * NV) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) N[SM::OFF_M + i * NV + (lane - 2 * NV)] = dtau_l[sl][i];
+    }
+#pragma unroll
+    for (int c = 0; c < NCAP; ++c) {
+      if (c >= ncap) continue;
+      const int f = capf[c];
+      const double* F = N + SM::OFF_FR + c * 18;
+      lin2_frame_jcol<DM>(m, N, lane, m.frame_body[f], F, F + 9, jc_l[sl][c]);
+      // frame velocity derivative column: Ad(bMf^-1) d(v_body)
+      double wxr[3], tmp[3];
+      cross3<double>(capdv[c] + 3, m.frame_p[f], wxr);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) tmp[i] = capdv[c][i] + wxr[i];
+      matTvec3<double>(m.frame_R[f], tmp, dvc_l[sl][c]);
+      matTvec3<double>(m.frame_R[f], capdv[c] + 3, dvc_l[sl][c] + 3);
+    }
+  });
+  ex.sync();
+  // ---- S4: Cholesky of M (lane 0), in place, reciprocal diagonal --------------------------------------------------
+  ex.each([&](int lane, int sl) {
+    if (lane != 0) return;
+    double* M = N + SM::OFF_M;
+    for (int j = 0; j < NV; ++j) {
+      double s = M[j * NV + j];
+      for (int k = 0; k < j; ++k) s -= M[j * NV + k] * M[j * NV + k];
+      const double inv = 1.0 / sqrt(s);
+      M[j * NV + j] = inv;
+      for (int i = j + 1; i < NV; ++i) {
+        double tt = M[i * NV + j];
+        for (int k = 0; k < j; ++k) tt -= M[i * NV + k] * M[j * NV + k];
+        M[i * NV + j] = tt * inv;
+      }
+    }
+  });
+  ex.sync();
+  // ---- S5: M^-1 solves, Euler Jacobian columns -> tape ------------------------------------------------------------
+  ex.each([&](int lane, int sl) {
+    const bool xlane = lane < NDX;
+    const int k = lane - 2 * NV;
+    const bool ulane = k >= 0 && k < NU;
+    if (!xlane && !ulane) return;
+    double da[NV];
+    if (xlane) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) da[i] = -dtau_l[sl][i];
+    } else {
+      const double dus = N[SM::OFF_DUS + k];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        double Bik;
+        if (i < 6)
+          Bik = (k < NROT) ? P.tau_f[i * NROT + k] : 0.0;
+        else
+          Bik = (k == NROT + i - 6) ? 1.0 : 0.0;
+        da[i] = Bik * dus;
+      }
+    }
+    const double* Lm = N + SM::OFF_M;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      double s = da[i];
+#pragma unroll
+      for (int kk = 0; kk < i; ++kk) s -= Lm[i * NV + kk] * da[kk];
+      da[i] = s * Lm[i * NV + i];
+    }
+#pragma unroll
+    for (int i = NV - 1; i >= 0; --i) {
+      double s = da[i];
+#pragma unroll
+      for (int kk = i + 1; kk < NV; ++kk) s -= Lm[kk * NV + i] * da[kk];
+      da[i] = s * Lm[i * NV + i];
+    }
+    double G[NDX];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      G[i] = da[i] * dt * dt + ((xlane && lane >= NV && lane - NV == i) ? dt : 0.0);
+      G[NV + i] = da[i] * dt;
+    }
+    double top[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      double a_ = 0;
+#pragma unroll
+      for (int l = 0; l < 6; ++l) a_ += N[SM::OFF_J2 + r * 6 + l] * G[l];
+      top[r] = a_;
+    }
+    if (xlane) {
+      if (lane < 6) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) top[r] += N[SM::OFF_J1 + r * 6 + lane];
+      }
+#pragma unroll
+      for (int r = 0; r < 6; ++r) out[DM::OFF_FX + r * NDX + lane] = top[r];
+#pragma unroll
+      for (int r = 6; r < NDX; ++r) out[DM::OFF_FX + r * NDX + lane] = G[r] + ((r == lane) ? 1.0 : 0.0);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 6; ++r) out[DM::OFF_FU + r * NU + k] = top[r];
+#pragma unroll
+      for (int r = 6; r < NDX; ++r) out[DM::OFF_FU + r * NU + k] = G[r];
+    }
+    // gaps
+    if (xlane) {
+      if (!terminal) D.tape[((size_t)b * (T + 1) + t + 1) * REC + DM::OFF_GAP + lane] = N[SM::OFF_GAP + lane];
+      if (t == 0) D.tape[((size_t)b * (T + 1)) * REC + DM::OFF_GAP + lane] = N[SM::OFF_GAP + NDX + lane];
+    }
+  });
+
+  // ---- S6: costs. Column accumulators live in registers: x lanes hold column `lane` of Lxx, u lanes column k of Luu.
+  double hx_l[Exec::SLOTS][NDX];  // column of Lxx (x lanes) -- or of Luu in the first NU entries (u lanes)
+  double lx_l[Exec::SLOTS];
+  ex.each([&](int lane, int sl) {
+#pragma unroll
+    for (int i = 0; i < NDX; ++i) hx_l[sl][i] = 0.0;
+    lx_l[sl] = 0.0;
+  });
+  // round 1: State costs, nominal parts by one lane per cost (same code), up to NSLOT at a time
+  for (int base = 0; base < set.ncosts; base += SM::NSLOT) {
+    ex.each([&](int lane, int sl) {
+      if (lane >= SM::NSLOT || base + lane >= set.ncosts) return;
+      const EMPC_K EmpcCost& c = set.costs[base + lane];
+      double* S = N + SM::OFF_CST + lane * SM::SLOT;
+      if (!c.active || c.type != EMPC_COST_STATE) {
+        S[3 * NDX + 36] = 0.0;
+        return;
+      }
+      double r[NDX], dpl[3], J6[36];
+      state_diff<DM>(c.ref, N + SM::OFF_X, r, dpl);
+      Jlog6(r, dpl, J6);
+      double cv = 0;
+#pragma unroll
+      for (int i = 0; i < NDX; ++i) {
+        double av, Ar, Arr;
+        activation1(c.activation, r[i], c.act_w[i], c.lb[i], c.ub[i], av, Ar, Arr);
+        cv += av;
+        S[NDX + i] = c.weight * Ar;
+        S[2 * NDX + i] = c.weight * Arr;
+      }
+#pragma unroll
+      for (int i = 0; i < 36; ++i) S[3 * NDX + i] = J6[i];
+      S[3 * NDX + 36] = c.weight * cv;
+    });
+    ex.sync();
+    ex.each([&](int lane, int sl) {
+      if (lane == 0) {
+        double a_ = 0;
+        for (int q = 0; q < SM::NSLOT && base + q < set.ncosts; ++q) a_ += N[SM::OFF_CST + q * SM::SLOT + 3 * NDX + 36];
+        N[SM::OFF_RED] += a_;
+      }
+      if (lane >= NDX) return;
+      for (int q = 0; q < SM::NSLOT && base + q < set.ncosts; ++q) {
+        const EMPC_K EmpcCost& c = set.costs[base + q];
+        if (!c.active || c.type != EMPC_COST_STATE) continue;
+        const double* S = N + SM::OFF_CST + q * SM::SLOT;
+        const double* J6 = S + 3 * NDX;
+        if (lane < 6) {
+          double g = 0;
+#pragma unroll
+          for (int rr = 0; rr < 6; ++rr) g += J6[rr * 6 + lane] * S[NDX + rr];
+          lx_l[sl] += g;
+#pragma unroll
+          for (int i = 0; i < 6; ++i) {
+            double h = 0;
+#pragma unroll
+            for (int rr = 0; rr < 6; ++rr) h += J6[rr * 6 + i] * S[2 * NDX + rr] * J6[rr * 6 + lane];
+            hx_l[sl][i] += h;
+          }
+        } else {
+          lx_l[sl] += S[NDX + lane];
+#pragma unroll
+          for (int i = 6; i < NDX; ++i)
+            if (i == lane) hx_l[sl][i] += S[2 * NDX + lane];
+        }
+      }
+    });
+    ex.sync();
+  }
+  // round 2: Control costs (including the barrier): component k on u lane k
+  ex.each([&](int lane, int sl) {
+    const int k = lane - 2 * NV;
+    if (k < 0 || k >= NU) return;
+    double cv = 0;
+    for (int ci = 0; ci < set.ncosts; ++ci) {
+      const EMPC_K EmpcCost& c = set.costs[ci];
+      if (!c.active || c.type != EMPC_COST_CONTROL) continue;
+      double av, Ar, Arr;
+      activation1(c.activation, N[SM::OFF_S + k] - c.ref[k], act_weight(c, k, smooth, P), c.lb[k], c.ub[k], av, Ar, Arr);
+      cv += c.weight * av;
+      lx_l[sl] += c.weight * Ar;
+#pragma unroll
+      for (int i = 0; i < NU; ++i)
+        if (i == k) hx_l[sl][i] += c.weight * Arr;
+    }
+    N[SM::OFF_RED + 1 + k] = cv;
+  });
+  ex.sync();
+  ex.each([&](int lane, int sl) {
+    if (lane == 0) {
+      double a_ = 0;
+      for (int k = 0; k < NU; ++k) a_ += N[SM::OFF_RED + 1 + k];
+      N[SM::OFF_RED] += a_;
+    }
+  });
+  // round 3: frame costs, one at a time
+  for (int ci = 0; ci < set.ncosts; ++ci) {
+    const EMPC_K EmpcCost& c = set.costs[ci];
+    if (!c.active || c.frame < 0 || c.type == EMPC_COST_CONTACT_FRICTION_CONE || c.type == EMPC_COST_STATE ||
+        c.type == EMPC_COST_CONTROL)
+      continue;
+    int cc = 0;
+#pragma unroll
+    for (int kk = 1; kk < NCAP; ++kk)
+      if (kk < ncap && capf[kk] == c.frame) cc = kk;
+    const int nr = (c.type == EMPC_COST_FRAME_PLACEMENT || c.type == EMPC_COST_FRAME_VELOCITY) ? 6 : 3;
+    ex.sync();
+    // nominal residual, activation and (for log-map residuals) the Jacobian of the log, by lane 0 -> slot 0
+    ex.each([&](int lane, int sl) {
+      if (lane != 0) return;
+      const double* F = N + SM::OFF_FR + cc * 18;
+      double* S = N + SM::OFF_CST;
+      double r[6];
+      if (c.type == EMPC_COST_FRAME_PLACEMENT) {
+        double rR[9], dp[3], rp[3], qq[4], J6[36];
+        matTmul3<double>(c.ref + 3, F, rR);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) dp[i] = F[9 + i] - c.ref[i];
+        matTvec3<double>(c.ref + 3, dp, rp);
+        R_to_quat(rR, qq);
+        log6_quat(qq, rp, r);
+        Jlog6(r, rp, J6);
+#pragma unroll
+        for (int i = 0; i < 36; ++i) S[3 * NDX + i] = J6[i];
+      } else if (c.type == EMPC_COST_FRAME_ROTATION) {
+        double rR[9], qq[4], J3[9];
+        matTmul3<double>(c.ref, F, rR);
+        R_to_quat(rR, qq);
+        quat_log3(qq, r);
+        SO3Coef kc;
+        so3_coef(r[0] * r[0] + r[1] * r[1] + r[2] * r[2], kc);
+        Jlog3(r, kc, J3);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) S[3 * NDX + i] = J3[i];
+      } else if (c.type == EMPC_COST_FRAME_TRANSLATION) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) r[i] = F[9 + i] - c.ref[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) r[i] = F[12 + i] - c.ref[i];
+      }
+      double cv = 0;
+      for (int i = 0; i < nr; ++i) {
+        double av, Ar, Arr;
+        activation1(c.activation, r[i], c.act_w[i], c.lb[i], c.ub[i], av, Ar, Arr);
+        cv += av;
+        S[NDX + i] = c.weight * Ar;
+        S[2 * NDX + i] = c.weight * Arr;
+      }
+      N[SM::OFF_RED] += c.weight * cv;
+    });
+    ex.sync();
+    double wcol_l[Exec::SLOTS][6];
+    ex.each([&](int lane, int sl) {
+      if (lane >= NDX) return;
+      const double* F = N + SM::OFF_FR + cc * 18;
+      const double* S = N + SM::OFF_CST;
+      double jcc[6], dvcc[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        jcc[i] = jc_l[sl][0][i];
+        dvcc[i] = dvc_l[sl][0][i];
+      }
+#pragma unroll
+      for (int kk = 1; kk < NCAP; ++kk)
+        if (kk == cc) {
+#pragma unroll
+          for (int i = 0; i < 6; ++i) {
+            jcc[i] = jc_l[sl][kk][i];
+            dvcc[i] = dvc_l[sl][kk][i];
+          }
+        }
+      double col[6] = {0, 0, 0, 0, 0, 0};
+      if (c.type == EMPC_COST_FRAME_PLACEMENT) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          double a_ = 0;
+#pragma unroll
+          for (int l = 0; l < 6; ++l) a_ += S[3 * NDX + i * 6 + l] * jcc[l];
+          col[i] = a_;
+        }
+      } else if (c.type == EMPC_COST_FRAME_ROTATION) {
+        matvec3<double>(S + 3 * NDX, jcc + 3, col);
+      } else if (c.type == EMPC_COST_FRAME_TRANSLATION) {
+        matvec3<double>(F, jcc, col);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) col[i] = dvcc[i];
+      }
+      double g = 0;
+      for (int i = 0; i < nr; ++i) {
+        g += col[i] * S[NDX + i];
+        wcol_l[sl][i] = S[2 * NDX + i] * col[i];
+        N[SM::OFF_RSH + i * NDX + lane] = col[i];
+      }
+      lx_l[sl] += g;
+    });
+    ex.sync();
+    ex.each([&](int lane, int sl) {
+      if (lane >= NDX) return;
+      const int ni = (c.type == EMPC_COST_FRAME_VELOCITY) ? NDX : NV;
+#pragma unroll
+      for (int i = 0; i < NDX; ++i) {
+        if (i >= ni) continue;
+        double h = 0;
+        for (int rr = 0; rr < nr; ++rr) h += N[SM::OFF_RSH + rr * NDX + i] * wcol_l[sl][rr];
+        hx_l[sl][i] += h;
+      }
+    });
+  }
+  ex.sync();
+  // ---- S7: scale and store ---------------------------------------------------------------------------------------------
+  const double cscale = (terminal && !P.prm.terminal_dt_scaling) ? 1.0 : dt;
+  ex.each([&](int lane, int sl) {
+    if (lane < NDX) {
+      out[DM::OFF_LX + lane] = lx_l[sl] * cscale;
+#pragma unroll
+      for (int i = 0; i < NDX; ++i) out[DM::OFF_LXX + i * NDX + lane] = hx_l[sl][i] * cscale;
+    }
+    const int k = lane - 2 * NV;
+    if (k >= 0 && k < NU) {
+      out[DM::OFF_LU + k] = lx_l[sl] * cscale;
+#pragma unroll
+      for (int i = 0; i < NU; ++i) out[DM::OFF_LUU + i * NU + k] = hx_l[sl][i] * cscale;
+#pragma unroll
+      for (int i = 0; i < NDX; ++i) out[DM::OFF_LXU + i * NU + k] = 0.0;
+    }
+    if (lane == 0) out[DM::OFF_COST] = N[SM::OFF_RED] * cscale;
+  });
+}
+
+}  // namespace empc

@@ -17,6 +17,8 @@
 #include "../../include/empc.h"
 #include "empc_internal.hpp"
 #include "empc_prep.hpp"
+#include "empc_linearize2.hpp"
+#include "empc_backward2.hpp"
 
 using namespace empc;
 
@@ -60,15 +62,33 @@ __global__ void __launch_bounds__(128) k_linearize(DevBuffers D) {
   const TrajState& st = D.st[b];
   if (st.phase == PHASE_DONE || !st.need_lin) return;
   LaneExec ex{lane};
-  linearize_unit<DM>(ex, D, b, t, LPU, smem_lin + (size_t)(threadIdx.x / LPU) * LinSmem<DM>::SIZE);
+  linearize_unit2<DM>(ex, D, b, t, LPU, smem_lin + (size_t)(threadIdx.x / LPU) * Lin2Smem<DM>::SIZE);
 }
 
+// workgroup-wide executor: barriers are real workgroup barriers
+struct BlockExec {
+  int lane;
+  static constexpr int SLOTS = 1;
+  template <class F>
+  __device__ __forceinline__ void each(F&& f) {
+    f(lane, 0);
+  }
+  __device__ __forceinline__ void sync() { __syncthreads(); }
+  template <class F>
+  __device__ __forceinline__ bool any(F&& f) {
+    return __syncthreads_or(f(lane, 0) ? 1 : 0) != 0;
+  }
+};
+
+#ifndef EMPC_BWD_NL
+#define EMPC_BWD_NL 64
+#endif
 template <class DM>
-__global__ void __launch_bounds__(64) k_backward(DevBuffers D) {
+__global__ void __launch_bounds__(EMPC_BWD_NL) k_backward(DevBuffers D) {
   extern __shared__ double smem_bwd[];
   const int b = blockIdx.x;
-  LaneExec ex{(int)threadIdx.x};
-  backward_traj<DM>(ex, D, b, smem_bwd);
+  BlockExec ex{(int)threadIdx.x};
+  backward_traj2<DM, EMPC_BWD_NL>(ex, D, b, smem_bwd);
 }
 
 template <class DM>
@@ -123,12 +143,12 @@ static void launch_linearize(DevBuffers D, hipStream_t s) {
   constexpr int LPU = (3 * DM::NV <= 32) ? 32 : 64;
   constexpr int UPB = 128 / LPU;
   const int n = D.B * (D.T + 1);
-  const size_t smem = sizeof(double) * LinSmem<DM>::SIZE * UPB;
+  const size_t smem = sizeof(double) * Lin2Smem<DM>::SIZE * UPB;
   hipLaunchKernelGGL((k_linearize<DM, LPU>), dim3((n + UPB - 1) / UPB), dim3(128), smem, s, D);
 }
 template <class DM>
 static void launch_backward(DevBuffers D, hipStream_t s) {
-  hipLaunchKernelGGL(k_backward<DM>, dim3(D.B), dim3(64), sizeof(double) * BwdSmem<DM>::SIZE, s, D);
+  hipLaunchKernelGGL(k_backward<DM>, dim3(D.B), dim3(EMPC_BWD_NL), sizeof(double) * Bwd2Smem<DM>::SIZE, s, D);
 }
 template <class DM>
 static void launch_rollout(DevBuffers D, hipStream_t s) {

@@ -7,6 +7,8 @@
 #include <vector>
 
 #include "../../eagle-mpc_amd/csrc/empc_prep.hpp"
+#include "../../eagle-mpc_amd/csrc/empc_linearize2.hpp"
+#include "../../eagle-mpc_amd/csrc/empc_backward2.hpp"
 
 using namespace empc;
 
@@ -19,6 +21,12 @@ struct CpuExec {
     for (int l = 0; l < nl; ++l) f(l, l);
   }
   void sync() {}
+  template <class F>
+  bool any(F&& f) {
+    bool r = false;
+    for (int l = 0; l < nl; ++l) r = f(l, l) || r;
+    return r;
+  }
 };
 
 struct Emu {
@@ -92,24 +100,34 @@ static void emu_calc(Emu& e) {
   for (int b = 0; b < e.B; ++b)
     for (int t = 0; t <= e.T; ++t) calc_thread<DM, false>(e.D, b, t);
 }
+static int g_lin_version = 2;
 template <class DM>
 static void emu_linearize(Emu& e) {
   constexpr int LPU = (3 * DM::NV <= 32) ? 32 : 64;
-  std::vector<double> smem(LinSmem<DM>::SIZE);
+  std::vector<double> smem(LinSmem<DM>::SIZE + Lin2Smem<DM>::SIZE);
   for (int t = 0; t <= e.T; ++t)
     for (int b = 0; b < e.B; ++b) {
       const TrajState& st = e.st[b];
       if (st.phase == PHASE_DONE || !st.need_lin) continue;
       CpuExec<64> ex{LPU};
-      linearize_unit<DM>(ex, e.D, b, t, LPU, smem.data());
+      if (g_lin_version == 2)
+        linearize_unit2<DM>(ex, e.D, b, t, LPU, smem.data());
+      else
+        linearize_unit<DM>(ex, e.D, b, t, LPU, smem.data());
     }
 }
+static int g_bwd_version = 2;
 template <class DM>
 static void emu_backward(Emu& e) {
-  std::vector<double> smem(BwdSmem<DM>::SIZE);
+  std::vector<double> smem(BwdSmem<DM>::SIZE + Bwd2Smem<DM>::SIZE);
   for (int b = 0; b < e.B; ++b) {
-    CpuExec<64> ex{64};
-    backward_traj<DM>(ex, e.D, b, smem.data());
+    if (g_bwd_version == 2) {
+      CpuExec<256> ex{256};
+      backward_traj2<DM, 256>(ex, e.D, b, smem.data());
+    } else {
+      CpuExec<64> ex{64};
+      backward_traj<DM>(ex, e.D, b, smem.data());
+    }
   }
 }
 template <class DM>
@@ -155,6 +173,8 @@ static void emu_solve(Emu& e, int maxiter, int is_feasible) {
   } while (0)
 
 extern "C" {
+void emu_set_linearize_version(int v) { g_lin_version = v; }
+void emu_set_backward_version(int v) { g_bwd_version = v; }
 void* emu_create(const EmpcProblemDesc* d, const EmpcSolverParams* prm, int B) {
   Emu* e = new Emu();
   try {
