@@ -81,18 +81,18 @@ def main():
     d = problem.desc
     B = args.batch
     # rank r owns rollouts [r*B, (r+1)*B) of the global batch; rollout 0 is the unperturbed YAML state
+    import importlib
+    sharding = importlib.import_module("eagle_mpc_amd.sharding")
     x0_all = empc.perturbed_x0s(problem.x0, B * world, nq=d.model.nq)
-    x0s = np.ascontiguousarray(x0_all[rank * B:(rank + 1) * B])
+    x0s = sharding.shard(x0_all, world, rank)
     solver = empc.SolverSbFDDP(problem, batch=B, device=local_rank)
 
     def one_step():
         solver.solve([], [], args.maxiter, x0s=x0s)
         if dist is not None:
             # the only exchange of the algorithm: results to rank 0 (RCCL gather over xGMI)
-            res = torch.from_numpy(np.concatenate([solver.xs_batch.reshape(B, -1), solver.us_squash_batch.reshape(B, -1),
-                                                   solver.cost_batch.reshape(B, 1)], axis=1)).cuda()
-            out = [torch.empty_like(res) for _ in range(world)] if rank == 0 else None
-            dist.gather(res, out, dst=0)
+            rows = sharding.pack_results(solver.xs_batch, solver.us_squash_batch, solver.cost_batch, solver.iter_batch)
+            sharding.gather_results(dist, rows, world, rank, device="cuda", global_batch=B * world)
         return solver.stats()
 
     for _ in range(args.warmup):

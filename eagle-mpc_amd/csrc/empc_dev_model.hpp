@@ -531,8 +531,7 @@ EMPC_HD void node_nominal(const EMPC_K DevProblem& P, const EMPC_K EmpcCostSet& 
   quat_to_R(q + 3, R0);
 #pragma unroll
   for (int b = 1; b < NB; ++b) {
-    sn[b - 1] = sin(q[7 + b - 1]);
-    cs[b - 1] = cos(q[7 + b - 1]);
+    sincos(q[7 + b - 1], &sn[b - 1], &cs[b - 1]);
   }
   // frames referenced by this node's costs / contacts
   int capf[NCAP] = {0, 0};
@@ -649,13 +648,18 @@ EMPC_HD void node_nominal(const EMPC_K DevProblem& P, const EMPC_K EmpcCostSet& 
 
   // costs (A.6)
   double ell = 0;
+  double rstate[DM::NDX];  // residual of the most recent State cost (shared between costs with one reference)
+  int rstate_of = -1;
   for (int ci = 0; ci < set.ncosts; ++ci) {
     const EMPC_K EmpcCost& c = set.costs[ci];
     if (!c.active) continue;
     double cval = 0;
     if (c.type == EMPC_COST_STATE) {
-      double r[DM::NDX];
-      state_diff<DM>(c.ref, x, r, nullptr);
+      double* r = rstate;
+      if (!(c.ref_share >= 0 && c.ref_share == rstate_of)) {
+        state_diff<DM>(c.ref, x, r, nullptr);
+        rstate_of = (c.ref_share >= 0) ? c.ref_share : ci;
+      }
 #pragma unroll
       for (int i = 0; i < DM::NDX; ++i) {
         double av, Ar, Arr;

@@ -88,6 +88,18 @@ inline void prepare_problem(const EmpcProblemDesc& d, const EmpcSolverParams& pr
       insert_barrier(H.sets[si], H.P);
     }
   }
+  // State costs that share a reference reuse the residual of the first one (reg_state / limits_state pairs)
+  for (auto& s : H.sets)
+    for (int i = 0; i < s.ncosts; ++i) {
+      s.costs[i].ref_share = -1;
+      if (s.costs[i].type != EMPC_COST_STATE) continue;
+      for (int j = 0; j < i; ++j)
+        if (s.costs[j].type == EMPC_COST_STATE && s.costs[j].active &&
+            std::memcmp(s.costs[j].ref, s.costs[i].ref, sizeof(double) * d.nx) == 0) {
+          s.costs[i].ref_share = j;
+          break;
+        }
+    }
   // frame-capture capacity per cost set
   for (const auto& s : H.sets) {
     int frames[EMPC_MAX_COSTS], nf = 0;

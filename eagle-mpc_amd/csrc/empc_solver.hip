@@ -19,6 +19,7 @@
 #include "empc_prep.hpp"
 #include "empc_linearize2.hpp"
 #include "empc_backward2.hpp"
+#include "empc_rollout2.hpp"
 
 using namespace empc;
 
@@ -42,12 +43,21 @@ __global__ void __launch_bounds__(64) k_calc(DevBuffers D) {
   calc_thread<DM, false>(D, b, t);
 }
 
+#ifndef EMPC_ROLLOUT_V
+#define EMPC_ROLLOUT_V 1
+#endif
 template <class DM>
 __global__ void __launch_bounds__(64) k_rollout(DevBuffers D) {
+#if EMPC_ROLLOUT_V == 2
+  extern __shared__ double smem_roll[];
+  LaneExec ex{(int)threadIdx.x};
+  rollout_block2<DM, false>(ex, D, blockIdx.x * Roll2Smem<DM>::TPB, smem_roll);
+#else
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= D.B * D.NA) return;
   const int b = idx / D.NA, ai = idx % D.NA;
   rollout_thread<DM, false>(D, b, ai);
+#endif
 }
 
 template <class DM, int LPU>
@@ -152,8 +162,13 @@ static void launch_backward(DevBuffers D, hipStream_t s) {
 }
 template <class DM>
 static void launch_rollout(DevBuffers D, hipStream_t s) {
+#if EMPC_ROLLOUT_V == 2
+  const int nblk = (D.B + Roll2Smem<DM>::TPB - 1) / Roll2Smem<DM>::TPB;
+  hipLaunchKernelGGL(k_rollout<DM>, dim3(nblk), dim3(64), sizeof(double) * Roll2Smem<DM>::SIZE, s, D);
+#else
   const int n = D.B * D.NA;
   hipLaunchKernelGGL(k_rollout<DM>, dim3((n + 63) / 64), dim3(64), 0, s, D);
+#endif
 }
 template <class DM>
 static void launch_select(DevBuffers D, hipStream_t s) {

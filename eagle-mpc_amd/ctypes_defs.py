@@ -41,6 +41,7 @@ class Cost(C.Structure):
     _fields_ = [
         ("name", C.c_char * NAME_LEN),
         ("type", i32), ("activation", i32), ("active", i32), ("frame", i32), ("nr", i32), ("is_barrier", i32),
+        ("ref_share", i32), ("reserved", i32),
         ("weight", d),
         ("ref", d * MAX_NX),
         ("act_w", d * MAX_NR),

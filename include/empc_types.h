@@ -90,6 +90,9 @@ typedef struct EmpcCost {
   int32_t frame;            /* index into EmpcModelDesc frames (frame costs / friction cone) */
   int32_t nr;               /* residual length                                               */
   int32_t is_barrier;       /* 1 for the cost SolverSbFDDP::barrierInit injects              */
+  int32_t ref_share;        /* filled by the solver: index of an earlier State cost of the same set with an
+                               identical reference (its residual is reused), or -1                          */
+  int32_t reserved;
   double weight;
   /* reference payload, by type:
    *   STATE: xref[nx] | CONTROL: uref[nu] | FRAME_PLACEMENT: p[3], R[9] | FRAME_ROTATION: R[9]

@@ -9,6 +9,7 @@
 #include "../../eagle-mpc_amd/csrc/empc_prep.hpp"
 #include "../../eagle-mpc_amd/csrc/empc_linearize2.hpp"
 #include "../../eagle-mpc_amd/csrc/empc_backward2.hpp"
+#include "../../eagle-mpc_amd/csrc/empc_rollout2.hpp"
 
 using namespace empc;
 
@@ -130,8 +131,17 @@ static void emu_backward(Emu& e) {
     }
   }
 }
+static int g_roll_version = 2;
 template <class DM>
 static void emu_rollout(Emu& e) {
+  if (g_roll_version == 2) {
+    std::vector<double> smem(Roll2Smem<DM>::SIZE);
+    for (int b0 = 0; b0 < e.B; b0 += Roll2Smem<DM>::TPB) {
+      CpuExec<64> ex{64};
+      rollout_block2<DM, false>(ex, e.D, b0, smem.data());
+    }
+    return;
+  }
   for (int b = 0; b < e.B; ++b)
     for (int ai = 0; ai < e.NA; ++ai) rollout_thread<DM, false>(e.D, b, ai);
 }
@@ -175,6 +185,7 @@ static void emu_solve(Emu& e, int maxiter, int is_feasible) {
 extern "C" {
 void emu_set_linearize_version(int v) { g_lin_version = v; }
 void emu_set_backward_version(int v) { g_bwd_version = v; }
+void emu_set_rollout_version(int v) { g_roll_version = v; }
 void* emu_create(const EmpcProblemDesc* d, const EmpcSolverParams* prm, int B) {
   Emu* e = new Emu();
   try {

@@ -1,0 +1,158 @@
+"""The HIP kernel bodies (eagle-mpc_amd/csrc/empc_*.hpp), executed lane by lane by tests/csrc/lane_emulator.cpp, against
+the oracle.  This is the strongest check available without a GPU: identical templates, identical index arithmetic and
+LDS staging; only the wave execution is emulated.  The emulator is test infrastructure (never loaded by the package)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU = os.path.join(ROOT, "tests", "csrc", "liblane_emulator.so")
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+
+@pytest.fixture(scope="module")
+def emu(empc):
+    src = os.path.join(ROOT, "tests", "csrc", "lane_emulator.cpp")
+    hdrs = [os.path.join(ROOT, "eagle-mpc_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "eagle-mpc_amd", "csrc"))
+            if f.endswith(".hpp")] + [os.path.join(ROOT, "include", "empc_types.h")]
+    if not os.path.exists(EMU) or any(os.path.getmtime(h) > os.path.getmtime(EMU) for h in hdrs + [src]):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"), src,
+                               "-o", EMU])
+    L = C.CDLL(EMU)
+    L.emu_create.restype = C.c_void_p
+    L.emu_create.argtypes = [C.POINTER(empc.T.ProblemDesc), C.POINTER(empc.T.SolverParams), C.c_int]
+    L.emu_destroy.argtypes = [C.c_void_p]
+    L.emu_rec.argtypes = [C.c_void_p]
+    L.emu_set_x0.argtypes = [C.c_void_p, _dp]
+    L.emu_set_warmstart.argtypes = [C.c_void_p, _dp, _dp]
+    L.emu_solve_c.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.emu_get.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _ip, _ip]
+    L.emu_phase_setup.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_double, C.c_int]
+    L.emu_phase_linearize.argtypes = [C.c_void_p, _dp, _dp]
+    L.emu_phase_backward.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _ip, _ip, _dp]
+    L.emu_phase_rollout.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _ip]
+    return L
+
+
+def rel(a, b):
+    return np.abs(a - b).max() / (1.0 + np.abs(b).max())
+
+
+def candidate(d, seed):
+    rng = np.random.default_rng(seed)
+    T, nx, nu = d.T, d.nx, d.nu
+    xs = np.zeros((T + 1, nx))
+    xs[:, :3] = rng.normal(size=(T + 1, 3)) * 0.3
+    q = np.array([0, 0, 0, 1.0]) + rng.normal(size=(T + 1, 4)) * 0.2
+    xs[:, 3:7] = q / np.linalg.norm(q, axis=-1, keepdims=True)
+    xs[:, 7:] = rng.normal(size=(T + 1, nx - 7)) * 0.3
+    us = rng.uniform(2, 6, size=(T, nu))
+    us[:, d.n_rotors:] = rng.normal(size=(T, nu - d.n_rotors)) * 0.2
+    return xs, us
+
+
+@pytest.mark.parametrize("lin,bwd,roll", [(2, 2, 1), (1, 1, 2)])
+@pytest.mark.parametrize("name", ["hover", "displacement", "push_slide"])
+def test_kernel_bodies_vs_oracle(empc, problems, emu, name, lin, bwd, roll):
+    _, problem = problems[name]
+    d = problem.desc
+    prm = ob.default_params()
+    emu.emu_set_linearize_version(lin)
+    emu.emu_set_backward_version(bwd)
+    emu.emu_set_rollout_version(roll)
+    e = C.c_void_p(emu.emu_create(C.byref(d), C.byref(prm), 1))
+    assert e.value
+    o = ob.OracleSolver(d)
+    T, nx, ndx, nu, nv = d.T, d.nx, d.ndx, d.nu, d.model.nv
+    rec = emu.emu_rec(e)
+    xs, us = candidate(d, 3)
+    o.set_smooth(0.1)
+    cost_o, fs, feas = o.phase_calcdiff(xs, us)
+    emu.emu_set_warmstart(e, ob.P(xs), ob.P(us))
+    emu.emu_phase_setup(e, 0.1, 0, 1e-9, 0)
+    tape = np.zeros((T + 1, rec))
+    acc = np.zeros((T + 1, nv))
+    emu.emu_phase_linearize(e, ob.P(tape), ob.P(acc))
+    n, m = ndx, nu
+    off, o_ = {}, 0
+    for key, sz in [("Fx", n * n), ("Fu", n * m), ("Lxx", n * n), ("Lxu", n * m), ("Luu", m * m), ("Lx", n), ("Lu", m),
+                    ("gap", n), ("cost", 1)]:
+        off[key] = (o_, sz)
+        o_ += sz
+    for t in range(T + 1):
+        ref = o.phase_tape(t)
+        ref["gap"] = fs[t]
+        ref["cost"] = np.array([ref["cost"]])
+        for key, (a, sz) in off.items():
+            if t == T and key in ("Fx", "Fu", "Lxu", "Luu", "Lu"):
+                continue
+            assert rel(tape[t, a:a + sz], np.asarray(ref[key]).ravel()) < 1e-11, (t, key)
+    ok, Ko, ko, Vxo, _, dgo = o.phase_backward(1e-9)
+    K = np.zeros((T, m, n))
+    k = np.zeros((T, m))
+    Vx = np.zeros((T + 1, n))
+    dg = np.zeros(2)
+    oke = np.zeros(1, dtype=np.int32)
+    fe = np.zeros(1, dtype=np.int32)
+    ce = np.zeros(1)
+    emu.emu_phase_backward(e, ob.P(K), ob.P(k), ob.P(Vx), ob.P(dg), oke.ctypes.data_as(_ip), fe.ctypes.data_as(_ip), ob.P(ce))
+    assert ok and oke[0] == 1 and fe[0] == int(feas)
+    assert rel(K, Ko) < 1e-6 and rel(k, ko) < 1e-6 and rel(Vx, Vxo) < 1e-8 and np.allclose(dg, dgo, rtol=1e-7)
+    assert abs(ce[0] - cost_o) < 1e-10 * (1 + abs(cost_o))
+    for ai in (2, 4):
+        oko, xo, uo, co, d01 = o.phase_forward(2.0 ** -ai)
+        xt = np.zeros((T + 1, nx))
+        ut = np.zeros((T, nu))
+        ct = np.zeros(1)
+        dv = np.zeros(1)
+        okr = np.zeros(1, dtype=np.int32)
+        emu.emu_phase_rollout(e, ai, ob.P(xt), ob.P(ut), ob.P(ct), ob.P(dv), okr.ctypes.data_as(_ip))
+        assert bool(okr[0]) == oko
+        if oko and abs(co) < 1e12:
+            assert rel(xt, xo) < 1e-7 and rel(ut, uo) < 1e-7 and abs(ct[0] - co) < 1e-7 * (1 + abs(co))
+            assert np.allclose([dg[0] + dv[0], dg[1] - 2 * dv[0]], d01, rtol=1e-6, atol=1e-6 * abs(d01).max())
+    # full solve through the emulated kernels (state machine `select_decide` included)
+    emu.emu_set_warmstart(e, None, None)
+    emu.emu_solve_c(e, 100, 0)
+    xs_e = np.zeros((T + 1, nx))
+    us_e = np.zeros((T, nu))
+    ul = np.zeros((T, nu))
+    it = np.zeros(1, dtype=np.int32)
+    st = np.zeros(1, dtype=np.int32)
+    emu.emu_get(e, ob.P(xs_e), ob.P(us_e), ob.P(ul), ob.P(ce), it.ctypes.data_as(_ip), st.ctypes.data_as(_ip))
+    o.solve(None, None, 100)
+    r = o.result()
+    assert it[0] == r["iter"] and st[0] == r["status"]
+    assert np.abs(xs_e - r["xs"]).max() < 1e-6 and np.abs(us_e - r["us"]).max() < 1e-6
+    assert abs(ce[0] - r["cost"]) < 1e-9 * (1 + abs(r["cost"]))
+    emu.emu_destroy(e)
+
+
+def test_emulated_batch_with_perturbed_states(empc, problems, emu):
+    _, problem = problems["displacement"]
+    d = problem.desc
+    B = 3
+    prm = ob.default_params()
+    emu.emu_set_linearize_version(2)
+    emu.emu_set_backward_version(2)
+    emu.emu_set_rollout_version(1)
+    e = C.c_void_p(emu.emu_create(C.byref(d), C.byref(prm), B))
+    x0s = empc.perturbed_x0s(problem.x0, B, nq=d.model.nq)
+    emu.emu_set_x0(e, ob.P(x0s))
+    emu.emu_set_warmstart(e, None, None)
+    emu.emu_solve_c(e, 100, 0)
+    xs = np.zeros((B, d.T + 1, d.nx))
+    cost = np.zeros(B)
+    it = np.zeros(B, dtype=np.int32)
+    st = np.zeros(B, dtype=np.int32)
+    emu.emu_get(e, ob.P(xs), None, None, ob.P(cost), it.ctypes.data_as(_ip), st.ctypes.data_as(_ip))
+    ref = ob.solve_batch(d, x0s, 100, nthreads=2)
+    assert (it == ref["iter"]).all() and (st == ref["status"]).all()
+    assert np.abs(xs - ref["xs"]).max() < 1e-5
+    emu.emu_destroy(e)
