@@ -36,6 +36,7 @@ struct Dims {
   static constexpr int NDX = 2 * NV;
   static constexpr int NU = NROT_ + NJ;
   static constexpr int NTRI = NV * (NV + 1) / 2;
+  static constexpr int NACC = NV + 6;  // stride of the per-node stash: generalized acceleration | contact force
   // tape record of one node (doubles); layout shared by linearize (writer) and backward (reader)
   static constexpr int OFF_FX = 0;                       // ndx x ndx row-major
   static constexpr int OFF_FU = OFF_FX + NDX * NDX;      // ndx x nu

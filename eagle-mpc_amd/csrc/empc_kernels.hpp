@@ -90,10 +90,11 @@ EMPC_HD void calc_thread(const DevBuffers& D, int b, int t) {
   const int T = D.T;
   const double* x = D.xs + ((size_t)b * (T + 1) + t) * DM::NX;
   const double* u = (t < T) ? D.us + ((size_t)b * T + t) * DM::NU : nullptr;
-  double xnext[DM::NX], acc[DM::NV], usq[DM::NU], cost;
-  node_nominal<DM, CT>(EMPC_KREF(DevProblem, D.P), EMPC_KPTR(EmpcCostSet, D.sets)[EMPC_KPTR(int, D.knot_set)[t]], st.smooth, x, u, t == T, xnext, acc, cost, usq, nullptr);
-  double* ao = D.acc + ((size_t)b * (T + 1) + t) * DM::NV;
+  double xnext[DM::NX], acc[DM::NV], usq[DM::NU], lam[6], cost;
+  node_nominal<DM, CT>(EMPC_KREF(DevProblem, D.P), EMPC_KPTR(EmpcCostSet, D.sets)[EMPC_KPTR(int, D.knot_set)[t]], st.smooth, x, u, t == T, xnext, acc, cost, usq, lam);
+  double* ao = D.acc + ((size_t)b * (T + 1) + t) * DM::NACC;
   for (int i = 0; i < DM::NV; ++i) ao[i] = acc[i];
+  for (int i = 0; i < 6; ++i) ao[DM::NV + i] = lam[i];
   if (t < T) {
     double* ul = D.us_last + ((size_t)b * T + t) * DM::NU;
     for (int i = 0; i < DM::NU; ++i) ul[i] = u[i];
@@ -114,14 +115,14 @@ EMPC_HD void rollout_thread(const DevBuffers& D, int b, int ai) {
   const double alpha = ldexp(1.0, -ai);
   const bool plain = ddp || feas || (ai == 0);
   const double smooth = st.smooth;
-  double xnext[NX], xtry[NX], dx[NDX], utry[NU], acc[NV], usq[NU];
+  double xnext[NX], xtry[NX], dx[NDX], utry[NU], acc[NV], usq[NU], lam[6];
   for (int i = 0; i < NX; ++i) xnext[i] = D.x0[(size_t)b * NX + i];
   double cost_try = 0, dv = 0;
   int ok = 1;
   const size_t slot = (size_t)b * NA + ai;
   double* xs_o = D.xs_try + slot * (T + 1) * NX;
   double* us_o = D.us_try + slot * T * NU;
-  double* ac_o = D.acc_try + slot * (T + 1) * NV;
+  double* ac_o = D.acc_try + slot * (T + 1) * DM::NACC;
   for (int t = 0; t <= T; ++t) {
     const double* rec = D.tape + ((size_t)b * (T + 1) + t) * REC;
     if (plain) {
@@ -147,14 +148,15 @@ EMPC_HD void rollout_thread(const DevBuffers& D, int b, int ai) {
         for (int j = 0; j < NDX; ++j) a_ -= KK[i * NDX + j] * dx[j];
         utry[i] = a_;
       }
-      node_nominal<DM, CT>(EMPC_KREF(DevProblem, D.P), EMPC_KPTR(EmpcCostSet, D.sets)[EMPC_KPTR(int, D.knot_set)[t]], smooth, xtry, utry, false, xnext, acc, cost, usq, nullptr);
+      node_nominal<DM, CT>(EMPC_KREF(DevProblem, D.P), EMPC_KPTR(EmpcCostSet, D.sets)[EMPC_KPTR(int, D.knot_set)[t]], smooth, xtry, utry, false, xnext, acc, cost, usq, lam);
       for (int i = 0; i < NU; ++i) us_o[(size_t)t * NU + i] = utry[i];
     } else {
       double xn2[NX];
-      node_nominal<DM, CT>(EMPC_KREF(DevProblem, D.P), EMPC_KPTR(EmpcCostSet, D.sets)[EMPC_KPTR(int, D.knot_set)[t]], smooth, xtry, nullptr, true, xn2, acc, cost, usq, nullptr);
+      node_nominal<DM, CT>(EMPC_KREF(DevProblem, D.P), EMPC_KPTR(EmpcCostSet, D.sets)[EMPC_KPTR(int, D.knot_set)[t]], smooth, xtry, nullptr, true, xn2, acc, cost, usq, lam);
     }
     for (int i = 0; i < NX; ++i) xs_o[(size_t)t * NX + i] = xtry[i];
-    for (int i = 0; i < NV; ++i) ac_o[(size_t)t * NV + i] = acc[i];
+    for (int i = 0; i < NV; ++i) ac_o[(size_t)t * DM::NACC + i] = acc[i];
+    for (int i = 0; i < 6; ++i) ac_o[(size_t)t * DM::NACC + NV + i] = lam[i];
     cost_try += cost;
     if (bad_number(cost_try)) {
       ok = 0;
@@ -234,7 +236,7 @@ EMPC_HD void linearize_unit(Exec& ex, const DevBuffers& D, int b, int t, int lpu
   ex.each([&](int lane, int sl) {
     LinLane<DM>& L = LS[sl];
     const double* xg = D.xs + ((size_t)b * (T + 1) + t) * NX;
-    const double* ag = D.acc + ((size_t)b * (T + 1) + t) * NV;
+    const double* ag = D.acc + ((size_t)b * (T + 1) + t) * DM::NACC;
     double x[NX], a[NV];
 #pragma unroll
     for (int i = 0; i < NX; ++i) x[i] = xg[i];
@@ -1103,13 +1105,13 @@ EMPC_HD void select_copy(const DevBuffers& D, int b, int accepted_ai, int last_a
     const size_t slot = (size_t)b * NA + accepted_ai;
     const double* xs_i = D.xs_try + slot * (T + 1) * DM::NX;
     const double* us_i = D.us_try + slot * T * DM::NU;
-    const double* ac_i = D.acc_try + slot * (T + 1) * DM::NV;
+    const double* ac_i = D.acc_try + slot * (T + 1) * DM::NACC;
     double* xs_o = D.xs + (size_t)b * (T + 1) * DM::NX;
     double* us_o = D.us + (size_t)b * T * DM::NU;
-    double* ac_o = D.acc + (size_t)b * (T + 1) * DM::NV;
+    double* ac_o = D.acc + (size_t)b * (T + 1) * DM::NACC;
     for (int i = tid; i < (T + 1) * DM::NX; i += nthreads) xs_o[i] = xs_i[i];
     for (int i = tid; i < T * DM::NU; i += nthreads) us_o[i] = us_i[i];
-    for (int i = tid; i < (T + 1) * DM::NV; i += nthreads) ac_o[i] = ac_i[i];
+    for (int i = tid; i < (T + 1) * DM::NACC; i += nthreads) ac_o[i] = ac_i[i];
   }
   if (last_ai >= 0) {
     // fillSquashedOutputs reads the data of the LAST calc at every node: the last trial that was rolled out

@@ -41,14 +41,21 @@ struct Lin2Smem {
   static constexpr int OFF_CST = OFF_FR + NCAP * 18;  // cost nominal slots
   static constexpr int NSLOT = 4;
   static constexpr int SLOT = 3 * NDX + 36 + 4;       // r | Ar | Arr | J6 | value
-  static constexpr int OFF_RSH = OFF_CST + NSLOT * SLOT;  // residual-Jacobian exchange 6 x NDX
-  static constexpr int OFF_RED = OFF_RSH + 6 * NDX;   // small reduction area (cost partial sums) 64
-  static constexpr int SIZE = (OFF_RED + 64 + 1) / 2 * 2;
+  static constexpr int OFF_RSH = OFF_CST + NSLOT * SLOT;  // residual-Jacobian exchange 6 x (NDX + NU)
+  static constexpr int OFF_RED = OFF_RSH + 6 * (NDX + NU);  // small reduction area (cost partial sums) 64
+  // contact block (ContactModel3D): lambda 6 | fext 6 | Jc 3 x NV | M^-1 Jc^T NV x 3 | G 9 | cone rows 15 + Ar 5 + Arr 5
+  static constexpr int OFF_LAM = OFF_RED + 64;
+  static constexpr int OFF_FEXT = OFF_LAM + 6;
+  static constexpr int OFF_JC = OFF_FEXT + 6;
+  static constexpr int OFF_MIJ = OFF_JC + 3 * NV;
+  static constexpr int OFF_G = OFF_MIJ + 3 * NV;
+  static constexpr int OFF_CONE = OFF_G + 9;
+  static constexpr int SIZE = (OFF_CONE + 25 + 1) / 2 * 2;
 };
 
 // forward kinematics + nominal Newton-Euler quantities of one unit, executed by ONE lane
 template <class DM>
-EMPC_HD void lin2_nominal_chain(const EMPC_K EmpcModelDesc& m, double* N) {
+EMPC_HD void lin2_nominal_chain(const EMPC_K EmpcModelDesc& m, double* N, int cbody = -1) {
   typedef Lin2Smem<DM> SM;
   constexpr int NB = DM::NB, NQ = DM::NQ, NX = DM::NX;
   const double* x = N + SM::OFF_X;
@@ -175,6 +182,14 @@ EMPC_HD void lin2_nominal_chain(const EMPC_K EmpcModelDesc& m, double* N) {
       Bb[SM::B_FS + 3 + i] = Ia[3 + i] + d2[i] + d3[i];
     }
   }
+  // external (contact) force acting on body `cbody`, body coordinates
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+    if (b == cbody) {
+      double* Bb = N + SM::OFF_BODY + b * SM::BODY;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) Bb[SM::B_FS + i] -= N[SM::OFF_FEXT + i];
+    }
   // subtree forces
 #pragma unroll
   for (int b = NB - 1; b >= 1; --b) {
@@ -219,7 +234,7 @@ EMPC_HD void lin2_dforce(const EMPC_K EmpcModelDesc& m, int b, const double* Bb,
 // of the body carrying captured frame c.
 template <class DM>
 EMPC_HD void lin2_tangent(const EMPC_K EmpcModelDesc& m, const double* N, int lane, double* dtau, int ncap,
-                          const int* capf, double (*capdv)[6]) {
+                          const int* capf, double (*capdv)[6], int cbody = -1, double* capda = nullptr) {
   typedef Lin2Smem<DM> SM;
   constexpr int NB = DM::NB, NV = DM::NV, NQ = DM::NQ, NX = DM::NX;
   const double* x = N + SM::OFF_X;
@@ -247,6 +262,10 @@ EMPC_HD void lin2_tangent(const EMPC_K EmpcModelDesc& m, const double* N, int la
 #pragma unroll
       for (int i = 0; i < 6; ++i) capdv[c][i] = dv[i];
     }
+  if (cbody == 0 && capda) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) capda[i] = da[i];
+  }
   lin2_dforce<DM>(m, 0, N + SM::OFF_BODY, dv, da, df[0]);
 #pragma unroll
   for (int b = 1; b < NB; ++b) {
@@ -306,6 +325,10 @@ EMPC_HD void lin2_tangent(const EMPC_K EmpcModelDesc& m, const double* N, int la
 #pragma unroll
         for (int i = 0; i < 6; ++i) capdv[cc][i] = dv[i];
       }
+    if (cbody == b && capda) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) capda[i] = da[i];
+    }
     lin2_dforce<DM>(m, b, Bb, dv, da, df[b]);
   }
 #pragma unroll
@@ -383,7 +406,7 @@ EMPC_HD void lin2_frame_jcol(const EMPC_K EmpcModelDesc& m, const double* N, int
   matTvec3<double>(Rf, z, col + 3);
 }
 
-template <class DM, class Exec>
+template <class DM, bool CT, class Exec>
 EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lpu, double* N) {
   typedef Lin2Smem<DM> SM;
   constexpr int NB = DM::NB, NV = DM::NV, NQ = DM::NQ, NX = DM::NX, NDX = DM::NDX, NU = DM::NU, NROT = DM::NROT;
@@ -417,15 +440,40 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
     }
   }
 
+  // contact of this node (ContactModel3D only on the device)
+  const bool use_contact = CT && P.has_contact && set.ncontacts > 0;
+  int cframe = -1, cbody = -1, ccap = 0;
+  if (use_contact) {
+    cframe = set.contacts[0].frame;
+    cbody = m.frame_body[cframe];
+    bool seen = false;
+#pragma unroll
+    for (int k = 0; k < NCAP; ++k)
+      if (k < ncap && capf[k] == cframe) {
+        seen = true;
+        ccap = k;
+      }
+    if (!seen) {
+#pragma unroll
+      for (int k = 0; k < NCAP; ++k)
+        if (k == ncap) capf[k] = cframe;
+      ccap = ncap;
+      ncap = (ncap < NCAP) ? ncap + 1 : ncap;
+    }
+  }
+
   // ---- S0: load x, s, a ------------------------------------------------------------------------------------
   ex.each([&](int lane, int sl) {
     const double* xg = D.xs + ((size_t)b * (T + 1) + t) * NX;
-    const double* ag = D.acc + ((size_t)b * (T + 1) + t) * NV;
+    const double* ag = D.acc + ((size_t)b * (T + 1) + t) * DM::NACC;
     const double* ug = D.us + ((size_t)b * T + (terminal ? 0 : t)) * NU;
     for (int i = lane; i < NX; i += lpu) N[SM::OFF_X + i] = xg[i];
     for (int i = lane; i < NV; i += lpu) N[SM::OFF_A + i] = ag[i];
     for (int i = lane; i < NU; i += lpu) N[SM::OFF_S + i] = terminal ? 0.0 : ug[i];
     if (lane == 0) N[SM::OFF_RED] = 0.0;  // cost accumulator
+    if (CT && lane < 6) {
+      N[SM::OFF_LAM + lane] = use_contact ? ag[NV + lane] : 0.0;
+    }
   });
   ex.sync();
   // ---- S1: squash (lanes < NU), joint sin/cos (next NJ lanes), base rotation (last lane) -------------------------
@@ -440,6 +488,18 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
       const double th = N[SM::OFF_X + 7 + j];
       N[SM::OFF_CS + j] = cos(th);
       N[SM::OFF_SN + j] = sin(th);
+    } else if (CT && lane == lpu - 2) {
+      // contact force as a spatial force on the contact body (body coordinates): X_f^* [lambda; 0]
+      if (use_contact) {
+        double fl[3] = {N[SM::OFF_LAM], N[SM::OFF_LAM + 1], N[SM::OFF_LAM + 2]}, fb[3], rxf[3];
+        matvec3<double>(m.frame_R[cframe], fl, fb);
+        cross3<double>(m.frame_p[cframe], fb, rxf);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          N[SM::OFF_FEXT + i] = fb[i];
+          N[SM::OFF_FEXT + 3 + i] = rxf[i];
+        }
+      }
     } else if (lane == lpu - 1) {
       double q[4] = {N[SM::OFF_X + 3], N[SM::OFF_X + 4], N[SM::OFF_X + 5], N[SM::OFF_X + 6]};
       double R0[9];
@@ -452,7 +512,7 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
   // ---- S2: nominal chain (lane 0) || Euler step and its Lie Jacobians (lane 1) ----------------------------------
   ex.each([&](int lane, int sl) {
     if (lane == 0) {
-      lin2_nominal_chain<DM>(m, N);
+      lin2_nominal_chain<DM>(m, N, use_contact ? cbody : -1);
       // nominal frame data
 #pragma unroll
       for (int c = 0; c < NCAP; ++c) {
@@ -542,13 +602,14 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
   // ---- S3: tangent recursion; inertia columns to LDS ---------------------------------------------------------
   double dtau_l[Exec::SLOTS][NV];
   double jc_l[Exec::SLOTS][NCAP][6], dvc_l[Exec::SLOTS][NCAP][6];
+  double dcon_l[Exec::SLOTS][3], dlam_l[Exec::SLOTS][3];
   ex.each([&](int lane, int sl) {
-    double capdv[NCAP][6];
+    double capdv[NCAP][6], capda[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int c = 0; c < NCAP; ++c)
 #pragma unroll
       for (int i = 0; i < 6; ++i) capdv[c][i] = 0.0;
-    lin2_tangent<DM>(m, N, lane, dtau_l[sl], ncap, capf, capdv);
+    lin2_tangent<DM>(m, N, lane, dtau_l[sl], ncap, capf, capdv, use_contact ? cbody : -1, capda);
     if (lane >= 2 * NV && lane < 3 * NV) {
 #pragma unroll
       for (int i = 0; i < NV; ++i) N[SM::OFF_M + i * NV + (lane - 2 * NV)] = dtau_l[sl][i];
@@ -566,6 +627,47 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
       for (int i = 0; i < 3; ++i) tmp[i] = capdv[c][i] + wxr[i];
       matTvec3<double>(m.frame_R[f], tmp, dvc_l[sl][c]);
       matTvec3<double>(m.frame_R[f], capdv[c] + 3, dvc_l[sl][c] + 3);
+    }
+    if constexpr (CT) {
+      dcon_l[sl][0] = dcon_l[sl][1] = dcon_l[sl][2] = 0.0;
+      dlam_l[sl][0] = dlam_l[sl][1] = dlam_l[sl][2] = 0.0;
+      if (use_contact) {
+        // d(classical acceleration of the contact frame origin, LOCAL), at fixed generalized acceleration:
+        //   d a_f.lin + dphi x (Rf^T (-g)) + d w_f x v_f.lin + w_f x d v_f.lin
+        const double* F = N + SM::OFF_FR + ccap * 18;
+        double daf[3], wxr[3], tmp[3], gf[3], c1[3], c2[3], c3[3];
+        cross3<double>(capda + 3, m.frame_p[cframe], wxr);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) tmp[i] = capda[i] + wxr[i];
+        matTvec3<double>(m.frame_R[cframe], tmp, daf);
+        double ng[3] = {-m.gravity[0], -m.gravity[1], -m.gravity[2]};
+        matTvec3<double>(F, ng, gf);
+        double jcc[6], dvcc[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          jcc[i] = jc_l[sl][0][i];
+          dvcc[i] = dvc_l[sl][0][i];
+        }
+#pragma unroll
+        for (int kk = 1; kk < NCAP; ++kk)
+          if (kk == ccap) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+              jcc[i] = jc_l[sl][kk][i];
+              dvcc[i] = dvc_l[sl][kk][i];
+            }
+          }
+        cross3<double>(jcc + 3, gf, c1);
+        cross3<double>(dvcc + 3, F + 12, c2);
+        cross3<double>(F + 15, dvcc, c3);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) dcon_l[sl][i] = daf[i] + c1[i] + c2[i] + c3[i];
+        if (lane >= 2 * NV && lane < 3 * NV) {
+          // direction da_j: d(con)/d(a_j) is column j of the contact Jacobian
+#pragma unroll
+          for (int r = 0; r < 3; ++r) N[SM::OFF_JC + r * NV + (lane - 2 * NV)] = dcon_l[sl][r];
+        }
+      }
     }
   });
   ex.sync();
@@ -586,6 +688,49 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
     }
   });
   ex.sync();
+  if constexpr (CT) {
+    if (use_contact) {
+      // M^-1 Jc^T (lanes 0..2), then G = Jc M^-1 Jc^T and its Cholesky factor (lane 0)
+      ex.each([&](int lane, int sl) {
+        if (lane >= 3) return;
+        const double* Lm = N + SM::OFF_M;
+        double y[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) y[i] = N[SM::OFF_JC + lane * NV + i];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          double s_ = y[i];
+#pragma unroll
+          for (int kk = 0; kk < i; ++kk) s_ -= Lm[i * NV + kk] * y[kk];
+          y[i] = s_ * Lm[i * NV + i];
+        }
+#pragma unroll
+        for (int i = NV - 1; i >= 0; --i) {
+          double s_ = y[i];
+#pragma unroll
+          for (int kk = i + 1; kk < NV; ++kk) s_ -= Lm[kk * NV + i] * y[kk];
+          y[i] = s_ * Lm[i * NV + i];
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) N[SM::OFF_MIJ + i * 3 + lane] = y[i];
+      });
+      ex.sync();
+      ex.each([&](int lane, int sl) {
+        if (lane != 0) return;
+        double G[6];
+        for (int r = 0; r < 3; ++r)
+          for (int c = 0; c <= r; ++c) {
+            double g = 0;
+            for (int i = 0; i < NV; ++i) g += N[SM::OFF_JC + r * NV + i] * N[SM::OFF_MIJ + i * 3 + c];
+            G[r * (r + 1) / 2 + c] = g;
+          }
+        chol_packed<3>(G);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) N[SM::OFF_G + i] = G[i];
+      });
+      ex.sync();
+    }
+  }
   // ---- S5: M^-1 solves, Euler Jacobian columns -> tape ------------------------------------------------------------
   ex.each([&](int lane, int sl) {
     const bool xlane = lane < NDX;
@@ -622,6 +767,27 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
 #pragma unroll
       for (int kk = i + 1; kk < NV; ++kk) s -= Lm[kk * NV + i] * da[kk];
       da[i] = s * Lm[i * NV + i];
+    }
+    if constexpr (CT) {
+      if (use_contact) {
+        // [M Jc^T; Jc 0][da; -dlam] = [rhs; -dcon]:  dlam = -(Jc M^-1 Jc^T)^-1 (Jc M^-1 rhs + dcon), da += M^-1 Jc^T dlam
+        double z[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          double a_ = xlane ? dcon_l[sl][r] : 0.0;
+#pragma unroll
+          for (int i = 0; i < NV; ++i) a_ += N[SM::OFF_JC + r * NV + i] * da[i];
+          z[r] = -a_;
+        }
+        double Gf[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) Gf[i] = N[SM::OFF_G + i];
+        chol_solve_packed<3>(Gf, z);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) dlam_l[sl][r] = z[r];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) da[i] += N[SM::OFF_MIJ + i * 3] * z[0] + N[SM::OFF_MIJ + i * 3 + 1] * z[1] + N[SM::OFF_MIJ + i * 3 + 2] * z[2];
+      }
     }
     double G[NDX];
 #pragma unroll
@@ -662,10 +828,15 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
   // ---- S6: costs. Column accumulators live in registers: x lanes hold column `lane` of Lxx, u lanes column k of Luu.
   double hx_l[Exec::SLOTS][NDX];  // column of Lxx (x lanes) -- or of Luu in the first NU entries (u lanes)
   double lx_l[Exec::SLOTS];
+  double hxu_l[Exec::SLOTS][CT ? NDX : 1];  // column of Lxu (u lanes; only the friction-cone cost couples x and u)
   ex.each([&](int lane, int sl) {
 #pragma unroll
     for (int i = 0; i < NDX; ++i) hx_l[sl][i] = 0.0;
     lx_l[sl] = 0.0;
+    if constexpr (CT) {
+#pragma unroll
+      for (int i = 0; i < NDX; ++i) hxu_l[sl][i] = 0.0;
+    }
   });
   // round 1: State costs, nominal parts by one lane per cost (same code), up to NSLOT at a time
   for (int base = 0; base < set.ncosts; base += SM::NSLOT) {
@@ -869,6 +1040,76 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
       }
     });
   }
+  if constexpr (CT) {
+    // round 4: ContactFrictionCone (r = A lambda; Rx = A dlambda/dx, Ru = A dlambda/du)
+    for (int ci = 0; ci < set.ncosts; ++ci) {
+      const EMPC_K EmpcCost& c = set.costs[ci];
+      if (!c.active || c.type != EMPC_COST_CONTACT_FRICTION_CONE || !use_contact) continue;
+      ex.sync();
+      ex.each([&](int lane, int sl) {
+        if (lane != 0) return;
+        double AR[5][3], nsf[3] = {c.ref[0], c.ref[1], c.ref[2]};
+        cone_rows(nsf, c.ref[3], AR);
+        double cv = 0;
+        for (int i = 0; i < 5; ++i) {
+          const double r = AR[i][0] * N[SM::OFF_LAM] + AR[i][1] * N[SM::OFF_LAM + 1] + AR[i][2] * N[SM::OFF_LAM + 2];
+          double av, Ar, Arr;
+          activation1(c.activation, r, c.act_w[i], c.lb[i], c.ub[i], av, Ar, Arr);
+          cv += av;
+          N[SM::OFF_CONE + 15 + i] = c.weight * Ar;
+          N[SM::OFF_CONE + 20 + i] = c.weight * Arr;
+          for (int j = 0; j < 3; ++j) N[SM::OFF_CONE + i * 3 + j] = AR[i][j];
+        }
+        N[SM::OFF_RED] += c.weight * cv;
+      });
+      ex.sync();
+      double wc_l[Exec::SLOTS][5];
+      ex.each([&](int lane, int sl) {
+        const bool xlane = lane < NDX;
+        const int k = lane - 2 * NV;
+        const bool ulane = k >= 0 && k < NU;
+        if (!xlane && !ulane) return;
+        const int colidx = xlane ? lane : NDX + k;
+        double g = 0;
+        for (int i = 0; i < 5; ++i) {
+          const double col = N[SM::OFF_CONE + i * 3] * dlam_l[sl][0] + N[SM::OFF_CONE + i * 3 + 1] * dlam_l[sl][1] +
+                             N[SM::OFF_CONE + i * 3 + 2] * dlam_l[sl][2];
+          g += col * N[SM::OFF_CONE + 15 + i];
+          wc_l[sl][i] = N[SM::OFF_CONE + 20 + i] * col;
+          N[SM::OFF_RSH + i * (NDX + NU) + colidx] = col;
+        }
+        lx_l[sl] += g;
+      });
+      ex.sync();
+      ex.each([&](int lane, int sl) {
+        const bool xlane = lane < NDX;
+        const int k = lane - 2 * NV;
+        const bool ulane = k >= 0 && k < NU;
+        if (!xlane && !ulane) return;
+        if (xlane) {
+#pragma unroll
+          for (int i = 0; i < NDX; ++i) {
+            double h = 0;
+            for (int rr = 0; rr < 5; ++rr) h += N[SM::OFF_RSH + rr * (NDX + NU) + i] * wc_l[sl][rr];
+            hx_l[sl][i] += h;
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < NDX; ++i) {
+            double h = 0;
+            for (int rr = 0; rr < 5; ++rr) h += N[SM::OFF_RSH + rr * (NDX + NU) + i] * wc_l[sl][rr];
+            hxu_l[sl][i] += h;
+          }
+#pragma unroll
+          for (int l = 0; l < NU; ++l) {
+            double h = 0;
+            for (int rr = 0; rr < 5; ++rr) h += N[SM::OFF_RSH + rr * (NDX + NU) + NDX + l] * wc_l[sl][rr];
+            hx_l[sl][l] += h;
+          }
+        }
+      });
+    }
+  }
   ex.sync();
   // ---- S7: scale and store ---------------------------------------------------------------------------------------------
   const double cscale = (terminal && !P.prm.terminal_dt_scaling) ? 1.0 : dt;
@@ -884,7 +1125,11 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
 #pragma unroll
       for (int i = 0; i < NU; ++i) out[DM::OFF_LUU + i * NU + k] = hx_l[sl][i] * cscale;
 #pragma unroll
-      for (int i = 0; i < NDX; ++i) out[DM::OFF_LXU + i * NU + k] = 0.0;
+      for (int i = 0; i < NDX; ++i) {
+        double v_ = 0.0;
+        if constexpr (CT) v_ = hxu_l[sl][i] * cscale;
+        out[DM::OFF_LXU + i * NU + k] = v_;
+      }
     }
     if (lane == 0) out[DM::OFF_COST] = N[SM::OFF_RED] * cscale;
   });

@@ -95,7 +95,7 @@ EMPC_HD void rollout_block2(Exec& ex, const DevBuffers& D, int b0, double* smem)
         const double alpha = ldexp(1.0, -ai);
         const bool plain = ddp || feas || (ai == 0);
         const double* S = buf + tb * SM::SLOT;
-        double xtry[NX], dx[NDX], utry[NU], acc[NV], usq[NU];
+        double xtry[NX], dx[NDX], utry[NU], acc[NV], usq[NU], lam[6];
         if (plain) {
 #pragma unroll
           for (int i = 0; i < NX; ++i) xtry[i] = L.xnext[i];
@@ -115,7 +115,7 @@ EMPC_HD void rollout_block2(Exec& ex, const DevBuffers& D, int b0, double* smem)
         const size_t slot = (size_t)b * NA + ai;
         double* xs_o = D.xs_try + slot * (T + 1) * NX;
         double* us_o = D.us_try + slot * T * NU;
-        double* ac_o = D.acc_try + slot * (T + 1) * NV;
+        double* ac_o = D.acc_try + slot * (T + 1) * DM::NACC;
         double cost;
         const EMPC_K EmpcCostSet& set = EMPC_KPTR(EmpcCostSet, D.sets)[EMPC_KPTR(int, D.knot_set)[t]];
         if (t < T) {
@@ -126,17 +126,19 @@ EMPC_HD void rollout_block2(Exec& ex, const DevBuffers& D, int b0, double* smem)
             for (int j = 0; j < NDX; ++j) a_ -= S[SM::S_K + i * NDX + j] * dx[j];
             utry[i] = a_;
           }
-          node_nominal<DM, CT>(EMPC_KREF(DevProblem, D.P), set, st.smooth, xtry, utry, false, L.xnext, acc, cost, usq, nullptr);
+          node_nominal<DM, CT>(EMPC_KREF(DevProblem, D.P), set, st.smooth, xtry, utry, false, L.xnext, acc, cost, usq, lam);
 #pragma unroll
           for (int i = 0; i < NU; ++i) us_o[(size_t)t * NU + i] = utry[i];
         } else {
           double xn2[NX];
-          node_nominal<DM, CT>(EMPC_KREF(DevProblem, D.P), set, st.smooth, xtry, nullptr, true, xn2, acc, cost, usq, nullptr);
+          node_nominal<DM, CT>(EMPC_KREF(DevProblem, D.P), set, st.smooth, xtry, nullptr, true, xn2, acc, cost, usq, lam);
         }
 #pragma unroll
         for (int i = 0; i < NX; ++i) xs_o[(size_t)t * NX + i] = xtry[i];
 #pragma unroll
-        for (int i = 0; i < NV; ++i) ac_o[(size_t)t * NV + i] = acc[i];
+        for (int i = 0; i < NV; ++i) ac_o[(size_t)t * DM::NACC + i] = acc[i];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) ac_o[(size_t)t * DM::NACC + NV + i] = lam[i];
         L.cost_try += cost;
         if (bad_number(L.cost_try)) L.ok = 0;
         if (t < T) {

@@ -33,34 +33,34 @@ using namespace empc;
 // --------------------------------------------------------------------------------------------------------------------
 // kernels
 // --------------------------------------------------------------------------------------------------------------------
-template <class DM>
+template <class DM, bool CT>
 __global__ void __launch_bounds__(64) k_calc(DevBuffers D) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = D.B * (D.T + 1);
   if (idx >= n) return;
   // consecutive lanes = consecutive trajectories of the same node (same cost set -> no divergence)
   const int t = idx / D.B, b = idx % D.B;
-  calc_thread<DM, false>(D, b, t);
+  calc_thread<DM, CT>(D, b, t);
 }
 
 #ifndef EMPC_ROLLOUT_V
 #define EMPC_ROLLOUT_V 1
 #endif
-template <class DM>
+template <class DM, bool CT>
 __global__ void __launch_bounds__(64) k_rollout(DevBuffers D) {
 #if EMPC_ROLLOUT_V == 2
   extern __shared__ double smem_roll[];
   LaneExec ex{(int)threadIdx.x};
-  rollout_block2<DM, false>(ex, D, blockIdx.x * Roll2Smem<DM>::TPB, smem_roll);
+  rollout_block2<DM, CT>(ex, D, blockIdx.x * Roll2Smem<DM>::TPB, smem_roll);
 #else
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= D.B * D.NA) return;
   const int b = idx / D.NA, ai = idx % D.NA;
-  rollout_thread<DM, false>(D, b, ai);
+  rollout_thread<DM, CT>(D, b, ai);
 #endif
 }
 
-template <class DM, int LPU>
+template <class DM, bool CT, int LPU>
 __global__ void __launch_bounds__(128) k_linearize(DevBuffers D) {
   extern __shared__ double smem_lin[];
   constexpr int UPB = 128 / LPU;  // units per block
@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(128) k_linearize(DevBuffers D) {
   const TrajState& st = D.st[b];
   if (st.phase == PHASE_DONE || !st.need_lin) return;
   LaneExec ex{lane};
-  linearize_unit2<DM>(ex, D, b, t, LPU, smem_lin + (size_t)(threadIdx.x / LPU) * Lin2Smem<DM>::SIZE);
+  linearize_unit2<DM, CT>(ex, D, b, t, LPU, smem_lin + (size_t)(threadIdx.x / LPU) * Lin2Smem<DM>::SIZE);
 }
 
 // workgroup-wide executor: barriers are real workgroup barriers
@@ -139,35 +139,35 @@ struct KernelTable {
   void (*rollout)(DevBuffers, hipStream_t);
   void (*select)(DevBuffers, hipStream_t);
   void (*squash_out)(DevBuffers, double*, hipStream_t);
-  int nx, ndx, nu, nv, rec;
+  int nx, ndx, nu, nv, nacc, rec;
   int off[9];
 };
 
-template <class DM>
+template <class DM, bool CT>
 static void launch_calc(DevBuffers D, hipStream_t s) {
   const int n = D.B * (D.T + 1);
-  hipLaunchKernelGGL(k_calc<DM>, dim3((n + 63) / 64), dim3(64), 0, s, D);
+  hipLaunchKernelGGL((k_calc<DM, CT>), dim3((n + 63) / 64), dim3(64), 0, s, D);
 }
-template <class DM>
+template <class DM, bool CT>
 static void launch_linearize(DevBuffers D, hipStream_t s) {
   constexpr int LPU = (3 * DM::NV <= 32) ? 32 : 64;
   constexpr int UPB = 128 / LPU;
   const int n = D.B * (D.T + 1);
   const size_t smem = sizeof(double) * Lin2Smem<DM>::SIZE * UPB;
-  hipLaunchKernelGGL((k_linearize<DM, LPU>), dim3((n + UPB - 1) / UPB), dim3(128), smem, s, D);
+  hipLaunchKernelGGL((k_linearize<DM, CT, LPU>), dim3((n + UPB - 1) / UPB), dim3(128), smem, s, D);
 }
 template <class DM>
 static void launch_backward(DevBuffers D, hipStream_t s) {
   hipLaunchKernelGGL(k_backward<DM>, dim3(D.B), dim3(EMPC_BWD_NL), sizeof(double) * Bwd2Smem<DM>::SIZE, s, D);
 }
-template <class DM>
+template <class DM, bool CT>
 static void launch_rollout(DevBuffers D, hipStream_t s) {
 #if EMPC_ROLLOUT_V == 2
   const int nblk = (D.B + Roll2Smem<DM>::TPB - 1) / Roll2Smem<DM>::TPB;
-  hipLaunchKernelGGL(k_rollout<DM>, dim3(nblk), dim3(64), sizeof(double) * Roll2Smem<DM>::SIZE, s, D);
+  hipLaunchKernelGGL((k_rollout<DM, CT>), dim3(nblk), dim3(64), sizeof(double) * Roll2Smem<DM>::SIZE, s, D);
 #else
   const int n = D.B * D.NA;
-  hipLaunchKernelGGL(k_rollout<DM>, dim3((n + 63) / 64), dim3(64), 0, s, D);
+  hipLaunchKernelGGL((k_rollout<DM, CT>), dim3((n + 63) / 64), dim3(64), 0, s, D);
 #endif
 }
 template <class DM>
@@ -179,28 +179,30 @@ static void launch_squash_out(DevBuffers D, double* out, hipStream_t s) {
   const int n = D.B * D.T * DM::NU;
   hipLaunchKernelGGL(k_squash_out<DM>, dim3((n + 255) / 256), dim3(256), 0, s, D, out);
 }
-template <class DM>
+template <class DM, bool CT>
 static KernelTable make_table() {
   KernelTable k;
-  k.calc = launch_calc<DM>;
-  k.linearize = launch_linearize<DM>;
+  k.calc = launch_calc<DM, CT>;
+  k.linearize = launch_linearize<DM, CT>;
   k.backward = launch_backward<DM>;
-  k.rollout = launch_rollout<DM>;
+  k.rollout = launch_rollout<DM, CT>;
   k.select = launch_select<DM>;
   k.squash_out = launch_squash_out<DM>;
   k.nx = DM::NX;
   k.ndx = DM::NDX;
   k.nu = DM::NU;
   k.nv = DM::NV;
+  k.nacc = DM::NACC;
   k.rec = DM::REC;
   const int off[9] = {DM::OFF_FX, DM::OFF_FU, DM::OFF_LXX, DM::OFF_LXU, DM::OFF_LUU, DM::OFF_LX, DM::OFF_LU, DM::OFF_GAP, DM::OFF_COST};
   std::memcpy(k.off, off, sizeof(off));
   return k;
 }
-static bool find_table(int nb, int nrot, KernelTable& k) {
-  if (nb == 1 && nrot == 6) k = make_table<Dims<1, 6>>();
-  else if (nb == 4 && nrot == 6) k = make_table<Dims<4, 6>>();
-  else if (nb == 6 && nrot == 6) k = make_table<Dims<6, 6>>();
+static bool find_table(int nb, int nrot, bool contact, KernelTable& k) {
+  if (nb == 1 && nrot == 6 && !contact) k = make_table<Dims<1, 6>, false>();
+  else if (nb == 4 && nrot == 6 && !contact) k = make_table<Dims<4, 6>, false>();
+  else if (nb == 4 && nrot == 6 && contact) k = make_table<Dims<4, 6>, true>();
+  else if (nb == 6 && nrot == 6 && !contact) k = make_table<Dims<6, 6>, false>();
   else return false;
   return true;
 }
@@ -299,10 +301,13 @@ EmpcSolver* empc_solver_create(const EmpcProblemDesc* problem, const EmpcSolverP
   s->device = device;
   prepare_problem(*problem, prm, s->H);
   if (problem->has_contact)
-    throw std::runtime_error("contact forward dynamics (ContactModel3D/6D) is not implemented on the device yet");
-  if (!find_table(problem->model.nbodies, problem->n_rotors, s->kt)) {
+    for (const auto& cs : s->H.sets)
+      for (int i = 0; i < cs.ncontacts; ++i)
+        if (cs.contacts[i].type != EMPC_CONTACT_3D)
+          throw std::runtime_error("only ContactModel3D is implemented on the device");
+  if (!find_table(problem->model.nbodies, problem->n_rotors, problem->has_contact != 0, s->kt)) {
     delete s;
-    empc::set_last_error("no kernel instantiation for this (bodies, rotors) combination");
+    empc::set_last_error("no kernel instantiation for this (bodies, rotors, contact) combination");
     return nullptr;
   }
   s->use();
@@ -325,7 +330,7 @@ EmpcSolver* empc_solver_create(const EmpcProblemDesc* problem, const EmpcSolverP
   D.x0 = s->dalloc<double>(B * k.nx);
   D.xs = s->dalloc<double>(B * (T + 1) * k.nx);
   D.us = s->dalloc<double>(B * T * k.nu);
-  D.acc = s->dalloc<double>(B * (T + 1) * k.nv);
+  D.acc = s->dalloc<double>(B * (T + 1) * k.nacc);
   D.tape = s->dalloc<double>(B * (T + 1) * k.rec);
   D.K = s->dalloc<double>(B * T * k.nu * k.ndx);
   D.kff = s->dalloc<double>(B * T * k.nu);
@@ -333,7 +338,7 @@ EmpcSolver* empc_solver_create(const EmpcProblemDesc* problem, const EmpcSolverP
   D.Vf = s->dalloc<double>(B * (T + 1) * k.ndx);
   D.xs_try = s->dalloc<double>(B * NA * (T + 1) * k.nx);
   D.us_try = s->dalloc<double>(B * NA * T * k.nu);
-  D.acc_try = s->dalloc<double>(B * NA * (T + 1) * k.nv);
+  D.acc_try = s->dalloc<double>(B * NA * (T + 1) * k.nacc);
   D.try_cost = s->dalloc<double>(B * NA);
   D.try_dv = s->dalloc<double>(B * NA);
   D.try_ok = s->dalloc<int>(B * NA);
@@ -346,7 +351,7 @@ EmpcSolver* empc_solver_create(const EmpcProblemDesc* problem, const EmpcSolverP
   s->dscratch = s->dalloc<double>(B * T * k.nu);
   HIP_CHECK(hipMemsetAsync(D.tape, 0, sizeof(double) * B * (T + 1) * k.rec, s->stream));
   HIP_CHECK(hipMemsetAsync(D.us_last, 0, sizeof(double) * B * T * k.nu, s->stream));
-  HIP_CHECK(hipMemsetAsync(D.acc, 0, sizeof(double) * B * (T + 1) * k.nv, s->stream));
+  HIP_CHECK(hipMemsetAsync(D.acc, 0, sizeof(double) * B * (T + 1) * k.nacc, s->stream));
   upload_problem(s);
   s->h_st.assign(B, TrajState());
   std::memset(s->h_st.data(), 0, sizeof(TrajState) * B);

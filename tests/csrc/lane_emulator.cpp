@@ -54,7 +54,7 @@ static void emu_alloc(Emu& e) {
   e.x0.assign((size_t)B * DM::NX, 0);
   e.xs.assign((size_t)B * (T + 1) * DM::NX, 0);
   e.us.assign((size_t)B * T * DM::NU, 0);
-  e.acc.assign((size_t)B * (T + 1) * DM::NV, 0);
+  e.acc.assign((size_t)B * (T + 1) * DM::NACC, 0);
   e.tape.assign((size_t)B * (T + 1) * DM::REC, 0);
   e.K.assign((size_t)B * T * DM::NU * DM::NDX, 0);
   e.kff.assign((size_t)B * T * DM::NU, 0);
@@ -62,7 +62,7 @@ static void emu_alloc(Emu& e) {
   e.Vf.assign((size_t)B * (T + 1) * DM::NDX, 0);
   e.xs_try.assign((size_t)B * NA * (T + 1) * DM::NX, 0);
   e.us_try.assign((size_t)B * NA * T * DM::NU, 0);
-  e.acc_try.assign((size_t)B * NA * (T + 1) * DM::NV, 0);
+  e.acc_try.assign((size_t)B * NA * (T + 1) * DM::NACC, 0);
   e.try_cost.assign((size_t)B * NA, 0);
   e.try_dv.assign((size_t)B * NA, 0);
   e.try_ok.assign((size_t)B * NA, 0);
@@ -98,8 +98,17 @@ static void emu_alloc(Emu& e) {
 
 template <class DM>
 static void emu_calc(Emu& e) {
+  const bool ct = e.H.P.has_contact != 0;
   for (int b = 0; b < e.B; ++b)
-    for (int t = 0; t <= e.T; ++t) calc_thread<DM, false>(e.D, b, t);
+    for (int t = 0; t <= e.T; ++t) {
+      if constexpr (DM::NB == 4) {
+        if (ct) {
+          calc_thread<DM, true>(e.D, b, t);
+          continue;
+        }
+      }
+      calc_thread<DM, false>(e.D, b, t);
+    }
 }
 static int g_lin_version = 2;
 template <class DM>
@@ -111,8 +120,15 @@ static void emu_linearize(Emu& e) {
       const TrajState& st = e.st[b];
       if (st.phase == PHASE_DONE || !st.need_lin) continue;
       CpuExec<64> ex{LPU};
-      if (g_lin_version == 2)
-        linearize_unit2<DM>(ex, e.D, b, t, LPU, smem.data());
+      if (g_lin_version == 2) {
+        if constexpr (DM::NB == 4) {
+          if (e.H.P.has_contact) {
+            linearize_unit2<DM, true>(ex, e.D, b, t, LPU, smem.data());
+            continue;
+          }
+        }
+        linearize_unit2<DM, false>(ex, e.D, b, t, LPU, smem.data());
+      }
       else
         linearize_unit<DM>(ex, e.D, b, t, LPU, smem.data());
     }
@@ -138,12 +154,27 @@ static void emu_rollout(Emu& e) {
     std::vector<double> smem(Roll2Smem<DM>::SIZE);
     for (int b0 = 0; b0 < e.B; b0 += Roll2Smem<DM>::TPB) {
       CpuExec<64> ex{64};
+      if constexpr (DM::NB == 4) {
+        if (e.H.P.has_contact) {
+          rollout_block2<DM, true>(ex, e.D, b0, smem.data());
+          continue;
+        }
+      }
       rollout_block2<DM, false>(ex, e.D, b0, smem.data());
     }
     return;
   }
+  const bool ct = e.H.P.has_contact != 0;
   for (int b = 0; b < e.B; ++b)
-    for (int ai = 0; ai < e.NA; ++ai) rollout_thread<DM, false>(e.D, b, ai);
+    for (int ai = 0; ai < e.NA; ++ai) {
+      if constexpr (DM::NB == 4) {
+        if (ct) {
+          rollout_thread<DM, true>(e.D, b, ai);
+          continue;
+        }
+      }
+      rollout_thread<DM, false>(e.D, b, ai);
+    }
 }
 template <class DM>
 static void emu_select(Emu& e) {
@@ -256,7 +287,10 @@ void emu_phase_linearize(void* h, double* tape, double* acc) {
   DISPATCH(e, emu_calc, *e);
   DISPATCH(e, emu_linearize, *e);
   if (tape) std::memcpy(tape, e->tape.data(), sizeof(double) * e->tape.size());
-  if (acc) std::memcpy(acc, e->acc.data(), sizeof(double) * e->acc.size());
+  if (acc) {
+    const int nacc = e->nv + 6;
+    for (size_t u = 0; u < (size_t)e->B * (e->T + 1); ++u) std::memcpy(acc + u * e->nv, &e->acc[u * nacc], sizeof(double) * e->nv);
+  }
 }
 void emu_phase_backward(void* h, double* K, double* k, double* Vx, double* dgdq, int* ok, int* feas, double* cost) {
   Emu* e = static_cast<Emu*>(h);

@@ -42,7 +42,7 @@ def tape_blocks(solver):
             "Lu": (lay["off_lu"], m), "gap": (lay["off_gap"], n), "cost": (lay["off_cost"], 1)}
 
 
-@pytest.mark.parametrize("name", ["hover", "displacement", "push_slide"])
+@pytest.mark.parametrize("name", ["hover", "displacement", "push_slide", "eagle_catch"])
 def test_phase_parity(empc, problems, name):
     """linearize (HOT-A), backward (HOT-B) and rollout (HOT-C) kernels against the oracle's calcDiff / backwardPass /
     forwardPass on random candidates (seeded), one trajectory of the batch at a time."""
@@ -91,7 +91,8 @@ def test_phase_parity(empc, problems, name):
                 assert abs(ct[b] - co) < 1e-6 * (1 + abs(co))
 
 
-@pytest.mark.parametrize("name,B,amp", [("hover", 4, 0.0), ("displacement", 16, 0.05), ("push_slide", 4, 0.05)])
+@pytest.mark.parametrize("name,B,amp", [("hover", 4, 0.0), ("displacement", 16, 0.05), ("push_slide", 4, 0.05),
+                                        ("eagle_catch", 2, 0.0)])
 def test_solve_parity(empc, problems, name, B, amp):
     """SolverSbFDDP.solve on the GPU vs the oracle, same YAML, same perturbed initial states, empty initial guess.
     (hover is solved from the YAML state only: from perturbed states this OCP -- 1e-5 state regularisation -- needs
