@@ -314,6 +314,19 @@ class SolverSbFDDP:
         _check(lib().empc_tape_layout(self._h, C.byref(l)))
         return {n: getattr(l, n) for n, _ in T.TapeLayout._fields_}
 
+    def tape_blocks(self, rec):
+        """Split one tape record (1-D array of `rec` doubles) into its named blocks (matrices as 2-D arrays)."""
+        l = self.tape_layout()
+        n, m = self.ndx, self.nu
+
+        def mat(off, ld, rows, cols):
+            return np.array([rec[off + r * ld: off + r * ld + cols] for r in range(rows)])
+        return {"Fx": mat(l["off_fx"], l["ld_fx"], n, n), "Fu": mat(l["off_fu"], l["ld_fu"], n, m),
+                "Lxx": mat(l["off_lxx"], l["ld_lxx"], n, n), "Lxu": mat(l["off_lxu"], l["ld_lxu"], n, m),
+                "Luu": mat(l["off_luu"], l["ld_luu"], m, m), "Lx": rec[l["off_lx"]:l["off_lx"] + n],
+                "Lu": rec[l["off_lu"]:l["off_lu"] + m], "gap": rec[l["off_gap"]:l["off_gap"] + n],
+                "cost": rec[l["off_cost"]:l["off_cost"] + 1]}
+
     def linearize(self, xs, us, smooth=0.1, is_feasible=False, x0s=None, fetch=True):
         B = self.batch
         if x0s is not None:

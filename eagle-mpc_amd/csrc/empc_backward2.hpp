@@ -100,7 +100,7 @@ EMPC_HD void backward_traj2(Exec& ex, const DevBuffers& D, int b, double* smem) 
     {
       const double* r = tape + (size_t)T * REC;
       ex.each([&](int lane, int sl) {
-        for (int i = lane; i < n * n; i += NL) V[i] = r[DM::OFF_LXX + i] + (((i / n) == (i % n)) ? xreg : 0.0);
+        for (int i = lane; i < n * n; i += NL) V[i] = r[DM::OFF_LXX + (i / n) * nm + (i % n)] + (((i / n) == (i % n)) ? xreg : 0.0);
         if (lane < n) {
           vx[lane] = r[DM::OFF_LX + lane];
           qv[lane] = r[DM::OFF_GAP + lane];  // gap of node T staged in qv
@@ -162,7 +162,7 @@ EMPC_HD void backward_traj2(Exec& ex, const DevBuffers& D, int b, double* smem) 
         if (c >= nm) return;
         double Acol[n];
 #pragma unroll
-        for (int k2 = 0; k2 < n; ++k2) Acol[k2] = (c < n) ? rec[DM::OFF_FX + k2 * n + c] : rec[DM::OFF_FU + k2 * m + (c - n)];
+        for (int k2 = 0; k2 < n; ++k2) Acol[k2] = rec[DM::OFF_A + k2 * nm + c];
         for (int i = g; i < n; i += NG) {
           double a_ = 0;
 #pragma unroll
@@ -181,16 +181,13 @@ EMPC_HD void backward_traj2(Exec& ex, const DevBuffers& D, int b, double* smem) 
         for (int rr = g; rr < nm; rr += NG) {
           if (rr >= n && c < n) continue;
           double a_;
-          if (rr < n && c < n)
-            a_ = rec[DM::OFF_LXX + rr * n + c];
-          else if (rr < n)
-            a_ = rec[DM::OFF_LXU + rr * m + (c - n)];
+          if (rr < n)
+            a_ = rec[DM::OFF_HX + rr * nm + c];
           else
             a_ = rec[DM::OFF_LUU + (rr - n) * m + (c - n)];
 #pragma unroll
           for (int k2 = 0; k2 < n; ++k2) {
-            const double Akr = (rr < n) ? rec[DM::OFF_FX + k2 * n + rr] : rec[DM::OFF_FU + k2 * m + (rr - n)];
-            a_ += Akr * Wcol[k2];
+            a_ += rec[DM::OFF_A + k2 * nm + rr] * Wcol[k2];
           }
           Q[rr * nm + c] = a_;
         }
@@ -198,8 +195,7 @@ EMPC_HD void backward_traj2(Exec& ex, const DevBuffers& D, int b, double* smem) 
           double a_ = (c < n) ? rec[DM::OFF_LX + c] : rec[DM::OFF_LU + (c - n)];
 #pragma unroll
           for (int k2 = 0; k2 < n; ++k2) {
-            const double Akc = (c < n) ? rec[DM::OFF_FX + k2 * n + c] : rec[DM::OFF_FU + k2 * m + (c - n)];
-            a_ += Akc * vx[k2];
+            a_ += rec[DM::OFF_A + k2 * nm + c] * vx[k2];
           }
           qv[c] = a_;
         }

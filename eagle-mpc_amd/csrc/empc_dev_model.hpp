@@ -37,12 +37,18 @@ struct Dims {
   static constexpr int NU = NROT_ + NJ;
   static constexpr int NTRI = NV * (NV + 1) / 2;
   static constexpr int NACC = NV + 6;  // stride of the per-node stash: generalized acceleration | contact force
-  // tape record of one node (doubles); layout shared by linearize (writer) and backward (reader)
-  static constexpr int OFF_FX = 0;                       // ndx x ndx row-major
-  static constexpr int OFF_FU = OFF_FX + NDX * NDX;      // ndx x nu
-  static constexpr int OFF_LXX = OFF_FU + NDX * NU;      // ndx x ndx
-  static constexpr int OFF_LXU = OFF_LXX + NDX * NDX;    // ndx x nu
-  static constexpr int OFF_LUU = OFF_LXU + NDX * NU;     // nu x nu
+  // tape record of one node (doubles); layout shared by linearize (writer) and backward (reader):
+  //   A  = [Fx Fu]    n x (n+m) row-major  (so that row k of the dynamics Jacobian is one contiguous LDS row)
+  //   HX = [Lxx Lxu]  n x (n+m) row-major
+  //   LUU m x m | LX n | LU m | GAP n (fs[t]) | COST 1
+  static constexpr int NM = NDX + NU;
+  static constexpr int OFF_A = 0;
+  static constexpr int OFF_FX = OFF_A;                   // leading dimension NM
+  static constexpr int OFF_FU = OFF_A + NDX;             // leading dimension NM
+  static constexpr int OFF_HX = OFF_A + NDX * NM;
+  static constexpr int OFF_LXX = OFF_HX;                 // leading dimension NM
+  static constexpr int OFF_LXU = OFF_HX + NDX;           // leading dimension NM
+  static constexpr int OFF_LUU = OFF_HX + NDX * NM;      // leading dimension NU
   static constexpr int OFF_LX = OFF_LUU + NU * NU;       // ndx
   static constexpr int OFF_LU = OFF_LX + NDX;            // nu
   static constexpr int OFF_GAP = OFF_LU + NU;            // ndx   fs[t]

@@ -809,14 +809,14 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
         for (int r = 0; r < 6; ++r) top[r] += N[SM::OFF_J1 + r * 6 + lane];
       }
 #pragma unroll
-      for (int r = 0; r < 6; ++r) out[DM::OFF_FX + r * NDX + lane] = top[r];
+      for (int r = 0; r < 6; ++r) out[DM::OFF_FX + r * DM::NM + lane] = top[r];
 #pragma unroll
-      for (int r = 6; r < NDX; ++r) out[DM::OFF_FX + r * NDX + lane] = G[r] + ((r == lane) ? 1.0 : 0.0);
+      for (int r = 6; r < NDX; ++r) out[DM::OFF_FX + r * DM::NM + lane] = G[r] + ((r == lane) ? 1.0 : 0.0);
     } else {
 #pragma unroll
-      for (int r = 0; r < 6; ++r) out[DM::OFF_FU + r * NU + k] = top[r];
+      for (int r = 0; r < 6; ++r) out[DM::OFF_FU + r * DM::NM + k] = top[r];
 #pragma unroll
-      for (int r = 6; r < NDX; ++r) out[DM::OFF_FU + r * NU + k] = G[r];
+      for (int r = 6; r < NDX; ++r) out[DM::OFF_FU + r * DM::NM + k] = G[r];
     }
     // gaps
     if (xlane) {
@@ -1117,7 +1117,7 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
     if (lane < NDX) {
       out[DM::OFF_LX + lane] = lx_l[sl] * cscale;
 #pragma unroll
-      for (int i = 0; i < NDX; ++i) out[DM::OFF_LXX + i * NDX + lane] = hx_l[sl][i] * cscale;
+      for (int i = 0; i < NDX; ++i) out[DM::OFF_LXX + i * DM::NM + lane] = hx_l[sl][i] * cscale;
     }
     const int k = lane - 2 * NV;
     if (k >= 0 && k < NU) {
@@ -1128,7 +1128,7 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
       for (int i = 0; i < NDX; ++i) {
         double v_ = 0.0;
         if constexpr (CT) v_ = hxu_l[sl][i] * cscale;
-        out[DM::OFF_LXU + i * NU + k] = v_;
+        out[DM::OFF_LXU + i * DM::NM + k] = v_;
       }
     }
     if (lane == 0) out[DM::OFF_COST] = N[SM::OFF_RED] * cscale;

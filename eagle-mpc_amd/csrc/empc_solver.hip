@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -19,7 +20,6 @@
 #include "empc_prep.hpp"
 #include "empc_linearize2.hpp"
 #include "empc_backward2.hpp"
-#include "empc_rollout2.hpp"
 
 using namespace empc;
 
@@ -43,21 +43,12 @@ __global__ void __launch_bounds__(64) k_calc(DevBuffers D) {
   calc_thread<DM, CT>(D, b, t);
 }
 
-#ifndef EMPC_ROLLOUT_V
-#define EMPC_ROLLOUT_V 1
-#endif
 template <class DM, bool CT>
 __global__ void __launch_bounds__(64) k_rollout(DevBuffers D) {
-#if EMPC_ROLLOUT_V == 2
-  extern __shared__ double smem_roll[];
-  LaneExec ex{(int)threadIdx.x};
-  rollout_block2<DM, CT>(ex, D, blockIdx.x * Roll2Smem<DM>::TPB, smem_roll);
-#else
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= D.B * D.NA) return;
   const int b = idx / D.NA, ai = idx % D.NA;
   rollout_thread<DM, CT>(D, b, ai);
-#endif
 }
 
 template <class DM, bool CT, int LPU>
@@ -81,9 +72,14 @@ struct BlockExec {
   static constexpr int SLOTS = 1;
   template <class F>
   __device__ __forceinline__ void each(F&& f) {
+    __builtin_amdgcn_sched_barrier(0);  // keep the scheduler from interleaving stages (register pressure)
     f(lane, 0);
+    __builtin_amdgcn_sched_barrier(0);
   }
-  __device__ __forceinline__ void sync() { __syncthreads(); }
+  __device__ __forceinline__ void sync() {
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+  }
   template <class F>
   __device__ __forceinline__ bool any(F&& f) {
     return __syncthreads_or(f(lane, 0) ? 1 : 0) != 0;
@@ -140,7 +136,7 @@ struct KernelTable {
   void (*select)(DevBuffers, hipStream_t);
   void (*squash_out)(DevBuffers, double*, hipStream_t);
   int nx, ndx, nu, nv, nacc, rec;
-  int off[9];
+  int off[9], ld[5];
 };
 
 template <class DM, bool CT>
@@ -162,13 +158,8 @@ static void launch_backward(DevBuffers D, hipStream_t s) {
 }
 template <class DM, bool CT>
 static void launch_rollout(DevBuffers D, hipStream_t s) {
-#if EMPC_ROLLOUT_V == 2
-  const int nblk = (D.B + Roll2Smem<DM>::TPB - 1) / Roll2Smem<DM>::TPB;
-  hipLaunchKernelGGL((k_rollout<DM, CT>), dim3(nblk), dim3(64), sizeof(double) * Roll2Smem<DM>::SIZE, s, D);
-#else
   const int n = D.B * D.NA;
   hipLaunchKernelGGL((k_rollout<DM, CT>), dim3((n + 63) / 64), dim3(64), 0, s, D);
-#endif
 }
 template <class DM>
 static void launch_select(DevBuffers D, hipStream_t s) {
@@ -196,6 +187,8 @@ static KernelTable make_table() {
   k.rec = DM::REC;
   const int off[9] = {DM::OFF_FX, DM::OFF_FU, DM::OFF_LXX, DM::OFF_LXU, DM::OFF_LUU, DM::OFF_LX, DM::OFF_LU, DM::OFF_GAP, DM::OFF_COST};
   std::memcpy(k.off, off, sizeof(off));
+  const int ld[5] = {DM::NM, DM::NM, DM::NM, DM::NM, DM::NU};  // Fx, Fu, Lxx, Lxu, Luu leading dimensions
+  std::memcpy(k.ld, ld, sizeof(ld));
   return k;
 }
 static bool find_table(int nb, int nrot, bool contact, KernelTable& k) {
@@ -213,6 +206,10 @@ struct EmpcSolver {
   int device = 0, B = 0, T = 0, NA = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev[8] = {};
+  static constexpr int MAX_STREAMS = 16;
+  int n_streams = 1;
+  hipStream_t streams[MAX_STREAMS] = {};
+  hipEvent_t cev[MAX_STREAMS][6] = {};
   DevBuffers D;
   DevProblem* dP = nullptr;
   EmpcCostSet* dsets = nullptr;
@@ -238,6 +235,11 @@ struct EmpcSolver {
     if (h_active) (void)hipHostFree(h_active);
     for (auto& e : ev)
       if (e) (void)hipEventDestroy(e);
+    for (int c = 0; c < MAX_STREAMS; ++c) {
+      for (auto& e : cev[c])
+        if (e) (void)hipEventDestroy(e);
+      if (streams[c]) (void)hipStreamDestroy(streams[c]);
+    }
     if (stream) (void)hipStreamDestroy(stream);
   }
 };
@@ -316,7 +318,19 @@ EmpcSolver* empc_solver_create(const EmpcProblemDesc* problem, const EmpcSolverP
   s->NA = prm.n_alphas;
   HIP_CHECK(hipStreamCreate(&s->stream));
   for (auto& e : s->ev) HIP_CHECK(hipEventCreate(&e));
-  HIP_CHECK(hipHostMalloc((void**)&s->h_active, sizeof(int)));
+  HIP_CHECK(hipHostMalloc((void**)&s->h_active, sizeof(int) * EmpcSolver::MAX_STREAMS));
+  {
+    // independent chunks of the batch run on separate streams (EMPC_STREAMS overrides; 1 = single stream)
+    int ns = 1;  // measured on MI355X (profiles/r01_streams.txt): lock-stepped chunks do not overlap usefully
+    if (const char* e = std::getenv("EMPC_STREAMS")) ns = std::atoi(e);
+    if (ns < 1) ns = 1;
+    if (ns > EmpcSolver::MAX_STREAMS) ns = EmpcSolver::MAX_STREAMS;
+    s->n_streams = ns;
+    for (int c = 0; c < ns; ++c) {
+      HIP_CHECK(hipStreamCreate(&s->streams[c]));
+      for (auto& e : s->cev[c]) HIP_CHECK(hipEventCreate(&e));
+    }
+  }
   const size_t B = batch, T = s->T, NA = s->NA;
   const KernelTable& k = s->kt;
   s->dP = s->dalloc<DevProblem>(1);
@@ -343,7 +357,9 @@ EmpcSolver* empc_solver_create(const EmpcProblemDesc* problem, const EmpcSolverP
   D.try_dv = s->dalloc<double>(B * NA);
   D.try_ok = s->dalloc<int>(B * NA);
   D.us_last = s->dalloc<double>(B * T * k.nu);
-  D.n_active = s->dalloc<int>(1);
+  D.n_active = s->dalloc<int>(EmpcSolver::MAX_STREAMS);
+  D.dbg = s->dalloc<unsigned long long>(64);
+  HIP_CHECK(hipMemsetAsync(D.dbg, 0, 64 * sizeof(unsigned long long), s->stream));
   D.B = batch;
   D.T = s->T;
   D.NA = s->NA;
@@ -391,6 +407,11 @@ int empc_tape_layout(const EmpcSolver* s, EmpcTapeLayout* l) {
   l->off_lu = s->kt.off[6];
   l->off_gap = s->kt.off[7];
   l->off_cost = s->kt.off[8];
+  l->ld_fx = s->kt.ld[0];
+  l->ld_fu = s->kt.ld[1];
+  l->ld_lxx = s->kt.ld[2];
+  l->ld_lxu = s->kt.ld[3];
+  l->ld_luu = s->kt.ld[4];
   return EMPC_OK;
 }
 
@@ -462,6 +483,42 @@ static void timed(EmpcSolver* s, int slot, double& acc_ms) {
   if (hipEventElapsedTime(&ms, s->ev[slot], s->ev[slot + 1]) == hipSuccess) acc_ms += ms;
 }
 
+// One chunk of the batch = one HIP stream.  The three hot kernels are latency bound at batch 1024 (backward: one
+// wavefront per SIMD; rollout: 160 wavefronts), so independent chunks running on separate streams overlap on the
+// device and fill the idle SIMDs; there is no dependency between trajectories, hence none between chunks.
+struct Chunk {
+  DevBuffers D;
+  hipStream_t stream;
+  hipEvent_t ev[6];
+  int b0, nb, active, idx;
+};
+
+static DevBuffers chunk_view(const EmpcSolver* s, int b0, int nb, int idx) {
+  DevBuffers D = s->D;
+  const size_t T = s->T, NA = s->NA;
+  const KernelTable& k = s->kt;
+  D.st += b0;
+  D.x0 += (size_t)b0 * k.nx;
+  D.xs += (size_t)b0 * (T + 1) * k.nx;
+  D.us += (size_t)b0 * T * k.nu;
+  D.acc += (size_t)b0 * (T + 1) * k.nacc;
+  D.tape += (size_t)b0 * (T + 1) * k.rec;
+  D.K += (size_t)b0 * T * k.nu * k.ndx;
+  D.kff += (size_t)b0 * T * k.nu;
+  D.Vx += (size_t)b0 * (T + 1) * k.ndx;
+  D.Vf += (size_t)b0 * (T + 1) * k.ndx;
+  D.xs_try += (size_t)b0 * NA * (T + 1) * k.nx;
+  D.us_try += (size_t)b0 * NA * T * k.nu;
+  D.acc_try += (size_t)b0 * NA * (T + 1) * k.nacc;
+  D.try_cost += (size_t)b0 * NA;
+  D.try_dv += (size_t)b0 * NA;
+  D.try_ok += (size_t)b0 * NA;
+  D.us_last += (size_t)b0 * T * k.nu;
+  D.n_active = s->D.n_active + idx;
+  D.B = nb;
+  return D;
+}
+
 int empc_solver_solve(EmpcSolver* s, int maxiter, int is_feasible) {
   EMPC_TRY
   if (!s) throw std::invalid_argument("solver is NULL");
@@ -472,51 +529,75 @@ int empc_solver_solve(EmpcSolver* s, int maxiter, int is_feasible) {
     init_traj_state(s->h_st[b], s->H.P.prm, maxiter, is_feasible != 0, s->have_state ? &prev : nullptr);
   }
   upload_states(s);
+  HIP_CHECK(hipStreamSynchronize(s->stream));
   EmpcSolveStats& S = s->stats;
   std::memset(&S, 0, sizeof(S));
+  const KernelTable& k = s->kt;
+  // chunking
+  int nchunks = s->n_streams;
+  if (nchunks > s->B) nchunks = s->B;
+  if (nchunks < 1) nchunks = 1;
+  std::vector<Chunk> chunks(nchunks);
+  for (int c = 0; c < nchunks; ++c) {
+    const int lo = (int)((long long)s->B * c / nchunks), hi = (int)((long long)s->B * (c + 1) / nchunks);
+    chunks[c].b0 = lo;
+    chunks[c].nb = hi - lo;
+    chunks[c].idx = c;
+    chunks[c].active = hi - lo;
+    chunks[c].D = chunk_view(s, lo, hi - lo, c);
+    chunks[c].stream = s->streams[c];
+    for (int e = 0; e < 6; ++e) chunks[c].ev[e] = s->cev[c][e];
+  }
   hipEvent_t t_begin, t_end;
   HIP_CHECK(hipEventCreate(&t_begin));
   HIP_CHECK(hipEventCreate(&t_end));
   HIP_CHECK(hipEventRecord(t_begin, s->stream));
-  const DevBuffers& D = s->D;
-  const KernelTable& k = s->kt;
-  const int hard_cap = 3 * (maxiter + 1) + 8;  // (passes + clean-up) x maxiter can never be exceeded
-  int active = s->B;
-  bool first = true;
-  while (active > 0 && S.sweeps < hard_cap * 4) {
-    HIP_CHECK(hipMemsetAsync(D.n_active, 0, sizeof(int), s->stream));
-    HIP_CHECK(hipEventRecord(s->ev[0], s->stream));
-    k.calc(D, s->stream);
-    HIP_CHECK(hipEventRecord(s->ev[1], s->stream));
-    k.linearize(D, s->stream);
-    HIP_CHECK(hipEventRecord(s->ev[2], s->stream));
-    k.backward(D, s->stream);
-    HIP_CHECK(hipEventRecord(s->ev[3], s->stream));
-    k.rollout(D, s->stream);
-    HIP_CHECK(hipEventRecord(s->ev[4], s->stream));
-    k.select(D, s->stream);
-    HIP_CHECK(hipEventRecord(s->ev[5], s->stream));
-    HIP_CHECK(hipMemcpyAsync(s->h_active, D.n_active, sizeof(int), hipMemcpyDeviceToHost, s->stream));
-    HIP_CHECK(hipStreamSynchronize(s->stream));
+  const int hard_cap = 4 * (3 * (maxiter + 1) + 8);  // (passes + clean-up) x maxiter can never be exceeded
+  int total_active = s->B;
+  while (total_active > 0 && S.sweeps < hard_cap) {
+    for (auto& c : chunks) {
+      if (c.active <= 0) continue;
+      HIP_CHECK(hipMemsetAsync(c.D.n_active, 0, sizeof(int), c.stream));
+      HIP_CHECK(hipEventRecord(c.ev[0], c.stream));
+      k.calc(c.D, c.stream);
+      HIP_CHECK(hipEventRecord(c.ev[1], c.stream));
+      k.linearize(c.D, c.stream);
+      HIP_CHECK(hipEventRecord(c.ev[2], c.stream));
+      k.backward(c.D, c.stream);
+      HIP_CHECK(hipEventRecord(c.ev[3], c.stream));
+      k.rollout(c.D, c.stream);
+      HIP_CHECK(hipEventRecord(c.ev[4], c.stream));
+      k.select(c.D, c.stream);
+      HIP_CHECK(hipEventRecord(c.ev[5], c.stream));
+      HIP_CHECK(hipMemcpyAsync(s->h_active + c.idx, c.D.n_active, sizeof(int), hipMemcpyDeviceToHost, c.stream));
+    }
+    total_active = 0;
+    for (auto& c : chunks) {
+      if (c.active <= 0) continue;
+      HIP_CHECK(hipStreamSynchronize(c.stream));
+      auto el = [&](int a) {
+        float ms = 0;
+        return hipEventElapsedTime(&ms, c.ev[a], c.ev[a + 1]) == hipSuccess ? (double)ms : 0.0;
+      };
+      S.ms_calc += el(0);
+      S.ms_linearize += el(1);
+      S.ms_backward += el(2);
+      S.ms_rollout += el(3);
+      S.ms_select += el(4);
+      S.n_calc++;
+      S.n_linearize++;
+      S.n_backward++;
+      S.n_rollout++;
+      S.n_select++;
+      S.backward_units += (long long)c.active * s->T;
+      S.rollout_units += (long long)c.active * s->NA * (s->T + 1);
+      S.linearize_units += (long long)c.active * (s->T + 1);  // upper bound: trajectories that re-linearize this sweep
+      c.active = s->h_active[c.idx];
+      total_active += c.active;
+    }
     HIP_CHECK(hipGetLastError());
-    timed(s, 0, S.ms_calc);
-    timed(s, 1, S.ms_linearize);
-    timed(s, 2, S.ms_backward);
-    timed(s, 3, S.ms_rollout);
-    timed(s, 4, S.ms_select);
-    S.n_calc++;
-    S.n_linearize++;
-    S.n_backward++;
-    S.n_rollout++;
-    S.n_select++;
-    S.backward_units += (long long)active * s->T;
-    S.rollout_units += (long long)active * s->NA * (s->T + 1);
-    S.linearize_units += (long long)active * (s->T + 1);  // upper bound: trajectories that re-linearize this sweep
     S.sweeps++;
-    active = *s->h_active;
-    first = false;
   }
-  (void)first;
   HIP_CHECK(hipEventRecord(t_end, s->stream));
   download_states(s);
   float ms = 0;
@@ -529,7 +610,7 @@ int empc_solver_solve(EmpcSolver* s, int maxiter, int is_feasible) {
     S.total_iters += s->h_st[b].total_iters;
     S.max_iters = std::max(S.max_iters, s->h_st[b].total_iters);
   }
-  if (active > 0) throw std::runtime_error("solve did not terminate within the sweep cap (internal error)");
+  if (total_active > 0) throw std::runtime_error("solve did not terminate within the sweep cap (internal error)");
   return EMPC_OK;
   EMPC_CATCH(RET_INT)
 }
@@ -579,6 +660,12 @@ int empc_solver_get_iters(EmpcSolver* s, int* iters) {
 int empc_solver_get_status(EmpcSolver* s, int* status) {
   if (!s || !status) return EMPC_ERR_INVALID;
   for (int b = 0; b < s->B; ++b) status[b] = s->h_st[b].status;
+  return EMPC_OK;
+}
+// diagnostic builds only (-DEMPC_STAMPS): per-stage cycle counters written by trajectory 0
+int empc_solver_debug_counters(EmpcSolver* s, unsigned long long* out, int n) {
+  if (!s || !out || n > 64) return EMPC_ERR_INVALID;
+  if (hipMemcpy(out, s->D.dbg, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost) != hipSuccess) return EMPC_ERR_RUNTIME;
   return EMPC_OK;
 }
 int empc_solver_get_stats(EmpcSolver* s, EmpcSolveStats* stats) {

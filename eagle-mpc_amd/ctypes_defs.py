@@ -107,7 +107,8 @@ class SolveStats(C.Structure):
 
 class TapeLayout(C.Structure):
     _fields_ = [(n, C.c_int) for n in
-                ("rec", "off_fx", "off_fu", "off_lxx", "off_lxu", "off_luu", "off_lx", "off_lu", "off_gap", "off_cost")]
+                ("rec", "off_fx", "off_fu", "off_lxx", "off_lxu", "off_luu", "off_lx", "off_lu", "off_gap", "off_cost",
+                 "ld_fx", "ld_fu", "ld_lxx", "ld_lxu", "ld_luu")]
 
 
 STATUS_CONVERGED = 1

@@ -106,6 +106,8 @@ typedef struct EmpcSolveStats {
   int n_linearize, n_backward, n_rollout, n_select, n_calc;         /* launches                              */
 } EmpcSolveStats;
 int empc_solver_get_stats(EmpcSolver* s, EmpcSolveStats* stats);
+/* diagnostic builds only (-DEMPC_STAMPS): in-kernel cycle stamps of the backward kernel, trajectory 0 */
+int empc_solver_debug_counters(EmpcSolver* s, unsigned long long* out, int n);
 int empc_solver_dims(const EmpcSolver* s, int* batch, int* T, int* nx, int* ndx, int* nu, int* rec_doubles);
 
 /* ---- phase-level entry points (device kernels, one call = one launch over the whole batch) ------------------
@@ -125,6 +127,7 @@ int empc_rollout_batch(EmpcSolver* s, double alpha, int ddp, int is_feasible, do
 /* offsets (in doubles) of the blocks inside one tape record */
 typedef struct EmpcTapeLayout {
   int rec, off_fx, off_fu, off_lxx, off_lxu, off_luu, off_lx, off_lu, off_gap, off_cost;
+  int ld_fx, ld_fu, ld_lxx, ld_lxu, ld_luu; /* leading dimensions (row strides) of the matrix blocks */
 } EmpcTapeLayout;
 int empc_tape_layout(const EmpcSolver* s, EmpcTapeLayout* layout);
 

@@ -9,7 +9,6 @@
 #include "../../eagle-mpc_amd/csrc/empc_prep.hpp"
 #include "../../eagle-mpc_amd/csrc/empc_linearize2.hpp"
 #include "../../eagle-mpc_amd/csrc/empc_backward2.hpp"
-#include "../../eagle-mpc_amd/csrc/empc_rollout2.hpp"
 
 using namespace empc;
 
@@ -89,6 +88,7 @@ static void emu_alloc(Emu& e) {
   D.try_ok = e.try_ok.data();
   D.us_last = e.us_last.data();
   D.n_active = &e.n_active;
+  D.dbg = nullptr;
   D.B = B;
   D.T = T;
   D.NA = NA;
@@ -114,56 +114,37 @@ static int g_lin_version = 2;
 template <class DM>
 static void emu_linearize(Emu& e) {
   constexpr int LPU = (3 * DM::NV <= 32) ? 32 : 64;
-  std::vector<double> smem(LinSmem<DM>::SIZE + Lin2Smem<DM>::SIZE);
+  std::vector<double> smem(Lin2Smem<DM>::SIZE);
   for (int t = 0; t <= e.T; ++t)
     for (int b = 0; b < e.B; ++b) {
       const TrajState& st = e.st[b];
       if (st.phase == PHASE_DONE || !st.need_lin) continue;
       CpuExec<64> ex{LPU};
-      if (g_lin_version == 2) {
-        if constexpr (DM::NB == 4) {
-          if (e.H.P.has_contact) {
-            linearize_unit2<DM, true>(ex, e.D, b, t, LPU, smem.data());
-            continue;
-          }
+      if constexpr (DM::NB == 4) {
+        if (e.H.P.has_contact) {
+          linearize_unit2<DM, true>(ex, e.D, b, t, LPU, smem.data());
+          continue;
         }
-        linearize_unit2<DM, false>(ex, e.D, b, t, LPU, smem.data());
       }
-      else
-        linearize_unit<DM>(ex, e.D, b, t, LPU, smem.data());
+      linearize_unit2<DM, false>(ex, e.D, b, t, LPU, smem.data());
     }
 }
 static int g_bwd_version = 2;
 template <class DM>
 static void emu_backward(Emu& e) {
-  std::vector<double> smem(BwdSmem<DM>::SIZE + Bwd2Smem<DM>::SIZE);
+  std::vector<double> smem(Bwd2Smem<DM>::SIZE);
   for (int b = 0; b < e.B; ++b) {
     if (g_bwd_version == 2) {
       CpuExec<256> ex{256};
-      backward_traj2<DM, 256>(ex, e.D, b, smem.data());
+      backward_traj2<DM, 256>(ex, e.D, b, smem.data());  // four-wavefront tiling
     } else {
-      CpuExec<64> ex{64};
-      backward_traj<DM>(ex, e.D, b, smem.data());
+      CpuExec<256> ex{64};
+      backward_traj2<DM, 64>(ex, e.D, b, smem.data());   // the shipped single-wavefront configuration
     }
   }
 }
-static int g_roll_version = 2;
 template <class DM>
 static void emu_rollout(Emu& e) {
-  if (g_roll_version == 2) {
-    std::vector<double> smem(Roll2Smem<DM>::SIZE);
-    for (int b0 = 0; b0 < e.B; b0 += Roll2Smem<DM>::TPB) {
-      CpuExec<64> ex{64};
-      if constexpr (DM::NB == 4) {
-        if (e.H.P.has_contact) {
-          rollout_block2<DM, true>(ex, e.D, b0, smem.data());
-          continue;
-        }
-      }
-      rollout_block2<DM, false>(ex, e.D, b0, smem.data());
-    }
-    return;
-  }
   const bool ct = e.H.P.has_contact != 0;
   for (int b = 0; b < e.B; ++b)
     for (int ai = 0; ai < e.NA; ++ai) {
@@ -216,7 +197,7 @@ static void emu_solve(Emu& e, int maxiter, int is_feasible) {
 extern "C" {
 void emu_set_linearize_version(int v) { g_lin_version = v; }
 void emu_set_backward_version(int v) { g_bwd_version = v; }
-void emu_set_rollout_version(int v) { g_roll_version = v; }
+
 void* emu_create(const EmpcProblemDesc* d, const EmpcSolverParams* prm, int B) {
   Emu* e = new Emu();
   try {

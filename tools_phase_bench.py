@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Time the three hot kernels in isolation (phase-level C ABI) on a full batch: ms per launch from HIP events."""
+import argparse, json, sys, os
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import empc_loader
+empc = empc_loader.load()
+from bench import CONFIGS, algorithmic_words
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--config", default="displacement")
+ap.add_argument("--batch", type=int, default=1024)
+ap.add_argument("--reps", type=int, default=5)
+a = ap.parse_args()
+rel, dt = CONFIGS[a.config]
+t = empc.Trajectory(); t.autoSetup(empc.yaml_path(rel)); p = t.createProblem(dt, True, "IntegratedActionModelEuler")
+d = p.desc
+B = a.batch
+s = empc.SolverSbFDDP(p, batch=B)
+x0s = empc.perturbed_x0s(p.x0, B, nq=d.model.nq)
+# a realistic candidate: two iterations of the solver from the empty guess
+s.solve([], [], 2, x0s=x0s)
+xs, us = s.xs_batch, s.us_batch
+res = {}
+for name in ("linearize", "backward", "rollout"):
+    ts = []
+    for r in range(a.reps):
+        if name == "linearize":
+            s.linearize(xs, us, smooth=0.1, is_feasible=False, x0s=x0s, fetch=False)
+        elif name == "backward":
+            s.backward(xreg=1e-9, is_feasible=False)
+        else:
+            s.rollout(1.0, ddp=False, is_feasible=False)
+        ts.append(s.stats()["ms_" + name])
+    res[name] = float(np.median(ts))
+w = algorithmic_words(d.nx, d.ndx, d.nu)
+units = {"linearize": B * (d.T + 1), "backward": B * d.T, "rollout": B * 10 * (d.T + 1)}
+out = {k: {"ms": v, "GBs": units[k] * w[k] * 8 / (v * 1e-3) / 1e9} for k, v in res.items()}
+print(json.dumps(out))
+import ctypes as C
+cnt = (C.c_ulonglong * 24)()
+empc.lib().empc_solver_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
+empc.lib().empc_solver_debug_counters(s._h, cnt, 24)
+print('backward stage cycles (traj 0, whole sweep):', list(cnt))
