@@ -82,6 +82,20 @@ def lib():
     L.empc_linearize_batch.argtypes = [C.c_void_p, _dp, _dp, C.c_double, C.c_int, _dp, _dp, _dp]
     L.empc_backward_batch.argtypes = [C.c_void_p, C.c_double, C.c_int, _dp, _dp, _dp, _dp, _ip]
     L.empc_rollout_batch.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int, _dp, _dp, _dp, _ip]
+    L.empc_plant_set_state.argtypes = [C.c_void_p, _dp]
+    L.empc_plant_get_state.argtypes = [C.c_void_p, _dp]
+    L.empc_plant_step.argtypes = [C.c_void_p, C.c_double, _dp, C.c_int]
+    L.empc_solver_set_x0_from_plant.argtypes = [C.c_void_p]
+    L.empc_carrot_mpc_create.restype = C.c_void_p
+    L.empc_carrot_mpc_create.argtypes = [C.c_void_p, _dp, C.c_int, C.c_int, C.c_char_p]
+    L.empc_carrot_mpc_destroy.argtypes = [C.c_void_p]
+    L.empc_carrot_mpc_params.argtypes = [C.c_void_p] + [_ip] * 7
+    L.empc_carrot_mpc_t_stages.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+    L.empc_carrot_mpc_update_problem.argtypes = [C.c_void_p, C.c_longlong]
+    L.empc_carrot_mpc_state_reference.argtypes = [C.c_void_p, C.c_longlong, _dp]
+    L.empc_carrot_mpc_set_x0.argtypes = [C.c_void_p, _dp]
+    L.empc_carrot_mpc_problem_desc.restype = C.POINTER(T.ProblemDesc)
+    L.empc_carrot_mpc_problem_desc.argtypes = [C.c_void_p]
     L.empc_set_data_dirs(YAML_DIR.encode(), ROBOT_DIR.encode())
     _lib = L
     return L
@@ -228,10 +242,24 @@ class SolverSbFDDP:
 
     # -- reference API -------------------------------------------------------------------------------------
     def solve(self, init_xs=None, init_us=None, maxiter=100, is_feasible=False, regInit=1e-9, x0s=None):
+        """solve(init_xs, init_us, maxiter, is_feasible, regInit).  Batched extensions: ``x0s`` (B x nx; the string
+        "plant" takes the device-resident plant states) and ``init_xs = init_us = "previous"``, which warm-starts every
+        trajectory from its own last solution without moving it through the host -- the MPC call
+        ``solver.solve(solver.xs, solver.us, iters)`` of examples/python/mpc.py:55."""
         B, T_, nx, nu = self.batch, self.T, self.nx, self.nu
-        if x0s is not None:
-            x0s = np.ascontiguousarray(x0s, dtype=np.float64).reshape(B, nx)
-        _check(lib().empc_solver_set_x0(self._h, _ptr(x0s)))
+        if isinstance(x0s, str):
+            if x0s != "plant":
+                raise ValueError("x0s must be an array, None or 'plant'")
+            _check(lib().empc_solver_set_x0_from_plant(self._h))
+        else:
+            if x0s is not None:
+                x0s = np.ascontiguousarray(x0s, dtype=np.float64).reshape(B, nx)
+            _check(lib().empc_solver_set_x0(self._h, _ptr(x0s)))
+        if isinstance(init_xs, str) or isinstance(init_us, str):
+            if init_xs != "previous" or init_us != "previous":
+                raise ValueError("init_xs / init_us must both be 'previous' to reuse the last solution")
+            _check(lib().empc_solver_solve(self._h, int(maxiter), int(bool(is_feasible))))
+            return True
         xs = us = None
         if init_xs is not None and len(init_xs):
             xs = np.ascontiguousarray(init_xs, dtype=np.float64)
@@ -258,6 +286,30 @@ class SolverSbFDDP:
 
     def update_problem(self):
         _check(lib().empc_solver_update_problem(self._h, C.byref(self.problem.desc)))
+
+    # -- plant of closed-loop runs (AerialSimulator, bindings/python/eagle_mpc/utils/simulator.py) ------------
+    @property
+    def plant_states(self):
+        x = np.zeros((self.batch, self.nx))
+        _check(lib().empc_plant_get_state(self._h, _ptr(x)))
+        return x
+
+    @plant_states.setter
+    def plant_states(self, value):
+        x = np.ascontiguousarray(value, dtype=np.float64)
+        assert x.shape == (self.batch, self.nx)
+        _check(lib().empc_plant_set_state(self._h, _ptr(x)))
+
+    def plant_step(self, dt_ms, controls=None, substeps=1):
+        """simulateStep(u) for every plant: RK4 over dt_ms milliseconds (x substeps).  controls=None applies each
+        trajectory's own us_squash[0] of the last solve."""
+        u = None
+        if controls is not None:
+            u = np.ascontiguousarray(controls, dtype=np.float64)
+            if u.shape == (self.nu,):
+                u = np.ascontiguousarray(np.broadcast_to(u, (self.batch, self.nu)))
+            assert u.shape == (self.batch, self.nu)
+        _check(lib().empc_plant_step(self._h, float(dt_ms) / 1000.0, _ptr(u), int(substeps)))
 
     def _get(self, name, shape):
         a = np.zeros(shape)
@@ -361,6 +413,83 @@ class SolverSbFDDP:
     def __del__(self):
         try:
             lib().empc_solver_destroy(self._h)
+        except Exception:
+            pass
+
+
+class MpcProblem:
+    """The controller's ShootingProblem (get_problem()); owned by the controller."""
+
+    def __init__(self, mpc):
+        self._mpc = mpc
+
+    @property
+    def desc(self):
+        p = lib().empc_carrot_mpc_problem_desc(self._mpc._h)
+        if not p:
+            raise EmpcError(lib().empc_last_error().decode())
+        return p.contents
+
+    @property
+    def T(self):
+        return self.desc.T
+
+    @property
+    def x0(self):
+        d = self.desc
+        return np.array([d.x0[i] for i in range(d.nx)])
+
+    @x0.setter
+    def x0(self, value):
+        v = np.ascontiguousarray(value, dtype=np.float64)
+        assert v.shape == (self._mpc.nx,)
+        _check(lib().empc_carrot_mpc_set_x0(self._mpc._h, _ptr(v)))
+
+
+class CarrotMpc:
+    """Mirror of eagle_mpc.CarrotMpc(trajectory, state_ref, dt_ref, yaml_path)
+    (bindings/python/eagle_mpc/mpc-controllers/carrot-mpc.hpp, src/mpc-controllers/carrot-mpc.cpp).
+
+    ``updateProblem(t)`` edits the cost tables on the host and, when the solver exists, uploads them;
+    ``solver`` is created on first use with ``batch`` rollouts (the batched extension: one controller, B plants).
+    """
+
+    def __init__(self, trajectory, state_ref, dt_ref, yaml_path, batch=1, device=0, params=None):
+        self.trajectory = trajectory
+        ref = np.ascontiguousarray(np.asarray(state_ref, dtype=np.float64).reshape(-1, trajectory.nx))
+        h = lib().empc_carrot_mpc_create(trajectory._h, _ptr(ref), ref.shape[0], int(dt_ref), os.fspath(yaml_path).encode())
+        if not h:
+            raise EmpcError(lib().empc_last_error().decode())
+        self._h = C.c_void_p(h)
+        v = [C.c_int() for _ in range(7)]
+        _check(lib().empc_carrot_mpc_params(self._h, *[C.byref(x) for x in v]))
+        self.knots, self.iters, self.dt, self.nx, self.ndx, self.nu, n_ts = [x.value for x in v]
+        ts = (C.c_longlong * n_ts)()
+        _check(lib().empc_carrot_mpc_t_stages(self._h, ts))
+        self.t_stages = [int(x) for x in ts]
+        self.problem = MpcProblem(self)
+        self._batch, self._device, self._params = int(batch), int(device), params
+        self._solver = None
+
+    @property
+    def solver(self):
+        if self._solver is None:
+            self._solver = SolverSbFDDP(self.problem, batch=self._batch, device=self._device, params=self._params)
+        return self._solver
+
+    def updateProblem(self, current_time):
+        _check(lib().empc_carrot_mpc_update_problem(self._h, int(current_time)))
+        if self._solver is not None:
+            self._solver.update_problem()
+
+    def computeStateReference(self, time):
+        x = np.zeros(self.nx)
+        _check(lib().empc_carrot_mpc_state_reference(self._h, int(time), _ptr(x)))
+        return x
+
+    def __del__(self):
+        try:
+            lib().empc_carrot_mpc_destroy(self._h)
         except Exception:
             pass
 

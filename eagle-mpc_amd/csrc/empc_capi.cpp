@@ -152,6 +152,76 @@ int empc_trajectory_get_param(const EmpcTrajectory* t, const char* key, char* va
   EMPC_CATCH(EMPC_ERR_INVALID)
 }
 
+// ---- Carrot MPC ------------------------------------------------------------------------------------------------
+struct EmpcCarrotMpc {
+  std::shared_ptr<CarrotMpc> m;
+};
+
+EmpcCarrotMpc* empc_carrot_mpc_create(const EmpcTrajectory* t, const double* state_ref, int n_ref, int dt_ref_ms,
+                                      const char* mpc_yaml_path) {
+  EMPC_TRY
+  if (!t || !mpc_yaml_path) throw std::invalid_argument("NULL argument");
+  if (n_ref < 0 || dt_ref_ms < 0 || (n_ref > 0 && !state_ref)) throw std::invalid_argument("bad state reference");
+  const std::size_t nx = t->t->get_nx();
+  std::vector<VectorXd> ref((std::size_t)n_ref);
+  for (int i = 0; i < n_ref; ++i) ref[(std::size_t)i].assign(state_ref + (std::size_t)i * nx, state_ref + (std::size_t)(i + 1) * nx);
+  return new EmpcCarrotMpc{std::make_shared<CarrotMpc>(t->t, ref, (std::size_t)dt_ref_ms, mpc_yaml_path)};
+  EMPC_CATCH(nullptr)
+}
+void empc_carrot_mpc_destroy(EmpcCarrotMpc* m) { delete m; }
+int empc_carrot_mpc_params(const EmpcCarrotMpc* m, int* knots, int* iters, int* dt_ms, int* nx, int* ndx, int* nu,
+                           int* n_t_stages) {
+  EMPC_TRY
+  if (!m) throw std::invalid_argument("controller is NULL");
+  if (knots) *knots = (int)m->m->get_knots();
+  if (iters) *iters = (int)m->m->get_iters();
+  if (dt_ms) *dt_ms = (int)m->m->get_dt();
+  if (nx) *nx = (int)m->m->get_nx();
+  if (ndx) *ndx = (int)m->m->get_ndx();
+  if (nu) *nu = (int)m->m->get_nu();
+  if (n_t_stages) *n_t_stages = (int)m->m->get_t_stages().size();
+  return EMPC_OK;
+  EMPC_CATCH(EMPC_ERR_INVALID)
+}
+int empc_carrot_mpc_t_stages(const EmpcCarrotMpc* m, long long* t_stages) {
+  EMPC_TRY
+  if (!m || !t_stages) throw std::invalid_argument("NULL argument");
+  const auto& ts = m->m->get_t_stages();
+  for (std::size_t i = 0; i < ts.size(); ++i) t_stages[i] = (long long)ts[i];
+  return EMPC_OK;
+  EMPC_CATCH(EMPC_ERR_INVALID)
+}
+int empc_carrot_mpc_update_problem(EmpcCarrotMpc* m, long long current_time_ms) {
+  EMPC_TRY
+  if (!m) throw std::invalid_argument("controller is NULL");
+  if (current_time_ms < 0) throw std::invalid_argument("current_time must be >= 0");
+  m->m->updateProblem((std::size_t)current_time_ms);
+  return EMPC_OK;
+  EMPC_CATCH(EMPC_ERR_INVALID)
+}
+int empc_carrot_mpc_state_reference(EmpcCarrotMpc* m, long long time_ms, double* xref) {
+  EMPC_TRY
+  if (!m || !xref) throw std::invalid_argument("NULL argument");
+  if (time_ms < 0) throw std::invalid_argument("time must be >= 0");
+  const VectorXd& r = m->m->computeStateReference((std::size_t)time_ms);
+  std::memcpy(xref, r.data(), sizeof(double) * r.size());
+  return EMPC_OK;
+  EMPC_CATCH(EMPC_ERR_INVALID)
+}
+int empc_carrot_mpc_set_x0(EmpcCarrotMpc* m, const double* x0) {
+  EMPC_TRY
+  if (!m || !x0) throw std::invalid_argument("NULL argument");
+  m->m->get_problem()->set_x0(VectorXd(x0, x0 + m->m->get_nx()));
+  return EMPC_OK;
+  EMPC_CATCH(EMPC_ERR_INVALID)
+}
+const EmpcProblemDesc* empc_carrot_mpc_problem_desc(EmpcCarrotMpc* m) {
+  EMPC_TRY
+  if (!m) throw std::invalid_argument("controller is NULL");
+  return &m->m->get_problem()->desc();
+  EMPC_CATCH(nullptr)
+}
+
 void empc_solver_params_default(EmpcSolverParams* p) {
   if (!p) return;
   std::memset(p, 0, sizeof(*p));

@@ -731,4 +731,70 @@ EMPC_HD void node_nominal(const EMPC_K DevProblem& P, const EMPC_K EmpcCostSet& 
   cost_out = cscale * ell;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Plant model of the closed-loop MPC runs (reference: bindings/python/eagle_mpc/utils/simulator.py:8-29):
+// DifferentialActionModelFreeFwdDynamics with the *unsquashed* ActuationModelMultiCopterBase, no costs, integrated
+// with crocoddyl::IntegratedActionModelRK4.  `u` are rotor thrusts + arm torques.
+// ---------------------------------------------------------------------------------------------------------
+template <class DM>
+EMPC_HD void free_fwd_acc(const EMPC_K DevProblem& P, const double* x, const double* u, double* a) {
+  constexpr int NB = DM::NB, NV = DM::NV, NQ = DM::NQ, NROT = DM::NROT;
+  const EMPC_K EmpcModelDesc& m = P.model;
+  double tau[NV];
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    double s = 0;
+#pragma unroll
+    for (int c = 0; c < NROT; ++c) s += P.tau_f[r * NROT + c] * u[c];
+    tau[r] = s;
+  }
+#pragma unroll
+  for (int i = 6; i < NV; ++i) tau[i] = u[NROT + i - 6];
+  const double* q = x;
+  const double* v = x + NQ;
+  double R0[9], cs[NB], sn[NB];
+  quat_to_R(q + 3, R0);
+#pragma unroll
+  for (int b = 1; b < NB; ++b) sincos(q[7 + b - 1], &sn[b - 1], &cs[b - 1]);
+  int capf[NCAP] = {0, 0};
+  FrameCap<double> caps[NCAP];
+  double zero[NV], h[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) zero[i] = 0.0;
+  rnea_chain<NB, double>(m, R0, q, cs, sn, v, zero, true, -1, nullptr, h, 0, capf, caps);
+  double L[DM::NTRI];
+  crba_chain<NB>(m, cs, sn, L);
+  chol_packed<NV>(L);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) a[i] = tau[i] - h[i];
+  chol_solve_packed<NV>(L, a);
+}
+
+template <class DM>
+EMPC_HD void plant_rk4_step(const EMPC_K DevProblem& P, const double* x, const double* u, double dt, double* xnext) {
+  constexpr int NV = DM::NV, NQ = DM::NQ, NX = DM::NX, NDX = DM::NDX;
+  const double rk4_c[4] = {0.0, 0.5, 0.5, 1.0};
+  double ksum[NDX], ki[NDX], y[NX], dxi[NDX];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) y[i] = x[i];
+#pragma unroll
+  for (int i = 0; i < NDX; ++i) ksum[i] = 0.0;
+  for (int stage = 0; stage < 4; ++stage) {
+    if (stage > 0) {
+#pragma unroll
+      for (int i = 0; i < NDX; ++i) dxi[i] = rk4_c[stage] * ki[i] * dt;
+      state_integrate<DM>(x, dxi, y, (double*)nullptr);
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) ki[i] = y[NQ + i];
+    free_fwd_acc<DM>(P, y, u, ki + NV);
+    const double w = (stage == 0 || stage == 3) ? 1.0 : 2.0;
+#pragma unroll
+    for (int i = 0; i < NDX; ++i) ksum[i] += w * ki[i];
+  }
+#pragma unroll
+  for (int i = 0; i < NDX; ++i) dxi[i] = ksum[i] * dt / 6.0;
+  state_integrate<DM>(x, dxi, xnext, (double*)nullptr);
+}
+
 }  // namespace empc

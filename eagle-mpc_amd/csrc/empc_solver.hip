@@ -125,6 +125,36 @@ __global__ void k_squash_out(DevBuffers D, double* out) {
   out[idx] = u;
 }
 
+// Plant of the closed-loop MPC runs: x[b] <- RK4(x[b], u[b], dt) repeated nsub times, one lane per plant.
+// u == nullptr takes the squashed first control of the last solve (control = solver.us_squash[0], examples/python/mpc.py:60).
+template <class DM>
+__global__ void __launch_bounds__(64) k_plant_rk4(DevBuffers D, double* x, const double* u, double dt, int nsub) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= D.B) return;
+  const EMPC_K DevProblem& P = EMPC_KREF(DevProblem, D.P);
+  double uu[DM::NU], xa[DM::NX], xb[DM::NX];
+#pragma unroll
+  for (int i = 0; i < DM::NU; ++i) {
+    if (u) {
+      uu[i] = u[(size_t)b * DM::NU + i];
+    } else {
+      const double s = D.us_last[(size_t)b * D.T * DM::NU + i];
+      double du;
+      uu[i] = s;
+      if (P.use_squash) squash1(s, P.u_lb[i], P.u_ub[i], D.st[b].smooth, P.prm.smoothsat_power, uu[i], du);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < DM::NX; ++i) xa[i] = x[(size_t)b * DM::NX + i];
+  for (int k = 0; k < nsub; ++k) {
+    plant_rk4_step<DM>(P, xa, uu, dt, xb);
+#pragma unroll
+    for (int i = 0; i < DM::NX; ++i) xa[i] = xb[i];
+  }
+#pragma unroll
+  for (int i = 0; i < DM::NX; ++i) x[(size_t)b * DM::NX + i] = xa[i];
+}
+
 // --------------------------------------------------------------------------------------------------------------------
 // solver object
 // --------------------------------------------------------------------------------------------------------------------
@@ -135,6 +165,7 @@ struct KernelTable {
   void (*rollout)(DevBuffers, hipStream_t);
   void (*select)(DevBuffers, hipStream_t);
   void (*squash_out)(DevBuffers, double*, hipStream_t);
+  void (*plant)(DevBuffers, double*, const double*, double, int, hipStream_t);
   int nx, ndx, nu, nv, nacc, rec;
   int off[9], ld[5];
 };
@@ -170,6 +201,10 @@ static void launch_squash_out(DevBuffers D, double* out, hipStream_t s) {
   const int n = D.B * D.T * DM::NU;
   hipLaunchKernelGGL(k_squash_out<DM>, dim3((n + 255) / 256), dim3(256), 0, s, D, out);
 }
+template <class DM>
+static void launch_plant(DevBuffers D, double* x, const double* u, double dt, int nsub, hipStream_t s) {
+  hipLaunchKernelGGL(k_plant_rk4<DM>, dim3((D.B + 63) / 64), dim3(64), 0, s, D, x, u, dt, nsub);
+}
 template <class DM, bool CT>
 static KernelTable make_table() {
   KernelTable k;
@@ -179,6 +214,7 @@ static KernelTable make_table() {
   k.rollout = launch_rollout<DM, CT>;
   k.select = launch_select<DM>;
   k.squash_out = launch_squash_out<DM>;
+  k.plant = launch_plant<DM>;
   k.nx = DM::NX;
   k.ndx = DM::NDX;
   k.nu = DM::NU;
@@ -215,6 +251,8 @@ struct EmpcSolver {
   EmpcCostSet* dsets = nullptr;
   int* dknot = nullptr;
   double* dscratch = nullptr;  // output staging (squashed controls)
+  double* dplant_x = nullptr;  // [B][NX] plant states of closed-loop runs (empc_plant_*)
+  double* dplant_u = nullptr;  // [B][NU] staging of caller-supplied plant controls
   int* h_active = nullptr;     // pinned
   std::vector<TrajState> h_st;
   bool have_state = false;
@@ -365,6 +403,8 @@ EmpcSolver* empc_solver_create(const EmpcProblemDesc* problem, const EmpcSolverP
   D.NA = s->NA;
   D.gaptol = std::max(prm.th_gaptol, 1e-13);
   s->dscratch = s->dalloc<double>(B * T * k.nu);
+  s->dplant_x = s->dalloc<double>(B * k.nx);
+  s->dplant_u = s->dalloc<double>(B * k.nu);
   HIP_CHECK(hipMemsetAsync(D.tape, 0, sizeof(double) * B * (T + 1) * k.rec, s->stream));
   HIP_CHECK(hipMemsetAsync(D.us_last, 0, sizeof(double) * B * T * k.nu, s->stream));
   HIP_CHECK(hipMemsetAsync(D.acc, 0, sizeof(double) * B * (T + 1) * k.nacc, s->stream));
@@ -440,6 +480,52 @@ int empc_solver_set_x0(EmpcSolver* s, const double* x0s) {
     for (int b = 0; b < s->B; ++b) std::memcpy(&tmp[b * nx], s->H.x0.data(), sizeof(double) * nx);
     HIP_CHECK(hipMemcpyAsync(s->D.x0, tmp.data(), sizeof(double) * tmp.size(), hipMemcpyHostToDevice, s->stream));
   }
+  HIP_CHECK(hipStreamSynchronize(s->stream));
+  return EMPC_OK;
+  EMPC_CATCH(RET_INT)
+}
+
+// ---- plant of closed-loop MPC runs (bindings/python/eagle_mpc/utils/simulator.py) ------------------------------
+int empc_plant_set_state(EmpcSolver* s, const double* x) {
+  EMPC_TRY
+  if (!s || !x) throw std::invalid_argument("NULL argument");
+  s->use();
+  HIP_CHECK(hipMemcpyAsync(s->dplant_x, x, sizeof(double) * s->B * s->kt.nx, hipMemcpyHostToDevice, s->stream));
+  HIP_CHECK(hipStreamSynchronize(s->stream));
+  return EMPC_OK;
+  EMPC_CATCH(RET_INT)
+}
+int empc_plant_get_state(EmpcSolver* s, double* x) {
+  EMPC_TRY
+  if (!s || !x) throw std::invalid_argument("NULL argument");
+  s->use();
+  HIP_CHECK(hipMemcpyAsync(x, s->dplant_x, sizeof(double) * s->B * s->kt.nx, hipMemcpyDeviceToHost, s->stream));
+  HIP_CHECK(hipStreamSynchronize(s->stream));
+  return EMPC_OK;
+  EMPC_CATCH(RET_INT)
+}
+int empc_plant_step(EmpcSolver* s, double dt_s, const double* u, int n_substeps) {
+  EMPC_TRY
+  if (!s) throw std::invalid_argument("solver is NULL");
+  if (!(dt_s > 0) || n_substeps < 1) throw std::invalid_argument("plant step: dt must be positive and n_substeps >= 1");
+  if (!u && !s->have_state) throw std::invalid_argument("plant step: no solve has run yet, pass the controls explicitly");
+  s->use();
+  const double* du = nullptr;
+  if (u) {
+    HIP_CHECK(hipMemcpyAsync(s->dplant_u, u, sizeof(double) * s->B * s->kt.nu, hipMemcpyHostToDevice, s->stream));
+    du = s->dplant_u;
+  }
+  s->kt.plant(s->D, s->dplant_x, du, dt_s, n_substeps, s->stream);
+  HIP_CHECK(hipStreamSynchronize(s->stream));
+  HIP_CHECK(hipGetLastError());
+  return EMPC_OK;
+  EMPC_CATCH(RET_INT)
+}
+int empc_solver_set_x0_from_plant(EmpcSolver* s) {
+  EMPC_TRY
+  if (!s) throw std::invalid_argument("solver is NULL");
+  s->use();
+  HIP_CHECK(hipMemcpyAsync(s->D.x0, s->dplant_x, sizeof(double) * s->B * s->kt.nx, hipMemcpyDeviceToDevice, s->stream));
   HIP_CHECK(hipStreamSynchronize(s->stream));
   return EMPC_OK;
   EMPC_CATCH(RET_INT)

@@ -300,4 +300,89 @@ class SolverSbFDDP {
   std::vector<int> iter_b_, status_b_;
 };
 
+// ------------------------------------------------------------------------------------------------------------
+// MPC controllers (include/eagle_mpc/mpc-base.hpp:34-119, include/eagle_mpc/mpc-controllers/carrot-mpc.hpp:23-88)
+// ------------------------------------------------------------------------------------------------------------
+enum class SolverTypes { SolverSbFDDP, SolverBoxFDDP, SolverBoxDDP, NbSolverTypes };  // mpc-base.hpp:34-39
+
+struct MpcParams {  // mpc-base.hpp:49-57
+  IntegratedActionModelTypes integrator_type = IntegratedActionModelTypes::IntegratedActionModelEuler;
+  std::size_t knots = 0, iters = 0, dt = 0;
+  SolverTypes solver_type = SolverTypes::SolverSbFDDP;
+  bool callback = false;
+};
+
+// MpcAbstract: reads the `mpc_controller:` YAML, builds robot / platform objects, owns problem and solver.  The
+// reference's per-knot dif/int action models are the rows of the problem's cost-set table here (one private
+// EmpcCostSet per knot); get_problem()->get_sets()[i] is what dif_models_[i]->get_costs() is to the reference.
+class MpcAbstract {
+ public:
+  explicit MpcAbstract(const std::string& yaml_path);
+  virtual ~MpcAbstract() {}
+  virtual void createProblem() = 0;
+  virtual void updateProblem(const std::size_t& current_time) = 0;
+
+  const std::shared_ptr<RobotModel>& get_robot_model() const { return robot_model_; }
+  const std::string& get_robot_model_path() const { return robot_model_path_; }
+  const std::shared_ptr<MultiCopterBaseParams>& get_platform_params() const { return platform_params_; }
+  const std::shared_ptr<ParamsServer>& get_params_server() const { return params_server_; }
+  const std::shared_ptr<ShootingProblem>& get_problem() const { return problem_; }
+  // created lazily on the first call (needs a HIP device); batch_size rollouts share the problem
+  const std::shared_ptr<SolverSbFDDP>& get_solver(std::size_t batch_size = 1, int device = 0);
+  const std::size_t& get_dt() const { return params_.dt; }
+  const std::size_t& get_knots() const { return params_.knots; }
+  const std::size_t& get_iters() const { return params_.iters; }
+  const SolverTypes& get_solver_type() const { return params_.solver_type; }
+  std::size_t get_nx() const { return (std::size_t)(robot_model_->nq() + robot_model_->nv()); }
+  std::size_t get_ndx() const { return (std::size_t)(2 * robot_model_->nv()); }
+  std::size_t get_nu() const { return platform_params_->n_rotors_ + (std::size_t)(robot_model_->nv() - 6); }
+  VectorXd zero_state() const;
+
+ protected:
+  void initializeRobotObjects();  // src/mpc-base.cpp:19-38
+  void loadParams();              // src/mpc-base.cpp:40-60
+  std::shared_ptr<ParamsServer> params_server_;
+  std::shared_ptr<RobotModel> robot_model_;
+  std::string robot_model_path_;
+  std::shared_ptr<MultiCopterBaseParams> platform_params_;
+  MpcParams params_;
+  std::shared_ptr<ShootingProblem> problem_;
+  std::shared_ptr<SolverSbFDDP> solver_;
+};
+
+class CarrotMpc : public MpcAbstract {
+ public:
+  // reference ctor: src/mpc-controllers/carrot-mpc.cpp:15-50
+  CarrotMpc(const std::shared_ptr<Trajectory>& trajectory, const std::vector<VectorXd>& state_ref, std::size_t dt_ref,
+            const std::string& yaml_path);
+  void createProblem() override;                                 // :178-248
+  void updateProblem(const std::size_t& current_time) override;  // :298-313
+
+  const std::shared_ptr<Trajectory>& get_trajectory() const { return trajectory_; }
+  const std::vector<std::size_t>& get_t_stages() const { return t_stages_; }
+  const std::vector<std::size_t>& get_t_ref() const { return t_ref_; }
+  const std::vector<VectorXd>& get_state_ref() const { return state_ref_; }
+  const VectorXd& computeStateReference(const std::size_t& time);  // :384-403
+
+ private:
+  void loadCostParams();                                                      // :53-176
+  EmpcCostSet createCosts() const;                                            // :250-296
+  void computeActiveStage(const std::size_t& current_time);                   // :315-319
+  void updateContactCosts(const std::size_t& idx);                            // :329 (empty in the reference)
+  void updateFreeCosts(const std::size_t& idx, const std::size_t& current_time);  // :331-362
+
+  std::shared_ptr<Trajectory> trajectory_;
+  std::vector<VectorXd> state_ref_;
+  std::vector<std::size_t> t_ref_, t_stages_;
+  double carrot_weight_ = 10, carrot_tail_weight_ = 5, control_reg_weight_ = 1e-2, state_reg_weight_ = 1e-3,
+         state_limits_weight_ = 100;
+  VectorXd carrot_tail_act_weights_, control_reg_act_weights_, state_ref_act_weights_, state_limits_act_weights_,
+      state_limits_l_bound_, state_limits_u_bound_;
+  struct UpdateVars {
+    std::size_t idx_stage = 0, idx_last_stage = 0, node_time = 0, idx_state = 0;
+    double alpha = 0;
+    VectorXd state_ref;
+  } update_vars_;
+};
+
 }  // namespace eagle_mpc

@@ -21,6 +21,9 @@
  *   empc_solver_set_convergence_init  SolverSbFDDP::set_convergence_init   src/sbfddp.cpp:491
  *   empc_solver_update_problem  what MpcAbstract::updateProblem does by mutating shared cost models in place
  *                             (src/mpc-controllers/carrot-mpc.cpp:298-359)
+ *   empc_carrot_mpc_*         CarrotMpc ctor/createProblem/updateProblem/computeStateReference
+ *                             (src/mpc-controllers/carrot-mpc.cpp:15-50,178-248,298-403, src/mpc-base.cpp:5-60)
+ *   empc_plant_*              AerialSimulator.simulateStep (bindings/python/eagle_mpc/utils/simulator.py:24-29)
  *   empc_linearize_batch / empc_backward_batch / empc_rollout_batch
  *                             crocoddyl SolverDDP::calcDiff / backwardPass / SolverFDDP::forwardPass as called at
  *                             src/sbfddp.cpp:244,264 -- exposed per phase for parity tests and roofline measurements
@@ -130,6 +133,37 @@ typedef struct EmpcTapeLayout {
   int ld_fx, ld_fu, ld_lxx, ld_lxu, ld_luu; /* leading dimensions (row strides) of the matrix blocks */
 } EmpcTapeLayout;
 int empc_tape_layout(const EmpcSolver* s, EmpcTapeLayout* layout);
+
+/* ---- plant of closed-loop MPC runs --------------------------------------------------------------------------
+ * Reference: AerialSimulator (bindings/python/eagle_mpc/utils/simulator.py:8-29): FreeFwdDynamics with the unsquashed
+ * multicopter actuation, IntegratedActionModelRK4, no costs.  One plant per trajectory of the batch, states resident on
+ * the device next to the solver so that a closed-loop step (plant -> x0 -> solve) moves no state through the host. */
+int empc_plant_set_state(EmpcSolver* s, const double* x /* batch x nx */);
+int empc_plant_get_state(EmpcSolver* s, double* x /* batch x nx */);
+/* x <- RK4(x, u, dt_s), n_substeps times.  u: batch x nu rotor thrusts + arm torques, or NULL = the squashed first
+ * control of the last solve (control = solver.us_squash[0], examples/python/mpc.py:60) */
+int empc_plant_step(EmpcSolver* s, double dt_s, const double* u, int n_substeps);
+/* problem.x0 = simulator.states[-1] for every trajectory (examples/python/mpc.py:50), device to device */
+int empc_solver_set_x0_from_plant(EmpcSolver* s);
+
+/* ---- Carrot MPC controller (include/eagle_mpc/mpc-controllers/carrot-mpc.hpp:23-88) ----------------------------
+ * Host-side logic only: builds the receding-horizon problem (one private cost set per knot) and re-targets its
+ * carrot references for a given time; pass empc_carrot_mpc_problem_desc() to empc_solver_create / _update_problem. */
+typedef struct EmpcCarrotMpc EmpcCarrotMpc;
+/* CarrotMpc(trajectory, state_ref, dt_ref, yaml_path)   src/mpc-controllers/carrot-mpc.cpp:15-50 */
+EmpcCarrotMpc* empc_carrot_mpc_create(const EmpcTrajectory* t, const double* state_ref /* n_ref x nx */, int n_ref,
+                                      int dt_ref_ms, const char* mpc_yaml_path);
+void empc_carrot_mpc_destroy(EmpcCarrotMpc* m);
+int empc_carrot_mpc_params(const EmpcCarrotMpc* m, int* knots, int* iters, int* dt_ms, int* nx, int* ndx, int* nu,
+                           int* n_t_stages);
+int empc_carrot_mpc_t_stages(const EmpcCarrotMpc* m, long long* t_stages /* n_t_stages */);
+/* updateProblem(current_time)   src/mpc-controllers/carrot-mpc.cpp:298-313 */
+int empc_carrot_mpc_update_problem(EmpcCarrotMpc* m, long long current_time_ms);
+/* computeStateReference(time)   src/mpc-controllers/carrot-mpc.cpp:384-403 */
+int empc_carrot_mpc_state_reference(EmpcCarrotMpc* m, long long time_ms, double* xref /* nx */);
+/* problem.x0 = x0 */
+int empc_carrot_mpc_set_x0(EmpcCarrotMpc* m, const double* x0 /* nx */);
+const EmpcProblemDesc* empc_carrot_mpc_problem_desc(EmpcCarrotMpc* m);
 
 #ifdef __cplusplus
 }

@@ -285,4 +285,56 @@ double oracle_energy(const EmpcModelDesc* m, const double* q, const double* v) {
   }
   return E;
 }
+// Plant of the closed-loop MPC runs (reference: bindings/python/eagle_mpc/utils/simulator.py:8-29):
+// FreeFwdDynamics with the unsquashed multicopter actuation, crocoddyl::IntegratedActionModelRK4:
+//   k_i = [v_i; a(y_i, u)], y_i = x (+) c_i dt k_{i-1}, c = {0, 1/2, 1/2, 1}, xnext = x (+) dt/6 (k0 + 2 k1 + 2 k2 + k3)
+static void plant_acc(const Problem& P, const double* x, const double* u, double* a) {
+  const EmpcModelDesc& m = P.d.model;
+  const int nv = m.nv, nq = m.nq, nrot = P.d.n_rotors;
+  double tau[NV], h[NV], z[NV] = {0}, M[NV * NV];
+  for (int r = 0; r < 6; ++r) {
+    double s = 0;
+    for (int c = 0; c < nrot; ++c) s += P.d.tau_f[r * nrot + c] * u[c];
+    tau[r] = s;
+  }
+  for (int i = 6; i < nv; ++i) tau[i] = u[nrot + i - 6];
+  oracle_rnea(&m, x, x + nq, z, h);
+  oracle_crba(&m, x, M);
+  // dense Cholesky solve M a = tau - h
+  double L[NV * NV] = {0}, y[NV];
+  for (int i = 0; i < nv; ++i)
+    for (int j = 0; j <= i; ++j) {
+      double s = M[i * nv + j];
+      for (int k = 0; k < j; ++k) s -= L[i * nv + k] * L[j * nv + k];
+      L[i * nv + j] = (i == j) ? std::sqrt(s) : s / L[j * nv + j];
+    }
+  for (int i = 0; i < nv; ++i) {
+    double s = tau[i] - h[i];
+    for (int k = 0; k < i; ++k) s -= L[i * nv + k] * y[k];
+    y[i] = s / L[i * nv + i];
+  }
+  for (int i = nv - 1; i >= 0; --i) {
+    double s = y[i];
+    for (int k = i + 1; k < nv; ++k) s -= L[k * nv + i] * a[k];
+    a[i] = s / L[i * nv + i];
+  }
+}
+void oracle_plant_rk4(const EmpcProblemDesc* d, const double* x, const double* u, double dt, double* xnext) {
+  Problem P;
+  P.d = *d;
+  const int nv = d->model.nv, nq = d->model.nq, ndx = 2 * nv, nx = nq + nv;
+  const double c[4] = {0.0, 0.5, 0.5, 1.0};
+  double k[4][2 * NV], y[EMPC_MAX_NX], dx[2 * NV];
+  for (int i = 0; i < nx; ++i) y[i] = x[i];
+  for (int st = 0; st < 4; ++st) {
+    if (st > 0) {
+      for (int i = 0; i < ndx; ++i) dx[i] = c[st] * k[st - 1][i] * dt;
+      state_integrate(P, x, dx, y);
+    }
+    for (int i = 0; i < nv; ++i) k[st][i] = y[nq + i];
+    plant_acc(P, y, u, k[st] + nv);
+  }
+  for (int i = 0; i < ndx; ++i) dx[i] = (k[0][i] + 2.0 * k[1][i] + 2.0 * k[2][i] + k[3][i]) * dt / 6.0;
+  state_integrate(P, x, dx, xnext);
+}
 }

@@ -54,6 +54,7 @@ def orc():
         L.oracle_state_diff.argtypes = [C.c_void_p, _dp, _dp, _dp]
         L.oracle_rnea.argtypes = [C.POINTER(T.ModelDesc), _dp, _dp, _dp, _dp]
         L.oracle_crba.argtypes = [C.POINTER(T.ModelDesc), _dp, _dp]
+        L.oracle_plant_rk4.argtypes = [C.POINTER(T.ProblemDesc), _dp, _dp, C.c_double, _dp]
         L.oracle_energy.restype = C.c_double
         L.oracle_energy.argtypes = [C.POINTER(T.ModelDesc), _dp, _dp]
         for f in ("exp6", "log6"):
@@ -194,3 +195,18 @@ def solve_batch(desc, x0s, maxiter=100, nthreads=1, params=None, want_traj=True)
     secs = orc().oracle_solve_batch(C.byref(desc), C.byref(prm), B, P(x0s), int(maxiter), int(nthreads), P(xs), P(us), P(usq),
                                     P(cost), iters.ctypes.data_as(_ip), status.ctypes.data_as(_ip))
     return dict(xs=xs, us=us, us_squash=usq, cost=cost, iter=iters, status=status, seconds=secs)
+
+
+def plant_rk4(desc, x, u, dt_s, substeps=1):
+    """AerialSimulator.simulateStep restated on the CPU (oracle_plant_rk4): x, u are single vectors or batches."""
+    x = np.ascontiguousarray(np.atleast_2d(x), dtype=np.float64)
+    u = np.ascontiguousarray(np.broadcast_to(np.atleast_2d(u), (x.shape[0], desc.nu)), dtype=np.float64)
+    out = np.zeros_like(x)
+    for b in range(x.shape[0]):
+        cur = x[b].copy()
+        nxt = np.zeros_like(cur)
+        for _ in range(substeps):
+            orc().oracle_plant_rk4(C.byref(desc), P(cur), P(np.ascontiguousarray(u[b])), float(dt_s), P(nxt))
+            cur, nxt = nxt.copy(), cur
+        out[b] = cur
+    return out
