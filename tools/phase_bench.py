@@ -2,7 +2,7 @@
 """Time the three hot kernels in isolation (phase-level C ABI) on a full batch: ms per launch from HIP events."""
 import argparse, json, sys, os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import empc_loader
 empc = empc_loader.load()
 from bench import CONFIGS, algorithmic_words

@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 output directories into the small files kept under profiles/.
+
+  python tools/profile_summarize.py stats   <rocprof dir> <out.csv>          # --kernel-trace --stats run
+  python tools/profile_summarize.py traffic <fetch dir> <write dir> <tag>     # two --pmc passes (FETCH_SIZE / WRITE_SIZE)
+
+`traffic` writes profiles/traffic_<kernel>.json per hot kernel: HBM bytes per launch as /opt/skills/guides/
+MI355X_MICROARCH.md prescribes -- FETCH_SIZE and WRITE_SIZE are reported in KiB-sized units by rocprofv3 (x1024) and, on
+gfx950, FETCH_SIZE tallies 128-B requests at 64 B, so reads are doubled; the raw values are kept next to the corrected one.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+KERNELS = ("k_linearize", "k_backward", "k_rollout", "k_select", "k_calc", "k_squash_out", "k_plant_rk4")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(name):
+    for k in KERNELS:
+        if k in name:
+            return k
+    return name[:60]
+
+
+def stats(src, out):
+    files = glob.glob(os.path.join(src, "**", "*kernel_stats.csv"), recursive=True)
+    if not files:
+        raise SystemExit("no *kernel_stats.csv under " + src)
+    rows = list(csv.DictReader(open(files[0])))
+    with open(out, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "calls", "total_ms", "avg_ms", "min_ms", "max_ms", "percent", "full_name"])
+        for r in rows:
+            w.writerow([short(r["Name"]), r["Calls"], "%.4f" % (float(r["TotalDurationNs"]) / 1e6),
+                        "%.4f" % (float(r["AverageNs"]) / 1e6), "%.4f" % (float(r["MinNs"]) / 1e6),
+                        "%.4f" % (float(r["MaxNs"]) / 1e6), r["Percentage"], r["Name"][:160]])
+    print(open(out).read())
+
+
+def counters(src, counter):
+    files = glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive=True)
+    if not files:
+        raise SystemExit("no *counter_collection.csv under " + src)
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(files[0])):
+        if r["Counter_Name"] == counter:
+            agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    return agg
+
+
+def traffic(fetch_dir, write_dir, tag):
+    fe = counters(fetch_dir, "FETCH_SIZE")
+    wr = counters(write_dir, "WRITE_SIZE")
+    for k in ("k_linearize", "k_backward", "k_rollout"):
+        if k not in fe or k not in wr:
+            continue
+        # the solve loop launches over a shrinking active set; the first launches (whole batch active) are the ones the
+        # bench's per-launch algorithmic bytes describe on average, so report the mean over all launches of the run
+        f_raw = sum(fe[k]) / len(fe[k]) * 1024.0
+        w_raw = sum(wr[k]) / len(wr[k]) * 1024.0
+        out = {"kernel": k, "tag": tag, "launches": len(fe[k]),
+               "fetch_bytes_raw_per_launch": f_raw, "write_bytes_raw_per_launch": w_raw,
+               "hbm_bytes_per_launch": 2.0 * f_raw + w_raw,
+               "correction": "FETCH_SIZE x1024 x2 (gfx950 tallies 128-B read requests at 64 B), WRITE_SIZE x1024; 8-B/lane "
+                             "accesses are outside the guide's calibrated 16-B/lane pattern, so the absolute value is "
+                             "indicative, ratios between builds are exact"}
+        name = k.replace("k_", "")
+        with open(os.path.join(ROOT, "profiles", "traffic_%s.json" % name), "w") as f:
+            json.dump(out, f, indent=1)
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    if len(sys.argv) >= 4 and sys.argv[1] == "stats":
+        stats(sys.argv[2], sys.argv[3])
+    elif len(sys.argv) >= 5 and sys.argv[1] == "traffic":
+        traffic(sys.argv[2], sys.argv[3], sys.argv[4])
+    else:
+        raise SystemExit(__doc__)
