@@ -61,6 +61,116 @@ EMPC_HD D1& operator-=(D1& a, const D1& b) {
 EMPC_HD double val(double a) { return a; }
 EMPC_HD double val(const D1& a) { return a.v; }
 
+// ---- scalar primitives of the hot loops --------------------------------------------------------------------
+// The per-knot chain of the rollout / linearize kernels is made of scalar SE(3) exp/log work, so the cost of one
+// division, square root or sine matters.  These forms are a few ulp from the correctly rounded results (the parity
+// tolerance of the solver is 1e-4 on xs/us; kernel-vs-oracle tests hold 1e-11) and cost a fraction of the IEEE
+// expansions: rcp/rsq hardware seeds + Newton steps on the device, fdlibm polynomial kernels without the
+// Payne-Hanek path for sin/cos (arguments here are joint angles and rotation half-angles, |x| << 2^20 pi/2).
+EMPC_HD double frcp(double x) {
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+  double r = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-x, r, 1.0);
+  return fma(r, e, r);
+#else
+  return 1.0 / x;
+#endif
+}
+EMPC_HD double fdiv(double a, double b) {
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+  const double r = frcp(b);
+  const double q = a * r;
+  return fma(fma(-b, q, a), r, q);
+#else
+  return a / b;
+#endif
+}
+// 1 / sqrt(x), x > 0
+EMPC_HD double frsqrt(double x) {
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+  double r = __builtin_amdgcn_rsq(x);
+  const double h = 0.5 * x;
+  r = r * fma(-h * r, r, 1.5);
+  const double e = fma(-x * r, r, 1.0);  // 1 - x r^2
+  return fma(0.5 * r, e, r);
+#else
+  return 1.0 / sqrt(x);
+#endif
+}
+// sqrt(x), x >= 0
+EMPC_HD double fsqrt(double x) {
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+  if (!(x > 1e-300)) return (x == x && x >= 0.0) ? 0.0 : x * __builtin_nan("");
+  const double r = frsqrt(x);
+  const double s = x * r;
+  return fma(fma(-s, s, x), 0.5 * r, s);
+#else
+  return sqrt(x);
+#endif
+}
+// sin and cos of x: Cody-Waite reduction by pi/2 (three 33-bit pieces, exact with fma for |k| < 2^20) and the
+// fdlibm kernels on [-pi/4, pi/4]
+EMPC_HD void fsincos(double x, double* sn, double* cs) {
+  const double kf = rint(x * 6.36619772367581382433e-01);
+  double r = fma(-kf, 1.57079632673412561417e+00, x);
+  r = fma(-kf, 6.07710050630396597660e-11, r);
+  r = fma(-kf, 2.02226624871116645580e-21, r);
+  r = fma(-kf, 8.47842766036889956997e-32, r);
+  const double z = r * r;
+  const double ps = -1.66666666666666324348e-01 +
+                    z * (8.33333333332248946124e-03 +
+                         z * (-1.98412698298579493134e-04 +
+                              z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10))));
+  const double s = fma(r * z, ps, r);
+  const double pc = 4.16666666666666019037e-02 +
+                    z * (-1.38888888888741095749e-03 +
+                         z * (2.48015872894767294178e-05 +
+                              z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))));
+  const double hz = 0.5 * z;
+  const double w = 1.0 - hz;
+  const double c = w + (((1.0 - w) - hz) + z * z * pc);
+  const int q = (int)((long long)kf & 3);
+  const double s1 = (q & 1) ? c : s, c1 = (q & 1) ? s : c;
+  *sn = (q & 2) ? -s1 : s1;
+  *cs = ((q + 1) & 2) ? -c1 : c1;
+}
+// atan2(y, x) for y >= 0, x >= 0 (first quadrant; the only use is the half-angle of a unit quaternion):
+// fdlibm atan kernel on the ratio min/max, with the interval transforms folded into one division
+EMPC_HD double fatan2_pos(double y, double x) {
+  const bool sw = y > x;
+  const double mn = sw ? x : y, mx = sw ? y : x;
+  double num, den, hi, lo;
+  if (16.0 * mn < 7.0 * mx) {  // z < 7/16
+    num = mn;
+    den = mx;
+    hi = 0.0;
+    lo = 0.0;
+  } else if (16.0 * mn < 11.0 * mx) {  // atan(z) = atan(1/2) + atan((2z - 1) / (2 + z))
+    num = 2.0 * mn - mx;
+    den = 2.0 * mx + mn;
+    hi = 4.63647609000806093515e-01;
+    lo = 2.26987774529616870924e-17;
+  } else {  // atan(z) = pi/4 + atan((z - 1) / (z + 1))
+    num = mn - mx;
+    den = mx + mn;
+    hi = 7.85398163397448278999e-01;
+    lo = 3.06161699786838301793e-17;
+  }
+  const double z = (den > 0.0) ? fdiv(num, den) : 0.0;
+  const double z2 = z * z, w = z2 * z2;
+  const double s1 = z2 * (3.33333333333329318027e-01 +
+                          w * (1.42857142725034663711e-01 +
+                               w * (9.09088713343650656196e-02 +
+                                    w * (6.66107313738753120669e-02 + w * (4.97687799461593236017e-02 + w * 1.62858201153657823623e-02)))));
+  const double s2 = w * (-1.99999999998764832476e-01 +
+                         w * (-1.11111104054623557880e-01 +
+                              w * (-7.69187620504482999495e-02 + w * (-5.83357013379057348645e-02 + w * -3.65315727442169155270e-02))));
+  const double a = hi - ((z * (s1 + s2) - lo) - z);
+  return sw ? (1.57079632679489655800e+00 - a) + 6.12323399573676603587e-17 : a;
+}
+
 // ---- 3-vector / 3x3 (row-major) helpers, generic in the scalar ----------------------------------------
 template <class S, class A, class B>
 EMPC_HD void cross3(const A* a, const B* b, S* r) {
@@ -149,7 +259,7 @@ EMPC_HD void quat_mul(const double* a, const double* b, double* r) {
   r[3] = w;
 }
 EMPC_HD void quat_normalize(double* q) {
-  const double n = 1.0 / sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  const double n = frsqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
   q[0] *= n;
   q[1] *= n;
   q[2] *= n;
@@ -157,58 +267,69 @@ EMPC_HD void quat_normalize(double* q) {
 }
 EMPC_HD void quat_exp3(const double* w, double* q) {
   const double t2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
-  const double t = sqrt(t2);
-  double k;
+  const double t = fsqrt(t2);
+  double k, sh, ch;
+  fsincos(0.5 * t, &sh, &ch);
   if (t < 1e-4)
     k = 0.5 - t2 / 48.0 + t2 * t2 / 3840.0;
   else
-    k = sin(0.5 * t) / t;
+    k = fdiv(sh, t);
   q[0] = k * w[0];
   q[1] = k * w[1];
   q[2] = k * w[2];
-  q[3] = cos(0.5 * t);
+  q[3] = ch;
 }
-EMPC_HD void quat_log3(const double* q, double* w) {
+// log of a unit quaternion; optionally returns the half-angle sine / cosine (n, |q.w|) and the angle
+EMPC_HD void quat_log3(const double* q, double* w, double* half = nullptr) {
   const double n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2];
-  const double n = sqrt(n2);
+  const double n = fsqrt(n2);
   const double sgn = q[3] >= 0 ? 1.0 : -1.0;
   const double aw = fabs(q[3]);
-  double k;
-  if (n < 1e-6)
-    k = 2.0 / aw * (1.0 - n2 / (3.0 * aw * aw));
-  else
-    k = 2.0 * atan2(n, aw) / n;
+  double k, t;
+  if (n < 1e-6) {
+    k = fdiv(2.0, aw) * (1.0 - fdiv(n2, 3.0 * aw * aw));
+    t = k * n;
+  } else {
+    t = 2.0 * fatan2_pos(n, aw);
+    k = fdiv(t, n);
+  }
   k *= sgn;
   w[0] = k * q[0];
   w[1] = k * q[1];
   w[2] = k * q[2];
+  if (half) {
+    half[0] = n;
+    half[1] = aw;
+    half[2] = t;
+  }
 }
 EMPC_HD void R_to_quat(const double* R, double* q) {
   const double tr = R[0] + R[4] + R[8];
+  // s = 2 sqrt(d): the dominant component is s / 4 = d * (0.5 / sqrt(d)), the others are differences * (0.5 / sqrt(d))
   if (tr > 0) {
-    const double s = sqrt(tr + 1.0) * 2;
-    q[3] = 0.25 * s;
-    q[0] = (R[7] - R[5]) / s;
-    q[1] = (R[2] - R[6]) / s;
-    q[2] = (R[3] - R[1]) / s;
+    const double d = tr + 1.0, h = 0.5 * frsqrt(d);
+    q[3] = d * h;
+    q[0] = (R[7] - R[5]) * h;
+    q[1] = (R[2] - R[6]) * h;
+    q[2] = (R[3] - R[1]) * h;
   } else if (R[0] > R[4] && R[0] > R[8]) {
-    const double s = sqrt(1.0 + R[0] - R[4] - R[8]) * 2;
-    q[3] = (R[7] - R[5]) / s;
-    q[0] = 0.25 * s;
-    q[1] = (R[1] + R[3]) / s;
-    q[2] = (R[2] + R[6]) / s;
+    const double d = 1.0 + R[0] - R[4] - R[8], h = 0.5 * frsqrt(d);
+    q[3] = (R[7] - R[5]) * h;
+    q[0] = d * h;
+    q[1] = (R[1] + R[3]) * h;
+    q[2] = (R[2] + R[6]) * h;
   } else if (R[4] > R[8]) {
-    const double s = sqrt(1.0 + R[4] - R[0] - R[8]) * 2;
-    q[3] = (R[2] - R[6]) / s;
-    q[0] = (R[1] + R[3]) / s;
-    q[1] = 0.25 * s;
-    q[2] = (R[5] + R[7]) / s;
+    const double d = 1.0 + R[4] - R[0] - R[8], h = 0.5 * frsqrt(d);
+    q[3] = (R[2] - R[6]) * h;
+    q[0] = (R[1] + R[3]) * h;
+    q[1] = d * h;
+    q[2] = (R[5] + R[7]) * h;
   } else {
-    const double s = sqrt(1.0 + R[8] - R[0] - R[4]) * 2;
-    q[3] = (R[3] - R[1]) / s;
-    q[0] = (R[2] + R[6]) / s;
-    q[1] = (R[5] + R[7]) / s;
-    q[2] = 0.25 * s;
+    const double d = 1.0 + R[8] - R[0] - R[4], h = 0.5 * frsqrt(d);
+    q[3] = (R[3] - R[1]) * h;
+    q[0] = (R[2] + R[6]) * h;
+    q[1] = (R[5] + R[7]) * h;
+    q[2] = d * h;
   }
   quat_normalize(q);
 }
@@ -222,8 +343,8 @@ struct SO3Coef {
   double al;    // t sin t / (2 (1 - cos t))       alpha of log6
   double bdot;  // d(beta)/dt / t
 };
-EMPC_HD void so3_coef(double t2, SO3Coef& k) {
-  const double t = sqrt(t2);
+// from the angle t (t2 = t^2) and the sine / cosine of HALF the angle: sin t = 2 sh ch, 1 - cos t = 2 sh^2
+EMPC_HD void so3_coef_half(double t2, double t, double sh, double ch, SO3Coef& k) {
   if (t < 1e-2) {
     const double t4 = t2 * t2;
     k.a = 1.0 - t2 / 6.0 + t4 / 120.0 - t4 * t2 / 5040.0;
@@ -233,14 +354,22 @@ EMPC_HD void so3_coef(double t2, SO3Coef& k) {
     k.al = 1.0 - t2 / 12.0 - t4 / 720.0 - t4 * t2 / 30240.0;
     k.bdot = 1.0 / 360.0 + t2 / 7560.0 + t4 / 201600.0;
   } else {
-    const double st = sin(t), ct = cos(t);
-    k.a = st / t;
-    k.b = (1.0 - ct) / t2;
-    k.c = (t - st) / (t2 * t);
-    k.e = 1.0 / t2 - st / (2.0 * t * (1.0 - ct));
-    k.al = t * st / (2.0 * (1.0 - ct));
-    k.bdot = -2.0 / (t2 * t2) + (1.0 + st / t) / (2.0 * t2 * (1.0 - ct));
+    const double st = 2.0 * sh * ch;
+    const double it = frcp(t), it2 = it * it;
+    const double cot = fdiv(ch, sh);      // cot(t/2) = sin t / (1 - cos t)
+    k.a = st * it;
+    k.b = 2.0 * sh * sh * it2;
+    k.c = (t - st) * it2 * it;
+    k.e = it2 - 0.5 * it * cot;           // 1/t^2 - sin t / (2 t (1 - cos t))
+    k.al = 0.5 * t * cot;                 // t sin t / (2 (1 - cos t))
+    k.bdot = -2.0 * it2 * it2 + (1.0 + k.a) * it2 * fdiv(0.25, sh * sh);  // (1 + sin t / t) / (2 t^2 (1 - cos t))
   }
+}
+EMPC_HD void so3_coef(double t2, SO3Coef& k) {
+  const double t = fsqrt(t2);
+  double sh, ch;
+  fsincos(0.5 * t, &sh, &ch);
+  so3_coef_half(t2, t, sh, ch, k);
 }
 
 // exp6 of [v; w] -> rotation as quaternion and translation
@@ -259,11 +388,11 @@ EMPC_HD void exp6_quat(const double* xi, double* q, double* p) {
 }
 // log6 from a unit quaternion and a translation
 EMPC_HD void log6_quat(const double* q, const double* p, double* xi) {
-  double w[3];
-  quat_log3(q, w);
-  const double t2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  double w[3], half[3];
+  quat_log3(q, w, half);
+  const double t = half[2], t2 = t * t;
   SO3Coef k;
-  so3_coef(t2, k);
+  so3_coef_half(t2, t, half[0], half[1], k);  // unit quaternion: (|q.xyz|, |q.w|) = (sin, cos) of t / 2
   double wxp[3];
   cross3<double>(w, p, wxp);
   const double wp = dot3<double>(w, p);

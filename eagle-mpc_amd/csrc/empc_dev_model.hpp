@@ -354,7 +354,7 @@ EMPC_HD bool chol_packed(double* L) {
 #pragma unroll
     for (int k = 0; k < j; ++k) s -= L[j * (j + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
     if (!(s > 0.0)) ok = false;
-    const double inv = 1.0 / sqrt(s);
+    const double inv = frsqrt(s);
     L[j * (j + 1) / 2 + j] = inv;
 #pragma unroll
     for (int i = j + 1; i < N; ++i) {
@@ -388,10 +388,11 @@ EMPC_HD void chol_solve_packed(const double* L, double* b) {
 EMPC_HD void squash1(double s, double lb, double ub, double smooth, int power, double& u, double& du) {
   const double dd = smooth * (ub - lb);
   const double a = (power == 4) ? dd * dd * dd * dd : dd * dd;
-  const double sl = sqrt((s - lb) * (s - lb) + a);
-  const double su = sqrt((s - ub) * (s - ub) + a);
+  const double al = (s - lb) * (s - lb) + a, au = (s - ub) * (s - ub) + a;
+  const double rl = frsqrt(al), ru = frsqrt(au);
+  const double sl = al * rl, su = au * ru;
   u = 0.5 * (sl - su + ub + lb);
-  du = 0.5 * ((s - lb) / sl - (s - ub) / su);
+  du = 0.5 * ((s - lb) * rl - (s - ub) * ru);
 }
 
 // activation value and derivatives of one residual component
@@ -416,12 +417,85 @@ EMPC_HD void activation1(int act, double r, double w, double lb, double ub, doub
 }
 // weight of component i of cost c, with the barrier cost's weights derived from the trajectory's current smooth
 // (SolverSbFDDP::barrierUpdate, src/sbfddp.cpp:464-477)
-EMPC_HD double act_weight(const EMPC_K EmpcCost& c, int i, double smooth, const EMPC_K DevProblem& P) {
+template <class CostT>
+EMPC_HD double act_weight(const CostT& c, int i, double smooth, const EMPC_K DevProblem& P) {
   if (c.is_barrier) {
     const double aux = smooth * (P.u_ub[i] - P.u_lb[i]);
     return 1.0 / (aux * aux);
   }
   return c.act_w[i];
+}
+
+// Sum of the activation values of the first nr (<= NR) residual components -- the value-only path of the rollouts.
+// The activation type is branched on ONCE and each case is straight-line code, so the parameter loads (weights, bounds)
+// of all components are issued together instead of one dependent scalar load per component (measured: 1/3 of the
+// rollout kernel, profiles/r01_rollout_ablation.txt).  Same formulas and summation order as activation1.
+template <int NR, class CostT>
+EMPC_HD double activation_value(const CostT& c, const double* r, int nr) {
+  double cval = 0;
+  if (c.activation == EMPC_ACT_QUAD) {
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+      if (i < nr) cval += 0.5 * r[i] * r[i];
+  } else if (c.activation == EMPC_ACT_WEIGHTED_QUAD) {
+    double w[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) w[i] = c.act_w[i];
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+      if (i < nr) cval += 0.5 * w[i] * r[i] * r[i];
+  } else {
+    const bool weighted = (c.activation != EMPC_ACT_QUADRATIC_BARRIER);
+    double w[NR], lb[NR], ub[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      w[i] = weighted ? c.act_w[i] : 1.0;
+      lb[i] = c.lb[i];
+      ub[i] = c.ub[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      if (i < nr) {
+        const double lo = fmin(r[i] - lb[i], 0.0);
+        const double hi = fmax(r[i] - ub[i], 0.0);
+        cval += 0.5 * w[i] * lo * lo + 0.5 * w[i] * hi * hi;
+      }
+    }
+  }
+  return cval;
+}
+// Control cost value: residual s - ref with the barrier cost's weights derived from the current smoothness
+template <int NU, class CostT>
+EMPC_HD double control_cost_value(const CostT& c, const double* s, double smooth, const EMPC_K DevProblem& P) {
+  double r[NU];
+#pragma unroll
+  for (int i = 0; i < NU; ++i) r[i] = s[i] - c.ref[i];
+  if (!c.is_barrier) return activation_value<NU>(c, r, NU);
+  // SolverSbFDDP::barrierUpdate (src/sbfddp.cpp:464-477): weights 1 / (smooth (ub - lb))^2, bounds from the cost
+  double cval = 0;
+  double w[NU], lb[NU], ub[NU];
+#pragma unroll
+  for (int i = 0; i < NU; ++i) {
+    const double aux = smooth * (P.u_ub[i] - P.u_lb[i]);
+    w[i] = 1.0 / (aux * aux);
+    lb[i] = c.lb[i];
+    ub[i] = c.ub[i];
+  }
+  if (c.activation == EMPC_ACT_QUAD || c.activation == EMPC_ACT_WEIGHTED_QUAD) {
+    const bool weighted = (c.activation == EMPC_ACT_WEIGHTED_QUAD);
+#pragma unroll
+    for (int i = 0; i < NU; ++i) cval += weighted ? 0.5 * w[i] * r[i] * r[i] : 0.5 * r[i] * r[i];
+  } else {
+    const bool weighted = (c.activation != EMPC_ACT_QUADRATIC_BARRIER);
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      const double ww = weighted ? w[i] : 1.0;
+      const double lo = fmin(r[i] - lb[i], 0.0);
+      const double hi = fmax(r[i] - ub[i], 0.0);
+      cval += 0.5 * ww * lo * lo + 0.5 * ww * hi * hi;
+    }
+  }
+  return cval;
 }
 
 // StateMultibody::diff(x0, x1) for the free-flyer + joints layout; also returns the translation part of
@@ -502,9 +576,37 @@ EMPC_HD void cone_rows(const double* nsurf, double mu, double AR[5][3]) {
 // Outputs: xnext[NX], acc[NV] (generalized acceleration, reused by linearize), cost, usq[NU] (squashed control),
 //          lam[6] (contact force).
 // ---------------------------------------------------------------------------------------------------------
-template <class DM, bool CT>
-EMPC_HD void node_nominal(const EMPC_K DevProblem& P, const EMPC_K EmpcCostSet& set, double smooth, const double* x, const double* s_in,
-                          bool terminal, double* xnext, double* acc, double& cost_out, double* usq, double* lam_out) {
+#ifdef EMPC_ABL
+#if defined(__HIPCC__)
+__device__ int g_abl;
+#define ABL(bit) (g_abl & (bit))
+#else
+#define ABL(bit) 0
+#endif
+#else
+#define ABL(bit) 0
+#endif
+// diagnostic builds (-DEMPC_STAMPS): cycle counter deltas per section, accumulated in a caller-provided array
+#if defined(EMPC_STAMPS) && defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+#define EMPC_STAMP(i)                                               \
+  do {                                                              \
+    __builtin_amdgcn_sched_barrier(0);                              \
+    if (stp) {                                                      \
+      const unsigned long long now_ = __builtin_readcyclecounter(); \
+      stp[i] += now_ - stp[31];                                     \
+      stp[31] = now_;                                               \
+    }                                                               \
+  } while (0)
+#else
+#define EMPC_STAMP(i) \
+  do {                \
+  } while (0)
+#endif
+// SetT: the cost set either in the constant address space (scalar loads) or staged in LDS / generic memory
+template <class DM, bool CT, class SetT>
+EMPC_HD void node_nominal(const EMPC_K DevProblem& P, const SetT& set, double smooth, const double* x, const double* s_in,
+                          bool terminal, double* xnext, double* acc, double& cost_out, double* usq, double* lam_out,
+                          unsigned long long* stp = nullptr) {
   constexpr int NB = DM::NB, NV = DM::NV, NQ = DM::NQ, NU = DM::NU, NROT = DM::NROT;
   const EMPC_K EmpcModelDesc& m = P.model;
   const double dt = P.dt;
@@ -538,13 +640,13 @@ EMPC_HD void node_nominal(const EMPC_K DevProblem& P, const EMPC_K EmpcCostSet& 
   quat_to_R(q + 3, R0);
 #pragma unroll
   for (int b = 1; b < NB; ++b) {
-    sincos(q[7 + b - 1], &sn[b - 1], &cs[b - 1]);
+    fsincos(q[7 + b - 1], &sn[b - 1], &cs[b - 1]);
   }
   // frames referenced by this node's costs / contacts
   int capf[NCAP] = {0, 0};
   int ncap = 0;
   for (int ci = 0; ci < set.ncosts; ++ci) {
-    const EMPC_K EmpcCost& c = set.costs[ci];
+    const auto& c = set.costs[ci];
     if (!c.active || c.frame < 0 || c.type == EMPC_COST_CONTACT_FRICTION_CONE) continue;
     bool seen = false;
 #pragma unroll
@@ -557,24 +659,30 @@ EMPC_HD void node_nominal(const EMPC_K DevProblem& P, const EMPC_K EmpcCostSet& 
     }
   }
   FrameCap<double> caps[NCAP];
+  EMPC_STAMP(1);  // squash, tau, quaternion, joint sin/cos, frame scan
   // bias forces h = RNEA(q, v, 0)
   double zero[NV], h[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) zero[i] = 0.0;
-  rnea_chain<NB, double>(m, R0, q, cs, sn, v, zero, true, -1, nullptr, h, ncap, capf, caps);
+  if (!ABL(4)) rnea_chain<NB, double>(m, R0, q, cs, sn, v, zero, true, -1, nullptr, h, ncap, capf, caps);
+  else for (int i = 0; i < NV; ++i) h[i] = 0;
+  EMPC_STAMP(2);  // RNEA bias
   // joint-space inertia (packed lower triangle) by the composite-rigid-body algorithm
   double L[DM::NTRI];
-  crba_chain<NB>(m, cs, sn, L);
-  chol_packed<NV>(L);
+  if (!ABL(8)) crba_chain<NB>(m, cs, sn, L);
+  else for (int i = 0; i < DM::NTRI; ++i) L[i] = (i % 7 == 0) ? 1.0 + i : 0.01;
+  EMPC_STAMP(3);  // CRBA
+  if (!ABL(16)) chol_packed<NV>(L);
   double a[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) a[i] = tau[i] - h[i];
   chol_solve_packed<NV>(L, a);
+  EMPC_STAMP(4);  // Cholesky + solve
   double lam[6] = {0, 0, 0, 0, 0, 0};
   const bool use_contact = CT && P.has_contact && set.ncontacts > 0;
   if constexpr (CT) if (use_contact) {
     // ContactModel3D/6D: [M Jc^T; Jc 0][a; -lam] = [tau - h; -a0]
-    const EMPC_K EmpcContact& ct = set.contacts[0];
+    const auto& ct = set.contacts[0];
     const int nc = (ct.type == EMPC_CONTACT_3D) ? 3 : 6;
     int cf[1] = {ct.frame};
     FrameCap<double> ck[1];
@@ -651,14 +759,17 @@ EMPC_HD void node_nominal(const EMPC_K DevProblem& P, const EMPC_K EmpcCostSet& 
     dxe[i] = v[i] * dt + a[i] * dt * dt;
     dxe[NV + i] = a[i] * dt;
   }
-  state_integrate<DM>(x, dxe, xnext, nullptr);
+  EMPC_STAMP(5);  // contact KKT
+  if (!ABL(32)) state_integrate<DM>(x, dxe, xnext, nullptr);
+  else for (int i = 0; i < DM::NX; ++i) xnext[i] = x[i];
+  EMPC_STAMP(6);  // Euler step
 
   // costs (A.6)
   double ell = 0;
   double rstate[DM::NDX];  // residual of the most recent State cost (shared between costs with one reference)
   int rstate_of = -1;
-  for (int ci = 0; ci < set.ncosts; ++ci) {
-    const EMPC_K EmpcCost& c = set.costs[ci];
+  for (int ci = 0; ci < (ABL(1) ? 0 : set.ncosts); ++ci) {
+    const auto& c = set.costs[ci];
     if (!c.active) continue;
     double cval = 0;
     if (c.type == EMPC_COST_STATE) {
@@ -667,19 +778,9 @@ EMPC_HD void node_nominal(const EMPC_K DevProblem& P, const EMPC_K EmpcCostSet& 
         state_diff<DM>(c.ref, x, r, nullptr);
         rstate_of = (c.ref_share >= 0) ? c.ref_share : ci;
       }
-#pragma unroll
-      for (int i = 0; i < DM::NDX; ++i) {
-        double av, Ar, Arr;
-        activation1(c.activation, r[i], c.act_w[i], c.lb[i], c.ub[i], av, Ar, Arr);
-        cval += av;
-      }
+      cval = activation_value<DM::NDX>(c, r, DM::NDX);
     } else if (c.type == EMPC_COST_CONTROL) {
-#pragma unroll
-      for (int i = 0; i < NU; ++i) {
-        double av, Ar, Arr;
-        activation1(c.activation, s[i] - c.ref[i], act_weight(c, i, smooth, P), c.lb[i], c.ub[i], av, Ar, Arr);
-        cval += av;
-      }
+      cval = control_cost_value<NU>(c, s, smooth, P);
     } else if (c.type == EMPC_COST_CONTACT_FRICTION_CONE) {
       double AR[5][3];
       double nsf[3] = {c.ref[0], c.ref[1], c.ref[2]};
@@ -719,16 +820,16 @@ EMPC_HD void node_nominal(const EMPC_K DevProblem& P, const EMPC_K EmpcCostSet& 
 #pragma unroll
         for (int i = 0; i < 6; ++i) r[i] = fk.v[i] - c.ref[i];
       }
-      for (int i = 0; i < nr; ++i) {
-        double av, Ar, Arr;
-        activation1(c.activation, r[i], c.act_w[i], c.lb[i], c.ub[i], av, Ar, Arr);
-        cval += av;
+      if (nr == 3) {
+        r[3] = r[4] = r[5] = 0.0;
       }
+      cval = activation_value<6>(c, r, nr);
     }
     ell += c.weight * cval;
   }
   const double cscale = (terminal && !P.prm.terminal_dt_scaling) ? 1.0 : dt;
   cost_out = cscale * ell;
+  EMPC_STAMP(7);  // costs
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -755,7 +856,7 @@ EMPC_HD void free_fwd_acc(const EMPC_K DevProblem& P, const double* x, const dou
   double R0[9], cs[NB], sn[NB];
   quat_to_R(q + 3, R0);
 #pragma unroll
-  for (int b = 1; b < NB; ++b) sincos(q[7 + b - 1], &sn[b - 1], &cs[b - 1]);
+  for (int b = 1; b < NB; ++b) fsincos(q[7 + b - 1], &sn[b - 1], &cs[b - 1]);
   int capf[NCAP] = {0, 0};
   FrameCap<double> caps[NCAP];
   double zero[NV], h[NV];

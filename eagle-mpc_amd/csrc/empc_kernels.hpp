@@ -13,6 +13,8 @@
 // Reference semantics: src/sbfddp.cpp (solve loop, acceptance rules, barrier/squash schedule) and SURVEY.md
 // Appendix A.1-A.7 (Crocoddyl / Pinocchio behaviour).  Everything is FP64.
 #pragma once
+#include <type_traits>
+
 #include "empc_dev_model.hpp"
 
 namespace empc {
@@ -105,78 +107,460 @@ EMPC_HD void calc_thread(const DevBuffers& D, int b, int t) {
 // =====================================================================================================================
 // rollout: SolverFDDP::forwardPass(alpha) / SolverSbFDDP::forwardPassDDP(alpha).  One lane per (b, alpha index).
 // =====================================================================================================================
+// Per-lane state of one (trajectory, step length) trial across the knots.
+template <class DM>
+struct RollLane {
+  double xnext[DM::NX];
+  double cost_try, dv;
+  int ok;
+};
+
+// One knot of the forward pass for one trial.  The knot's nominal data comes through typed pointers so that the same
+// body serves per-lane global reads (k_rollout) and wave-shared LDS staging (k_rollout4).  Returns false when the trial
+// failed (NaN / overflow, crocoddyl's raiseIfNaN) and the caller must stop.
+template <class DM, bool CT, class SetT, class PX, class PU, class PK, class PG>
+EMPC_HD bool rollout_knot(const EMPC_K DevProblem& P, const SetT& set, RollLane<DM>& L, int t, int T, bool plain, bool need_dv,
+                          double alpha, double smooth, PX xc, PU uc, PU kk, PK KK, PG gap, PG vf, double* xs_o, double* us_o,
+                          double* ac_o, unsigned long long* stp) {
+  constexpr int NX = DM::NX, NU = DM::NU, NV = DM::NV, NDX = DM::NDX;
+  double xtry[NX], dx[NDX], utry[NU], acc[NV], usq[NU], lam[6];
+  EMPC_STAMP(9);  // stores / loop tail of the previous knot
+  if (plain) {
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xtry[i] = L.xnext[i];
+  } else {
+    double step[NDX];
+#pragma unroll
+    for (int i = 0; i < NDX; ++i) step[i] = gap[i] * (alpha - 1.0);
+    state_integrate<DM>(L.xnext, step, xtry, nullptr);
+  }
+  if (!ABL(2)) state_diff<DM>(xc, xtry, dx, nullptr);
+  else for (int i = 0; i < NDX; ++i) dx[i] = 0.001 * i;
+  if (need_dv) {
+    double dv = L.dv;
+#pragma unroll
+    for (int i = 0; i < NDX; ++i) dv += vf[i] * dx[i];  // -f^T Vxx (xs (-) xs_try) = +(Vxx f).(xs_try (-) xs)
+    L.dv = dv;
+  }
+  double cost;
+  if (t < T) {
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      double a_ = uc[i] - kk[i] * alpha;
+      if (!ABL(64)) {
+#pragma unroll
+      for (int j = 0; j < NDX; ++j) a_ -= KK[i * NDX + j] * dx[j];
+      }
+      utry[i] = a_;
+    }
+    EMPC_STAMP(0);  // x_try, state difference, feedback
+    node_nominal<DM, CT>(P, set, smooth, xtry, utry, false, L.xnext, acc, cost, usq, lam, stp);
+#pragma unroll
+    for (int i = 0; i < NU; ++i) us_o[(size_t)t * NU + i] = utry[i];
+  } else {
+    double xn2[NX];
+    node_nominal<DM, CT>(P, set, smooth, xtry, (const double*)nullptr, true, xn2, acc, cost, usq, lam, stp);
+  }
+  if (!ABL(128)) {
+#pragma unroll
+  for (int i = 0; i < NX; ++i) xs_o[(size_t)t * NX + i] = xtry[i];
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) ac_o[(size_t)t * DM::NACC + i] = acc[i];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) ac_o[(size_t)t * DM::NACC + NV + i] = lam[i];
+  L.cost_try += cost;
+  if (bad_number(L.cost_try)) {
+    L.ok = 0;
+    return false;
+  }
+  if (t < T) {
+    double mx = 0;
+    bool isn = false;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      mx = fmax(mx, fabs(L.xnext[i]));
+      isn = isn || (L.xnext[i] != L.xnext[i]);
+    }
+    if (isn || bad_number(mx)) {
+      L.ok = 0;
+      return false;
+    }
+  }
+  return true;
+}
+
 template <class DM, bool CT>
 EMPC_HD void rollout_thread(const DevBuffers& D, int b, int ai) {
   const TrajState& st = D.st[b];
   if (st.phase == PHASE_DONE || st.bwd_failed) return;
-  constexpr int NX = DM::NX, NU = DM::NU, NV = DM::NV, NDX = DM::NDX, REC = DM::REC;
+  constexpr int NX = DM::NX, NU = DM::NU, NDX = DM::NDX, REC = DM::REC;
+  const EMPC_K DevProblem& P = EMPC_KREF(DevProblem, D.P);
   const int T = D.T, NA = D.NA;
   const bool ddp = (st.phase == PHASE_DDP);
   const bool feas = st.is_feasible != 0;
   const double alpha = ldexp(1.0, -ai);
   const bool plain = ddp || feas || (ai == 0);
   const double smooth = st.smooth;
-  double xnext[NX], xtry[NX], dx[NDX], utry[NU], acc[NV], usq[NU], lam[6];
-  for (int i = 0; i < NX; ++i) xnext[i] = D.x0[(size_t)b * NX + i];
-  double cost_try = 0, dv = 0;
-  int ok = 1;
+  RollLane<DM> L;
+  for (int i = 0; i < NX; ++i) L.xnext[i] = D.x0[(size_t)b * NX + i];
+  L.cost_try = 0;
+  L.dv = 0;
+  L.ok = 1;
   const size_t slot = (size_t)b * NA + ai;
   double* xs_o = D.xs_try + slot * (T + 1) * NX;
   double* us_o = D.us_try + slot * T * NU;
   double* ac_o = D.acc_try + slot * (T + 1) * DM::NACC;
+#if defined(EMPC_STAMPS) && defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+  unsigned long long stamps[32];
+  for (int i = 0; i < 32; ++i) stamps[i] = 0;
+  unsigned long long* stp = (b == 0 && ai == 1) ? stamps : nullptr;
+  if (stp) stp[31] = __builtin_readcyclecounter();
+#else
+  unsigned long long* stp = nullptr;
+#endif
   for (int t = 0; t <= T; ++t) {
     const double* rec = D.tape + ((size_t)b * (T + 1) + t) * REC;
-    if (plain) {
-      for (int i = 0; i < NX; ++i) xtry[i] = xnext[i];
-    } else {
-      double step[NDX];
-      for (int i = 0; i < NDX; ++i) step[i] = rec[DM::OFF_GAP + i] * (alpha - 1.0);
-      state_integrate<DM>(xnext, step, xtry, nullptr);
-    }
     const double* xc = D.xs + ((size_t)b * (T + 1) + t) * NX;
-    state_diff<DM>(xc, xtry, dx, nullptr);
-    if (!ddp && !feas) {
-      const double* vf = D.Vf + ((size_t)b * (T + 1) + t) * NDX;
-      for (int i = 0; i < NDX; ++i) dv += vf[i] * dx[i];  // -f^T Vxx (xs (-) xs_try) = +(Vxx f).(xs_try (-) xs)
-    }
-    double cost;
-    if (t < T) {
-      const double* uc = D.us + ((size_t)b * T + t) * NU;
-      const double* kk = D.kff + ((size_t)b * T + t) * NU;
-      const double* KK = D.K + ((size_t)b * T + t) * NU * NDX;
-      for (int i = 0; i < NU; ++i) {
-        double a_ = uc[i] - kk[i] * alpha;
-        for (int j = 0; j < NDX; ++j) a_ -= KK[i * NDX + j] * dx[j];
-        utry[i] = a_;
-      }
-      node_nominal<DM, CT>(EMPC_KREF(DevProblem, D.P), EMPC_KPTR(EmpcCostSet, D.sets)[EMPC_KPTR(int, D.knot_set)[t]], smooth, xtry, utry, false, xnext, acc, cost, usq, lam);
-      for (int i = 0; i < NU; ++i) us_o[(size_t)t * NU + i] = utry[i];
-    } else {
-      double xn2[NX];
-      node_nominal<DM, CT>(EMPC_KREF(DevProblem, D.P), EMPC_KPTR(EmpcCostSet, D.sets)[EMPC_KPTR(int, D.knot_set)[t]], smooth, xtry, nullptr, true, xn2, acc, cost, usq, lam);
-    }
-    for (int i = 0; i < NX; ++i) xs_o[(size_t)t * NX + i] = xtry[i];
-    for (int i = 0; i < NV; ++i) ac_o[(size_t)t * DM::NACC + i] = acc[i];
-    for (int i = 0; i < 6; ++i) ac_o[(size_t)t * DM::NACC + NV + i] = lam[i];
-    cost_try += cost;
-    if (bad_number(cost_try)) {
-      ok = 0;
+    const double* vf = D.Vf + ((size_t)b * (T + 1) + t) * NDX;
+    const int tt = (t < T) ? t : 0;  // unused at the terminal node
+    const double* uc = D.us + ((size_t)b * T + tt) * NU;
+    const double* kk = D.kff + ((size_t)b * T + tt) * NU;
+    const double* KK = D.K + ((size_t)b * T + tt) * NU * NDX;
+    const EMPC_K EmpcCostSet& set = EMPC_KPTR(EmpcCostSet, D.sets)[EMPC_KPTR(int, D.knot_set)[t]];
+    if (!rollout_knot<DM, CT>(P, set, L, t, T, plain, !ddp && !feas, alpha, smooth, xc, uc, kk, KK, rec + DM::OFF_GAP, vf, xs_o,
+                              us_o, ac_o, stp))
       break;
-    }
-    if (t < T) {
-      double mx = 0;
-      for (int i = 0; i < NX; ++i) mx = fmax(mx, fabs(xnext[i]));
-      bool isn = false;
-      for (int i = 0; i < NX; ++i) isn = isn || (xnext[i] != xnext[i]);
-      if (isn || bad_number(mx)) {
-        ok = 0;
-        break;
-      }
-    }
   }
-  D.try_cost[slot] = cost_try;
-  D.try_dv[slot] = dv;
-  D.try_ok[slot] = ok;
+  D.try_cost[slot] = L.cost_try;
+  D.try_dv[slot] = L.dv;
+  D.try_ok[slot] = L.ok;
+#if defined(EMPC_STAMPS) && defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+  if (stp)
+    for (int i = 0; i < 16; ++i) D.dbg[i] = stamps[i];
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// rollout, wave-shared staging: one wavefront per trajectory, lanes 0..NA-1 = step lengths.  Everything a knot reads that
+// does not depend on the step length -- xs[t], us[t], k[t], K[t], the gap, Vxx f and the knot's cost tables -- is
+// identical for the lanes of the wave, so all 64 lanes fetch it together (coalesced, one knot ahead, through registers)
+// into LDS and the trial lanes read it back as LDS broadcasts.  Per-lane vector loads of the same addresses and the
+// dependent scalar loads of the cost tables were ~55 % of the per-lane form's time (profiles/).
+// ---------------------------------------------------------------------------------------------------------------------
+template <class DM>
+struct Roll4Smem {
+  static constexpr int NX = DM::NX, NU = DM::NU, NDX = DM::NDX;
+  static constexpr int IN_K = 0;                       // K[t]  NU x NDX
+  static constexpr int IN_X = IN_K + NU * NDX;         // xs[t]
+  static constexpr int IN_U = IN_X + NX;               // us[t]
+  static constexpr int IN_KFF = IN_U + NU;             // k[t]
+  static constexpr int IN_GAP = IN_KFF + NU;           // fs[t]
+  static constexpr int IN_VF = IN_GAP + NDX;           // Vxx[t] fs[t]
+  static constexpr int NIN = IN_VF + NDX;
+  static constexpr int NPRE = (NIN + 63) / 64;         // prefetch registers per lane
+  static constexpr int SET_DOUBLES = (int)(sizeof(EmpcCostSet) / sizeof(double));
+  static_assert(sizeof(EmpcCostSet) % sizeof(double) == 0, "cost set must be a whole number of doubles");
+  static constexpr int OFF_SET = 0;
+  static constexpr int OFF_IN = OFF_SET + SET_DOUBLES;  // two buffers of NIN
+  static constexpr int SIZE = (OFF_IN + 2 * NIN + 1) / 2 * 2;
+};
+
+template <class DM, bool CT, class Exec>
+EMPC_HD void rollout_wave(Exec& ex, const DevBuffers& D, int b, int nl, double* N) {
+  typedef Roll4Smem<DM> SM;
+  const TrajState& st = D.st[b];
+  if (st.phase == PHASE_DONE || st.bwd_failed) return;
+  constexpr int NX = DM::NX, NU = DM::NU, NDX = DM::NDX, REC = DM::REC;
+  const EMPC_K DevProblem& P = EMPC_KREF(DevProblem, D.P);
+  const int T = D.T, NA = D.NA;
+  const bool ddp = (st.phase == PHASE_DDP);
+  const bool feas = st.is_feasible != 0;
+  const double smooth = st.smooth;
+  RollLane<DM> L[Exec::SLOTS];
+  double pre[Exec::SLOTS][SM::NPRE];
+  int alive[Exec::SLOTS];
+#if defined(EMPC_STAMPS) && defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+  unsigned long long stamps[32];
+  for (int i = 0; i < 32; ++i) stamps[i] = 0;
+  stamps[31] = __builtin_readcyclecounter();
+#endif
+
+  // element i of the staged input block of knot t
+  auto fetch = [&](int t, int i) -> double {
+    const int tt = (t < T) ? t : 0;
+    if (i < SM::IN_X) return (t < T) ? D.K[((size_t)b * T + tt) * NU * NDX + i] : 0.0;
+    if (i < SM::IN_U) return D.xs[((size_t)b * (T + 1) + t) * NX + (i - SM::IN_X)];
+    if (i < SM::IN_KFF) return (t < T) ? D.us[((size_t)b * T + tt) * NU + (i - SM::IN_U)] : 0.0;
+    if (i < SM::IN_GAP) return (t < T) ? D.kff[((size_t)b * T + tt) * NU + (i - SM::IN_KFF)] : 0.0;
+    if (i < SM::IN_VF) return D.tape[((size_t)b * (T + 1) + t) * REC + DM::OFF_GAP + (i - SM::IN_GAP)];
+    return D.Vf[((size_t)b * (T + 1) + t) * NDX + (i - SM::IN_VF)];
+  };
+  int cur_set = -1;
+  ex.each([&](int lane, int sl) {
+#pragma unroll
+    for (int i = 0; i < NX; ++i) L[sl].xnext[i] = D.x0[(size_t)b * NX + i];
+    L[sl].cost_try = 0;
+    L[sl].dv = 0;
+    L[sl].ok = 1;
+    alive[sl] = (lane < NA) ? 1 : 0;
+#pragma unroll
+    for (int k = 0; k < SM::NPRE; ++k) {
+      const int i = lane + nl * k;
+      if (i < SM::NIN) N[SM::OFF_IN + i] = fetch(0, i);
+    }
+  });
+  ex.sync();
+  for (int t = 0; t <= T; ++t) {
+    const int si = EMPC_KPTR(int, D.knot_set)[t];
+    if (si != cur_set) {  // uniform: stage this knot's cost tables
+      const double* src = reinterpret_cast<const double*>(D.sets + si);
+      ex.each([&](int lane, int sl) {
+        for (int i = lane; i < SM::SET_DOUBLES; i += nl) N[SM::OFF_SET + i] = src[i];
+      });
+      ex.sync();
+      cur_set = si;
+    }
+    const double* in = N + SM::OFF_IN + (t & 1) * SM::NIN;
+    const EmpcCostSet& set = *reinterpret_cast<const EmpcCostSet*>(N + SM::OFF_SET);
+    ex.each([&](int lane, int sl) {
+      // next knot's inputs on their way while this knot is computed
+      if (t < T) {
+#pragma unroll
+        for (int k = 0; k < SM::NPRE; ++k) {
+          const int i = lane + nl * k;
+          pre[sl][k] = (i < SM::NIN) ? fetch(t + 1, i) : 0.0;
+        }
+      }
+      if (alive[sl]) {
+        const int ai = lane;
+        const double alpha = ldexp(1.0, -ai);
+        const bool plain = ddp || feas || (ai == 0);
+        const size_t slot = (size_t)b * NA + ai;
+        double* xs_o = D.xs_try + slot * (T + 1) * NX;
+        double* us_o = D.us_try + slot * T * NU;
+        double* ac_o = D.acc_try + slot * (T + 1) * DM::NACC;
+        if (!rollout_knot<DM, CT>(P, set, L[sl], t, T, plain, !ddp && !feas, alpha, smooth, in + SM::IN_X, in + SM::IN_U,
+                                  in + SM::IN_KFF, in + SM::IN_K, in + SM::IN_GAP, in + SM::IN_VF, xs_o, us_o, ac_o,
+#if defined(EMPC_STAMPS) && defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+                                  (b == 0 && lane == 1) ? stamps : (unsigned long long*)nullptr
+#else
+                                  (unsigned long long*)nullptr
+#endif
+                                  ))
+          alive[sl] = 0;
+      }
+      if (t < T) {
+        double* nxt = N + SM::OFF_IN + ((t + 1) & 1) * SM::NIN;
+#pragma unroll
+        for (int k = 0; k < SM::NPRE; ++k) {
+          const int i = lane + nl * k;
+          if (i < SM::NIN) nxt[i] = pre[sl][k];
+        }
+      }
+    });
+    ex.sync();
+  }
+  ex.each([&](int lane, int sl) {
+#if defined(EMPC_STAMPS) && defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+    if (b == 0 && lane == 1)
+      for (int i = 0; i < 16; ++i) D.dbg[i] = stamps[i];
+#endif
+    if (lane >= NA) return;
+    const size_t slot = (size_t)b * NA + lane;
+    D.try_cost[slot] = L[sl].cost_try;
+    D.try_dv[slot] = L[sl].dv;
+    D.try_ok[slot] = L[sl].ok;
+  });
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// rollout, cooperative feedback (the shipped form): one wavefront per trajectory, lanes 0..NA-1 own the step lengths.
+// Measured on the per-lane form (profiles/r01_rollout_ablation.txt): 37 % of the time is the feedback product
+// K[t] (xs_try (-) xs) -- every lane streams the same 162 doubles of K through too few registers, one exposed memory
+// latency per chunk.  Here the whole wave does that product: lane g*NU + i keeps row i of K[t] in registers (fetched one
+// knot ahead, 1 coalesced row per lane) and produces u_i for step lengths g, g + G, ...; the trial lanes only publish
+// their dx to LDS and read their u back.  xs[t], the gap and Vxx f travel the same way (1 double per lane, one knot
+// ahead, through LDS).
+// ---------------------------------------------------------------------------------------------------------------------
+template <class DM>
+struct Roll5Smem {
+  static constexpr int NX = DM::NX, NU = DM::NU, NDX = DM::NDX;
+  static constexpr int IN_X = 0;                 // xs[t]
+  static constexpr int IN_GAP = IN_X + NX;       // fs[t]
+  static constexpr int IN_VF = IN_GAP + NDX;     // Vxx[t] fs[t]
+  static constexpr int NIN = IN_VF + NDX;
+  static constexpr int NPRE = (NIN + 63) / 64;
+  static constexpr int OFF_IN = 0;               // two buffers of NIN
+  static constexpr int OFF_DX = OFF_IN + 2 * NIN;                 // [MAX_ALPHAS][NDX]
+  static constexpr int OFF_U = OFF_DX + MAX_ALPHAS * NDX;         // [MAX_ALPHAS][NU]
+  static constexpr int SIZE = (OFF_U + MAX_ALPHAS * NU + 1) / 2 * 2;
+};
+
+template <class DM, bool CT, class Exec>
+EMPC_HD void rollout_wave5(Exec& ex, const DevBuffers& D, int b, int nl, double* N) {
+  typedef Roll5Smem<DM> SM;
+  const TrajState& st = D.st[b];
+  if (st.phase == PHASE_DONE || st.bwd_failed) return;
+  constexpr int NX = DM::NX, NU = DM::NU, NV = DM::NV, NDX = DM::NDX, REC = DM::REC;
+  const EMPC_K DevProblem& P = EMPC_KREF(DevProblem, D.P);
+  const int T = D.T, NA = D.NA;
+  const bool ddp = (st.phase == PHASE_DDP);
+  const bool feas = st.is_feasible != 0;
+  const bool need_dv = !ddp && !feas;
+  const double smooth = st.smooth;
+  const int G = nl / NU;  // step lengths served per pass of the feedback product
+  RollLane<DM> L[Exec::SLOTS];
+  double xtry_l[Exec::SLOTS][NX];
+  double krow[Exec::SLOTS][NDX], ku[Exec::SLOTS], kk[Exec::SLOTS];  // row i of K[t], us[t][i], k[t][i]
+  double pre[Exec::SLOTS][SM::NPRE];
+  int alive[Exec::SLOTS];
+
+  auto fetch_in = [&](int t, int i) -> double {
+    if (i < SM::IN_GAP) return D.xs[((size_t)b * (T + 1) + t) * NX + (i - SM::IN_X)];
+    if (i < SM::IN_VF) return D.tape[((size_t)b * (T + 1) + t) * REC + DM::OFF_GAP + (i - SM::IN_GAP)];
+    return D.Vf[((size_t)b * (T + 1) + t) * NDX + (i - SM::IN_VF)];
+  };
+  auto fetch_row = [&](int t, int lane, int sl) {
+    const int i = lane % NU;
+    if (lane < G * NU && t < T) {
+      const double* Kr = D.K + (((size_t)b * T + t) * NU + i) * NDX;
+#pragma unroll
+      for (int j = 0; j < NDX; ++j) krow[sl][j] = Kr[j];
+      ku[sl] = D.us[((size_t)b * T + t) * NU + i];
+      kk[sl] = D.kff[((size_t)b * T + t) * NU + i];
+    }
+  };
+  ex.each([&](int lane, int sl) {
+#pragma unroll
+    for (int i = 0; i < NX; ++i) L[sl].xnext[i] = D.x0[(size_t)b * NX + i];
+    L[sl].cost_try = 0;
+    L[sl].dv = 0;
+    L[sl].ok = 1;
+    alive[sl] = (lane < NA) ? 1 : 0;
+#pragma unroll
+    for (int k = 0; k < SM::NPRE; ++k) {
+      const int i = lane + nl * k;
+      if (i < SM::NIN) N[SM::OFF_IN + i] = fetch_in(0, i);
+    }
+    fetch_row(0, lane, sl);
+  });
+  ex.sync();
+  for (int t = 0; t <= T; ++t) {
+    const double* in = N + SM::OFF_IN + (t & 1) * SM::NIN;
+    const EMPC_K EmpcCostSet& set = EMPC_KPTR(EmpcCostSet, D.sets)[EMPC_KPTR(int, D.knot_set)[t]];
+    // ---- S1: trial state and its difference to the nominal one (trial lanes); next knot's staged inputs requested ----
+    ex.each([&](int lane, int sl) {
+      if (t < T) {
+#pragma unroll
+        for (int k = 0; k < SM::NPRE; ++k) {
+          const int i = lane + nl * k;
+          pre[sl][k] = (i < SM::NIN) ? fetch_in(t + 1, i) : 0.0;
+        }
+      }
+      if (!alive[sl]) return;
+      const int ai = lane;
+      const double alpha = ldexp(1.0, -ai);
+      const bool plain = ddp || feas || (ai == 0);
+      double dx[NDX];
+      if (plain) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xtry_l[sl][i] = L[sl].xnext[i];
+      } else {
+        double step[NDX];
+#pragma unroll
+        for (int i = 0; i < NDX; ++i) step[i] = in[SM::IN_GAP + i] * (alpha - 1.0);
+        state_integrate<DM>(L[sl].xnext, step, xtry_l[sl], nullptr);
+      }
+      state_diff<DM>(in + SM::IN_X, xtry_l[sl], dx, nullptr);
+      if (need_dv) {
+        double dv = L[sl].dv;
+#pragma unroll
+        for (int i = 0; i < NDX; ++i) dv += in[SM::IN_VF + i] * dx[i];  // +(Vxx f).(xs_try (-) xs)
+        L[sl].dv = dv;
+      }
+#pragma unroll
+      for (int i = 0; i < NDX; ++i) N[SM::OFF_DX + ai * NDX + i] = dx[i];
+    });
+    ex.sync();
+    // ---- S2: feedback product by the whole wave: u_i = us_i - alpha k_i - K_i . dx(alpha) --------------------------
+    if (t < T) {
+      ex.each([&](int lane, int sl) {
+        if (lane < G * NU) {
+          const int g = lane / NU, i = lane % NU;
+          for (int a = g; a < NA; a += G) {
+            const double* dxa = N + SM::OFF_DX + a * NDX;
+            double a_ = ku[sl] - kk[sl] * ldexp(1.0, -a);
+#pragma unroll
+            for (int j = 0; j < NDX; ++j) a_ -= krow[sl][j] * dxa[j];
+            N[SM::OFF_U + a * NU + i] = a_;
+          }
+        }
+        fetch_row(t + 1, lane, sl);  // consumed at S2 of the next knot; in flight during S3
+      });
+      ex.sync();
+    }
+    // ---- S3: the node itself (trial lanes) ------------------------------------------------------------------------------
+    ex.each([&](int lane, int sl) {
+      if (alive[sl]) {
+        const int ai = lane;
+        const size_t slot = (size_t)b * NA + ai;
+        double* xs_o = D.xs_try + slot * (T + 1) * NX;
+        double* us_o = D.us_try + slot * T * NU;
+        double* ac_o = D.acc_try + slot * (T + 1) * DM::NACC;
+        double utry[NU], acc[NV], usq[NU], lam[6], cost;
+        if (t < T) {
+#pragma unroll
+          for (int i = 0; i < NU; ++i) utry[i] = N[SM::OFF_U + ai * NU + i];
+          node_nominal<DM, CT>(P, set, smooth, xtry_l[sl], utry, false, L[sl].xnext, acc, cost, usq, lam);
+#pragma unroll
+          for (int i = 0; i < NU; ++i) us_o[(size_t)t * NU + i] = utry[i];
+        } else {
+          double xn2[NX];
+          node_nominal<DM, CT>(P, set, smooth, xtry_l[sl], (const double*)nullptr, true, xn2, acc, cost, usq, lam);
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xs_o[(size_t)t * NX + i] = xtry_l[sl][i];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) ac_o[(size_t)t * DM::NACC + i] = acc[i];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) ac_o[(size_t)t * DM::NACC + NV + i] = lam[i];
+        L[sl].cost_try += cost;
+        if (bad_number(L[sl].cost_try)) {
+          L[sl].ok = 0;
+          alive[sl] = 0;
+        } else if (t < T) {
+          double mx = 0;
+          bool isn = false;
+#pragma unroll
+          for (int i = 0; i < NX; ++i) {
+            mx = fmax(mx, fabs(L[sl].xnext[i]));
+            isn = isn || (L[sl].xnext[i] != L[sl].xnext[i]);
+          }
+          if (isn || bad_number(mx)) {
+            L[sl].ok = 0;
+            alive[sl] = 0;
+          }
+        }
+      }
+      if (t < T) {
+        double* nxt = N + SM::OFF_IN + ((t + 1) & 1) * SM::NIN;
+#pragma unroll
+        for (int k = 0; k < SM::NPRE; ++k) {
+          const int i = lane + nl * k;
+          if (i < SM::NIN) nxt[i] = pre[sl][k];
+        }
+      }
+    });
+    ex.sync();
+  }
+  ex.each([&](int lane, int sl) {
+    if (lane >= NA) return;
+    const size_t slot = (size_t)b * NA + lane;
+    D.try_cost[slot] = L[sl].cost_try;
+    D.try_dv[slot] = L[sl].dv;
+    D.try_ok[slot] = L[sl].ok;
+  });
 }
 
 // =====================================================================================================================

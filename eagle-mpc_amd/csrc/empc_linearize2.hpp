@@ -51,6 +51,7 @@ struct Lin2Smem {
   static constexpr int OFF_G = OFF_MIJ + 3 * NV;
   static constexpr int OFF_CONE = OFF_G + 9;
   static constexpr int SIZE = (OFF_CONE + 25 + 1) / 2 * 2;
+  static constexpr int SIZE_NC = (OFF_LAM + 1) / 2 * 2;  // problems without contacts never touch the contact block
 };
 
 // forward kinematics + nominal Newton-Euler quantities of one unit, executed by ONE lane
@@ -486,8 +487,10 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
     } else if (lane < NU + DM::NJ) {
       const int j = lane - NU;
       const double th = N[SM::OFF_X + 7 + j];
-      N[SM::OFF_CS + j] = cos(th);
-      N[SM::OFF_SN + j] = sin(th);
+      double s_, c_;
+      fsincos(th, &s_, &c_);
+      N[SM::OFF_CS + j] = c_;
+      N[SM::OFF_SN + j] = s_;
     } else if (CT && lane == lpu - 2) {
       // contact force as a spatial force on the contact body (body coordinates): X_f^* [lambda; 0]
       if (use_contact) {
@@ -678,7 +681,7 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
     for (int j = 0; j < NV; ++j) {
       double s = M[j * NV + j];
       for (int k = 0; k < j; ++k) s -= M[j * NV + k] * M[j * NV + k];
-      const double inv = 1.0 / sqrt(s);
+      const double inv = frsqrt(s);
       M[j * NV + j] = inv;
       for (int i = j + 1; i < NV; ++i) {
         double tt = M[i * NV + j];

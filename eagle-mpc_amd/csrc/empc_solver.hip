@@ -20,6 +20,7 @@
 #include "empc_prep.hpp"
 #include "empc_linearize2.hpp"
 #include "empc_backward2.hpp"
+#include "empc_rollout2.hpp"
 
 using namespace empc;
 
@@ -51,10 +52,50 @@ __global__ void __launch_bounds__(64) k_rollout(DevBuffers D) {
   rollout_thread<DM, CT>(D, b, ai);
 }
 
-template <class DM, bool CT, int LPU>
-__global__ void __launch_bounds__(128) k_linearize(DevBuffers D) {
+// one wavefront per trajectory, lanes = step lengths, knot inputs and cost tables staged in LDS by the whole wave
+template <class DM, bool CT>
+__global__ void __launch_bounds__(64) k_rollout4(DevBuffers D) {
+  extern __shared__ double smem_roll4[];
+  LaneExec ex{(int)threadIdx.x};
+  rollout_wave<DM, CT>(ex, D, blockIdx.x, 64, smem_roll4);
+}
+
+// the shipped rollout: one wavefront per trajectory, lanes = step lengths, feedback product by the whole wave
+template <class DM, bool CT>
+__global__ void __launch_bounds__(64) k_rollout5(DevBuffers D) {
+  extern __shared__ double smem_roll5[];
+  static_assert(DM::NU <= 64, "feedback rows must fit one wavefront");
+  LaneExec ex{(int)threadIdx.x};
+  rollout_wave5<DM, CT>(ex, D, blockIdx.x, 64, smem_roll5);
+}
+
+// cooperative rollout: LPR lanes per (trajectory, step length) unit, 64 / LPR units per wavefront
+constexpr int EMPC_LPR = 16;
+static_assert(EMPC_LPR - 1 >= EMPC_MAX_COSTS, "one State-cost class / frame cost per lane");
+template <class DM, bool CT>
+__global__ void __launch_bounds__(64) k_rollout2(DevBuffers D) {
+  extern __shared__ double smem_roll[];
+  static_assert(DM::NV + 1 <= EMPC_LPR && DM::NU <= EMPC_LPR, "unit too narrow for this model");
+  constexpr int UPB = 64 / EMPC_LPR;
+  const int unit = blockIdx.x * UPB + threadIdx.x / EMPC_LPR;
+  if (unit >= D.B * D.NA) return;
+  const int b = unit / D.NA, ai = unit % D.NA;
+  LaneExec ex{(int)(threadIdx.x % EMPC_LPR)};
+  rollout_unit2<DM, CT>(ex, D, b, ai, EMPC_LPR, smem_roll + (size_t)(threadIdx.x / EMPC_LPR) * Roll2Smem<DM>::SIZE);
+}
+
+template <class DM, bool CT, int LPU, int BLK>
+// Two wavefronts per SIMD: at the compiler's own choice (326 registers, one wavefront per SIMD) the kernel sits at
+// ~1 resident wave per SIMD with 37 % of its time in waits; capping the budget at 256 registers costs ~250 spilled
+// values but doubles the resident waves: 2.02 -> 1.42 ms per launch (profiles/README.md).
+#ifndef EMPC_LIN_WAVES
+#define EMPC_LIN_WAVES 2
+#endif
+__global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(EMPC_LIN_WAVES, EMPC_LIN_WAVES)))
+k_linearize(DevBuffers D) {
   extern __shared__ double smem_lin[];
-  constexpr int UPB = 128 / LPU;  // units per block
+  constexpr int UPB = BLK / LPU;  // units per block
+  constexpr int USZ = CT ? Lin2Smem<DM>::SIZE : Lin2Smem<DM>::SIZE_NC;
   const int unit = blockIdx.x * UPB + threadIdx.x / LPU;
   const int lane = threadIdx.x % LPU;
   const int n_units = D.B * (D.T + 1);
@@ -63,7 +104,7 @@ __global__ void __launch_bounds__(128) k_linearize(DevBuffers D) {
   const TrajState& st = D.st[b];
   if (st.phase == PHASE_DONE || !st.need_lin) return;
   LaneExec ex{lane};
-  linearize_unit2<DM, CT>(ex, D, b, t, LPU, smem_lin + (size_t)(threadIdx.x / LPU) * Lin2Smem<DM>::SIZE);
+  linearize_unit2<DM, CT>(ex, D, b, t, LPU, smem_lin + (size_t)(threadIdx.x / LPU) * USZ);
 }
 
 // workgroup-wide executor: barriers are real workgroup barriers
@@ -175,13 +216,39 @@ static void launch_calc(DevBuffers D, hipStream_t s) {
   const int n = D.B * (D.T + 1);
   hipLaunchKernelGGL((k_calc<DM, CT>), dim3((n + 63) / 64), dim3(64), 0, s, D);
 }
+template <class DM, bool CT, int BLK>
+static void launch_linearize_blk(DevBuffers D, hipStream_t s) {
+  constexpr int LPU = (3 * DM::NV <= 32) ? 32 : 64;
+  constexpr int UPB = BLK / LPU;
+  constexpr int USZ = CT ? Lin2Smem<DM>::SIZE : Lin2Smem<DM>::SIZE_NC;
+  const int n = D.B * (D.T + 1);
+  const size_t smem = sizeof(double) * USZ * UPB;
+  static const bool once = [&] {
+    if (getenv("EMPC_DEBUG_OCC")) {
+      int nb = -1;
+      hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_linearize<DM, CT, LPU, BLK>, BLK, smem);
+      hipFuncAttributes fa;
+      hipError_t e2 = hipFuncGetAttributes(&fa, (const void*)k_linearize<DM, CT, LPU, BLK>);
+      fprintf(stderr, "[empc] k_linearize BLK=%d dyn smem=%zu B: max active blocks/CU=%d (%s); regs=%d static smem=%zu local=%zu (%s)\n", BLK,
+              smem, nb, hipGetErrorString(e), fa.numRegs, fa.sharedSizeBytes, fa.localSizeBytes, hipGetErrorString(e2));
+    }
+    return true;
+  }();
+  (void)once;
+  hipLaunchKernelGGL((k_linearize<DM, CT, LPU, BLK>), dim3((n + UPB - 1) / UPB), dim3(BLK), smem, s, D);
+}
 template <class DM, bool CT>
 static void launch_linearize(DevBuffers D, hipStream_t s) {
-  constexpr int LPU = (3 * DM::NV <= 32) ? 32 : 64;
-  constexpr int UPB = 128 / LPU;
-  const int n = D.B * (D.T + 1);
-  const size_t smem = sizeof(double) * Lin2Smem<DM>::SIZE * UPB;
-  hipLaunchKernelGGL((k_linearize<DM, CT, LPU>), dim3((n + UPB - 1) / UPB), dim3(128), smem, s, D);
+  static const int blk = [] {
+    const char* e = getenv("EMPC_LIN_BLOCK");
+    return e ? atoi(e) : 128;
+  }();
+  if (blk == 64)
+    launch_linearize_blk<DM, CT, 64>(D, s);
+  else if (blk == 256)
+    launch_linearize_blk<DM, CT, 256>(D, s);
+  else
+    launch_linearize_blk<DM, CT, 128>(D, s);
 }
 template <class DM>
 static void launch_backward(DevBuffers D, hipStream_t s) {
@@ -190,7 +257,27 @@ static void launch_backward(DevBuffers D, hipStream_t s) {
 template <class DM, bool CT>
 static void launch_rollout(DevBuffers D, hipStream_t s) {
   const int n = D.B * D.NA;
-  hipLaunchKernelGGL((k_rollout<DM, CT>), dim3((n + 63) / 64), dim3(64), 0, s, D);
+#ifdef EMPC_ABL
+  {
+    const char* e = getenv("EMPC_ABL");
+    int v = e ? atoi(e) : 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_abl), &v, sizeof(int));
+  }
+#endif
+  static const int version = [] {
+    const char* e = getenv("EMPC_ROLLOUT");
+    return e ? atoi(e) : 5;
+  }();
+  if (version == 1) {
+    hipLaunchKernelGGL((k_rollout<DM, CT>), dim3((n + 63) / 64), dim3(64), 0, s, D);
+  } else if (version == 5 && D.NA <= MAX_ALPHAS) {
+    hipLaunchKernelGGL((k_rollout5<DM, CT>), dim3(D.B), dim3(64), sizeof(double) * Roll5Smem<DM>::SIZE, s, D);
+  } else if (version == 4 && D.NA <= 64) {
+    hipLaunchKernelGGL((k_rollout4<DM, CT>), dim3(D.B), dim3(64), sizeof(double) * Roll4Smem<DM>::SIZE, s, D);
+  } else {
+    constexpr int UPB = 64 / EMPC_LPR;
+    hipLaunchKernelGGL((k_rollout2<DM, CT>), dim3((n + UPB - 1) / UPB), dim3(64), sizeof(double) * Roll2Smem<DM>::SIZE * UPB, s, D);
+  }
 }
 template <class DM>
 static void launch_select(DevBuffers D, hipStream_t s) {

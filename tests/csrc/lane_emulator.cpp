@@ -9,6 +9,7 @@
 #include "../../eagle-mpc_amd/csrc/empc_prep.hpp"
 #include "../../eagle-mpc_amd/csrc/empc_linearize2.hpp"
 #include "../../eagle-mpc_amd/csrc/empc_backward2.hpp"
+#include "../../eagle-mpc_amd/csrc/empc_rollout2.hpp"
 
 using namespace empc;
 
@@ -143,11 +144,50 @@ static void emu_backward(Emu& e) {
     }
   }
 }
+static int g_roll_version = 2;
 template <class DM>
 static void emu_rollout(Emu& e) {
   const bool ct = e.H.P.has_contact != 0;
+  std::vector<double> smem(Roll2Smem<DM>::SIZE);
   for (int b = 0; b < e.B; ++b)
     for (int ai = 0; ai < e.NA; ++ai) {
+      if (g_roll_version == 5) {
+        if (ai > 0) continue;  // one call per trajectory: the 64 lanes cover every step length
+        std::vector<double> smem5(Roll5Smem<DM>::SIZE);
+        CpuExec<64> ex{64};
+        if constexpr (DM::NB == 4) {
+          if (ct) {
+            rollout_wave5<DM, true>(ex, e.D, b, 64, smem5.data());
+            continue;
+          }
+        }
+        rollout_wave5<DM, false>(ex, e.D, b, 64, smem5.data());
+        continue;
+      }
+      if (g_roll_version == 4) {
+        if (ai > 0) continue;  // one call per trajectory: the 64 lanes cover every step length
+        std::vector<double> smem4(Roll4Smem<DM>::SIZE);
+        CpuExec<64> ex{64};
+        if constexpr (DM::NB == 4) {
+          if (ct) {
+            rollout_wave<DM, true>(ex, e.D, b, 64, smem4.data());
+            continue;
+          }
+        }
+        rollout_wave<DM, false>(ex, e.D, b, 64, smem4.data());
+        continue;
+      }
+      if (g_roll_version == 2) {
+        CpuExec<64> ex{16};  // the shipped cooperative form: 16 lanes per (trajectory, step length)
+        if constexpr (DM::NB == 4) {
+          if (ct) {
+            rollout_unit2<DM, true>(ex, e.D, b, ai, 16, smem.data());
+            continue;
+          }
+        }
+        rollout_unit2<DM, false>(ex, e.D, b, ai, 16, smem.data());
+        continue;
+      }
       if constexpr (DM::NB == 4) {
         if (ct) {
           rollout_thread<DM, true>(e.D, b, ai);
@@ -197,6 +237,7 @@ static void emu_solve(Emu& e, int maxiter, int is_feasible) {
 extern "C" {
 void emu_set_linearize_version(int v) { g_lin_version = v; }
 void emu_set_backward_version(int v) { g_bwd_version = v; }
+void emu_set_rollout_version(int v) { g_roll_version = v; }
 
 void* emu_create(const EmpcProblemDesc* d, const EmpcSolverParams* prm, int B) {
   Emu* e = new Emu();

@@ -41,4 +41,4 @@ import ctypes as C
 cnt = (C.c_ulonglong * 24)()
 empc.lib().empc_solver_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
 empc.lib().empc_solver_debug_counters(s._h, cnt, 24)
-print('backward stage cycles (traj 0, whole sweep):', list(cnt))
+print('stage cycles (EMPC_STAMPS builds; rollout v1, trajectory 0, alpha 1/2): feedback|prep|rnea|crba|chol|kkt|euler|costs|-|tail', list(cnt)[:10])

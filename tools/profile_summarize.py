@@ -74,8 +74,39 @@ def traffic(fetch_dir, write_dir, tag):
         print(json.dumps(out))
 
 
+def sq(dirs, out):
+    """Per-kernel means of every counter found in the given --pmc passes (one row per kernel)."""
+    table = collections.defaultdict(dict)
+    for d in dirs:
+        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        if not files:
+            raise SystemExit("no *counter_collection.csv under " + d)
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        meta = {}
+        for r in csv.DictReader(open(files[0])):
+            k = short(r["Kernel_Name"])
+            agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            meta[k] = (r["VGPR_Count"], r["Accum_VGPR_Count"], r["SGPR_Count"], r["LDS_Block_Size"], r["Workgroup_Size"], r["Grid_Size"])
+        for k in agg:
+            if k not in KERNELS:
+                continue
+            table[k].update({c: sum(v) / len(v) for c, v in agg[k].items()})
+            table[k].update(dict(zip(("VGPR", "AGPR", "SGPR", "LDS", "WG", "GRID"), meta[k])))
+    cols = sorted({c for k in table for c in table[k]})
+    with open(out, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel"] + cols)
+        for k in table:
+            w.writerow([k] + [("%.6g" % table[k][c]) if isinstance(table[k].get(c), float) else table[k].get(c, "") for c in cols])
+    for k in table:
+        t = table[k]
+        print(k, {c: (("%.4g" % t[c]) if isinstance(t[c], float) else t[c]) for c in cols if c in t})
+
+
 if __name__ == "__main__":
-    if len(sys.argv) >= 4 and sys.argv[1] == "stats":
+    if len(sys.argv) >= 4 and sys.argv[1] == "sq":
+        sq(sys.argv[3:], sys.argv[2])
+    elif len(sys.argv) >= 4 and sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
     elif len(sys.argv) >= 5 and sys.argv[1] == "traffic":
         traffic(sys.argv[2], sys.argv[3], sys.argv[4])
