@@ -271,7 +271,7 @@ EMPC_HD void quat_exp3(const double* w, double* q) {
   double k, sh, ch;
   fsincos(0.5 * t, &sh, &ch);
   if (t < 1e-4)
-    k = 0.5 - t2 / 48.0 + t2 * t2 / 3840.0;
+    k = 0.5 - t2 * (1.0 / 48.0) + t2 * t2 * (1.0 / 3840.0);
   else
     k = fdiv(sh, t);
   q[0] = k * w[0];
@@ -347,12 +347,13 @@ struct SO3Coef {
 EMPC_HD void so3_coef_half(double t2, double t, double sh, double ch, SO3Coef& k) {
   if (t < 1e-2) {
     const double t4 = t2 * t2;
-    k.a = 1.0 - t2 / 6.0 + t4 / 120.0 - t4 * t2 / 5040.0;
-    k.b = 0.5 - t2 / 24.0 + t4 / 720.0 - t4 * t2 / 40320.0;
-    k.c = 1.0 / 6.0 - t2 / 120.0 + t4 / 5040.0 - t4 * t2 / 362880.0;
-    k.e = 1.0 / 12.0 + t2 / 720.0 + t4 / 30240.0 + t4 * t2 / 1209600.0;
-    k.al = 1.0 - t2 / 12.0 - t4 / 720.0 - t4 * t2 / 30240.0;
-    k.bdot = 1.0 / 360.0 + t2 / 7560.0 + t4 / 201600.0;
+    const double t6 = t4 * t2;  // series coefficients as reciprocal constants: no divisions on this branch
+    k.a = 1.0 - t2 * (1.0 / 6.0) + t4 * (1.0 / 120.0) - t6 * (1.0 / 5040.0);
+    k.b = 0.5 - t2 * (1.0 / 24.0) + t4 * (1.0 / 720.0) - t6 * (1.0 / 40320.0);
+    k.c = 1.0 / 6.0 - t2 * (1.0 / 120.0) + t4 * (1.0 / 5040.0) - t6 * (1.0 / 362880.0);
+    k.e = 1.0 / 12.0 + t2 * (1.0 / 720.0) + t4 * (1.0 / 30240.0) + t6 * (1.0 / 1209600.0);
+    k.al = 1.0 - t2 * (1.0 / 12.0) - t4 * (1.0 / 720.0) - t6 * (1.0 / 30240.0);
+    k.bdot = 1.0 / 360.0 + t2 * (1.0 / 7560.0) + t4 * (1.0 / 201600.0);
   } else {
     const double st = 2.0 * sh * ch;
     const double it = frcp(t), it2 = it * it;

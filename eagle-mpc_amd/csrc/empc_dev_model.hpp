@@ -305,11 +305,11 @@ EMPC_HD void crba_chain(const EMPC_K EmpcModelDesc& m, const double* cs, const d
 #pragma unroll
       for (int j = 0; j < 3; ++j)
         I2[3 * i + j] = RI[3 * i] * XR[b][3 * j] + RI[3 * i + 1] * XR[b][3 * j + 1] + RI[3 * i + 2] * XR[b][3 * j + 2];
-    const double m1 = cm[b - 1], m2 = cm[b], Mt = m1 + m2;
+    const double m1 = cm[b - 1], m2 = cm[b], Mt = m1 + m2, iMt = frcp(Mt);
     double cn[3], d1[3], d2[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      cn[i] = (m1 * cc[b - 1][i] + m2 * c2[i]) / Mt;
+      cn[i] = (m1 * cc[b - 1][i] + m2 * c2[i]) * iMt;
       d1[i] = cc[b - 1][i] - cn[i];
       d2[i] = c2[i] - cn[i];
     }
@@ -421,7 +421,7 @@ template <class CostT>
 EMPC_HD double act_weight(const CostT& c, int i, double smooth, const EMPC_K DevProblem& P) {
   if (c.is_barrier) {
     const double aux = smooth * (P.u_ub[i] - P.u_lb[i]);
-    return 1.0 / (aux * aux);
+    return frcp(aux * aux);
   }
   return c.act_w[i];
 }
@@ -477,7 +477,7 @@ EMPC_HD double control_cost_value(const CostT& c, const double* s, double smooth
 #pragma unroll
   for (int i = 0; i < NU; ++i) {
     const double aux = smooth * (P.u_ub[i] - P.u_lb[i]);
-    w[i] = 1.0 / (aux * aux);
+    w[i] = frcp(aux * aux);
     lb[i] = c.lb[i];
     ub[i] = c.ub[i];
   }
@@ -576,16 +576,6 @@ EMPC_HD void cone_rows(const double* nsurf, double mu, double AR[5][3]) {
 // Outputs: xnext[NX], acc[NV] (generalized acceleration, reused by linearize), cost, usq[NU] (squashed control),
 //          lam[6] (contact force).
 // ---------------------------------------------------------------------------------------------------------
-#ifdef EMPC_ABL
-#if defined(__HIPCC__)
-__device__ int g_abl;
-#define ABL(bit) (g_abl & (bit))
-#else
-#define ABL(bit) 0
-#endif
-#else
-#define ABL(bit) 0
-#endif
 // diagnostic builds (-DEMPC_STAMPS): cycle counter deltas per section, accumulated in a caller-provided array
 #if defined(EMPC_STAMPS) && defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
 #define EMPC_STAMP(i)                                               \
@@ -613,16 +603,25 @@ EMPC_HD void node_nominal(const EMPC_K DevProblem& P, const SetT& set, double sm
   double s[NU], u[NU];
 #pragma unroll
   for (int i = 0; i < NU; ++i) s[i] = terminal ? 0.0 : s_in[i];
+  if (P.use_squash) {  // one uniform branch, then straight-line code: the bound loads of all controls go out together
+    double lbv[NU], ubv[NU];
+    const int power = P.prm.smoothsat_power;
 #pragma unroll
-  for (int i = 0; i < NU; ++i) {
-    if (P.use_squash) {
-      double du;
-      squash1(s[i], P.u_lb[i], P.u_ub[i], smooth, P.prm.smoothsat_power, u[i], du);
-    } else {
-      u[i] = s[i];
+    for (int i = 0; i < NU; ++i) {
+      lbv[i] = P.u_lb[i];
+      ubv[i] = P.u_ub[i];
     }
-    usq[i] = u[i];
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+      double du;
+      squash1(s[i], lbv[i], ubv[i], smooth, power, u[i], du);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NU; ++i) u[i] = s[i];
   }
+#pragma unroll
+  for (int i = 0; i < NU; ++i) usq[i] = u[i];
   double tau[NV];
 #pragma unroll
   for (int r = 0; r < 6; ++r) {
@@ -664,15 +663,13 @@ EMPC_HD void node_nominal(const EMPC_K DevProblem& P, const SetT& set, double sm
   double zero[NV], h[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) zero[i] = 0.0;
-  if (!ABL(4)) rnea_chain<NB, double>(m, R0, q, cs, sn, v, zero, true, -1, nullptr, h, ncap, capf, caps);
-  else for (int i = 0; i < NV; ++i) h[i] = 0;
+  rnea_chain<NB, double>(m, R0, q, cs, sn, v, zero, true, -1, nullptr, h, ncap, capf, caps);
   EMPC_STAMP(2);  // RNEA bias
   // joint-space inertia (packed lower triangle) by the composite-rigid-body algorithm
   double L[DM::NTRI];
-  if (!ABL(8)) crba_chain<NB>(m, cs, sn, L);
-  else for (int i = 0; i < DM::NTRI; ++i) L[i] = (i % 7 == 0) ? 1.0 + i : 0.01;
+  crba_chain<NB>(m, cs, sn, L);
   EMPC_STAMP(3);  // CRBA
-  if (!ABL(16)) chol_packed<NV>(L);
+  chol_packed<NV>(L);
   double a[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) a[i] = tau[i] - h[i];
@@ -760,15 +757,14 @@ EMPC_HD void node_nominal(const EMPC_K DevProblem& P, const SetT& set, double sm
     dxe[NV + i] = a[i] * dt;
   }
   EMPC_STAMP(5);  // contact KKT
-  if (!ABL(32)) state_integrate<DM>(x, dxe, xnext, nullptr);
-  else for (int i = 0; i < DM::NX; ++i) xnext[i] = x[i];
+  state_integrate<DM>(x, dxe, xnext, nullptr);
   EMPC_STAMP(6);  // Euler step
 
   // costs (A.6)
   double ell = 0;
   double rstate[DM::NDX];  // residual of the most recent State cost (shared between costs with one reference)
   int rstate_of = -1;
-  for (int ci = 0; ci < (ABL(1) ? 0 : set.ncosts); ++ci) {
+  for (int ci = 0; ci < set.ncosts; ++ci) {
     const auto& c = set.costs[ci];
     if (!c.active) continue;
     double cval = 0;

@@ -116,7 +116,7 @@ struct RollLane {
 };
 
 // One knot of the forward pass for one trial.  The knot's nominal data comes through typed pointers so that the same
-// body serves per-lane global reads (k_rollout) and wave-shared LDS staging (k_rollout4).  Returns false when the trial
+// body serves any placement of that data (k_rollout reads it per lane from global memory).  Returns false when the trial
 // failed (NaN / overflow, crocoddyl's raiseIfNaN) and the caller must stop.
 template <class DM, bool CT, class SetT, class PX, class PU, class PK, class PG>
 EMPC_HD bool rollout_knot(const EMPC_K DevProblem& P, const SetT& set, RollLane<DM>& L, int t, int T, bool plain, bool need_dv,
@@ -134,8 +134,7 @@ EMPC_HD bool rollout_knot(const EMPC_K DevProblem& P, const SetT& set, RollLane<
     for (int i = 0; i < NDX; ++i) step[i] = gap[i] * (alpha - 1.0);
     state_integrate<DM>(L.xnext, step, xtry, nullptr);
   }
-  if (!ABL(2)) state_diff<DM>(xc, xtry, dx, nullptr);
-  else for (int i = 0; i < NDX; ++i) dx[i] = 0.001 * i;
+  state_diff<DM>(xc, xtry, dx, nullptr);
   if (need_dv) {
     double dv = L.dv;
 #pragma unroll
@@ -147,10 +146,8 @@ EMPC_HD bool rollout_knot(const EMPC_K DevProblem& P, const SetT& set, RollLane<
 #pragma unroll
     for (int i = 0; i < NU; ++i) {
       double a_ = uc[i] - kk[i] * alpha;
-      if (!ABL(64)) {
 #pragma unroll
       for (int j = 0; j < NDX; ++j) a_ -= KK[i * NDX + j] * dx[j];
-      }
       utry[i] = a_;
     }
     EMPC_STAMP(0);  // x_try, state difference, feedback
@@ -161,10 +158,8 @@ EMPC_HD bool rollout_knot(const EMPC_K DevProblem& P, const SetT& set, RollLane<
     double xn2[NX];
     node_nominal<DM, CT>(P, set, smooth, xtry, (const double*)nullptr, true, xn2, acc, cost, usq, lam, stp);
   }
-  if (!ABL(128)) {
 #pragma unroll
   for (int i = 0; i < NX; ++i) xs_o[(size_t)t * NX + i] = xtry[i];
-  }
 #pragma unroll
   for (int i = 0; i < NV; ++i) ac_o[(size_t)t * DM::NACC + i] = acc[i];
 #pragma unroll
@@ -239,139 +234,6 @@ EMPC_HD void rollout_thread(const DevBuffers& D, int b, int ai) {
   if (stp)
     for (int i = 0; i < 16; ++i) D.dbg[i] = stamps[i];
 #endif
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// rollout, wave-shared staging: one wavefront per trajectory, lanes 0..NA-1 = step lengths.  Everything a knot reads that
-// does not depend on the step length -- xs[t], us[t], k[t], K[t], the gap, Vxx f and the knot's cost tables -- is
-// identical for the lanes of the wave, so all 64 lanes fetch it together (coalesced, one knot ahead, through registers)
-// into LDS and the trial lanes read it back as LDS broadcasts.  Per-lane vector loads of the same addresses and the
-// dependent scalar loads of the cost tables were ~55 % of the per-lane form's time (profiles/).
-// ---------------------------------------------------------------------------------------------------------------------
-template <class DM>
-struct Roll4Smem {
-  static constexpr int NX = DM::NX, NU = DM::NU, NDX = DM::NDX;
-  static constexpr int IN_K = 0;                       // K[t]  NU x NDX
-  static constexpr int IN_X = IN_K + NU * NDX;         // xs[t]
-  static constexpr int IN_U = IN_X + NX;               // us[t]
-  static constexpr int IN_KFF = IN_U + NU;             // k[t]
-  static constexpr int IN_GAP = IN_KFF + NU;           // fs[t]
-  static constexpr int IN_VF = IN_GAP + NDX;           // Vxx[t] fs[t]
-  static constexpr int NIN = IN_VF + NDX;
-  static constexpr int NPRE = (NIN + 63) / 64;         // prefetch registers per lane
-  static constexpr int SET_DOUBLES = (int)(sizeof(EmpcCostSet) / sizeof(double));
-  static_assert(sizeof(EmpcCostSet) % sizeof(double) == 0, "cost set must be a whole number of doubles");
-  static constexpr int OFF_SET = 0;
-  static constexpr int OFF_IN = OFF_SET + SET_DOUBLES;  // two buffers of NIN
-  static constexpr int SIZE = (OFF_IN + 2 * NIN + 1) / 2 * 2;
-};
-
-template <class DM, bool CT, class Exec>
-EMPC_HD void rollout_wave(Exec& ex, const DevBuffers& D, int b, int nl, double* N) {
-  typedef Roll4Smem<DM> SM;
-  const TrajState& st = D.st[b];
-  if (st.phase == PHASE_DONE || st.bwd_failed) return;
-  constexpr int NX = DM::NX, NU = DM::NU, NDX = DM::NDX, REC = DM::REC;
-  const EMPC_K DevProblem& P = EMPC_KREF(DevProblem, D.P);
-  const int T = D.T, NA = D.NA;
-  const bool ddp = (st.phase == PHASE_DDP);
-  const bool feas = st.is_feasible != 0;
-  const double smooth = st.smooth;
-  RollLane<DM> L[Exec::SLOTS];
-  double pre[Exec::SLOTS][SM::NPRE];
-  int alive[Exec::SLOTS];
-#if defined(EMPC_STAMPS) && defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
-  unsigned long long stamps[32];
-  for (int i = 0; i < 32; ++i) stamps[i] = 0;
-  stamps[31] = __builtin_readcyclecounter();
-#endif
-
-  // element i of the staged input block of knot t
-  auto fetch = [&](int t, int i) -> double {
-    const int tt = (t < T) ? t : 0;
-    if (i < SM::IN_X) return (t < T) ? D.K[((size_t)b * T + tt) * NU * NDX + i] : 0.0;
-    if (i < SM::IN_U) return D.xs[((size_t)b * (T + 1) + t) * NX + (i - SM::IN_X)];
-    if (i < SM::IN_KFF) return (t < T) ? D.us[((size_t)b * T + tt) * NU + (i - SM::IN_U)] : 0.0;
-    if (i < SM::IN_GAP) return (t < T) ? D.kff[((size_t)b * T + tt) * NU + (i - SM::IN_KFF)] : 0.0;
-    if (i < SM::IN_VF) return D.tape[((size_t)b * (T + 1) + t) * REC + DM::OFF_GAP + (i - SM::IN_GAP)];
-    return D.Vf[((size_t)b * (T + 1) + t) * NDX + (i - SM::IN_VF)];
-  };
-  int cur_set = -1;
-  ex.each([&](int lane, int sl) {
-#pragma unroll
-    for (int i = 0; i < NX; ++i) L[sl].xnext[i] = D.x0[(size_t)b * NX + i];
-    L[sl].cost_try = 0;
-    L[sl].dv = 0;
-    L[sl].ok = 1;
-    alive[sl] = (lane < NA) ? 1 : 0;
-#pragma unroll
-    for (int k = 0; k < SM::NPRE; ++k) {
-      const int i = lane + nl * k;
-      if (i < SM::NIN) N[SM::OFF_IN + i] = fetch(0, i);
-    }
-  });
-  ex.sync();
-  for (int t = 0; t <= T; ++t) {
-    const int si = EMPC_KPTR(int, D.knot_set)[t];
-    if (si != cur_set) {  // uniform: stage this knot's cost tables
-      const double* src = reinterpret_cast<const double*>(D.sets + si);
-      ex.each([&](int lane, int sl) {
-        for (int i = lane; i < SM::SET_DOUBLES; i += nl) N[SM::OFF_SET + i] = src[i];
-      });
-      ex.sync();
-      cur_set = si;
-    }
-    const double* in = N + SM::OFF_IN + (t & 1) * SM::NIN;
-    const EmpcCostSet& set = *reinterpret_cast<const EmpcCostSet*>(N + SM::OFF_SET);
-    ex.each([&](int lane, int sl) {
-      // next knot's inputs on their way while this knot is computed
-      if (t < T) {
-#pragma unroll
-        for (int k = 0; k < SM::NPRE; ++k) {
-          const int i = lane + nl * k;
-          pre[sl][k] = (i < SM::NIN) ? fetch(t + 1, i) : 0.0;
-        }
-      }
-      if (alive[sl]) {
-        const int ai = lane;
-        const double alpha = ldexp(1.0, -ai);
-        const bool plain = ddp || feas || (ai == 0);
-        const size_t slot = (size_t)b * NA + ai;
-        double* xs_o = D.xs_try + slot * (T + 1) * NX;
-        double* us_o = D.us_try + slot * T * NU;
-        double* ac_o = D.acc_try + slot * (T + 1) * DM::NACC;
-        if (!rollout_knot<DM, CT>(P, set, L[sl], t, T, plain, !ddp && !feas, alpha, smooth, in + SM::IN_X, in + SM::IN_U,
-                                  in + SM::IN_KFF, in + SM::IN_K, in + SM::IN_GAP, in + SM::IN_VF, xs_o, us_o, ac_o,
-#if defined(EMPC_STAMPS) && defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
-                                  (b == 0 && lane == 1) ? stamps : (unsigned long long*)nullptr
-#else
-                                  (unsigned long long*)nullptr
-#endif
-                                  ))
-          alive[sl] = 0;
-      }
-      if (t < T) {
-        double* nxt = N + SM::OFF_IN + ((t + 1) & 1) * SM::NIN;
-#pragma unroll
-        for (int k = 0; k < SM::NPRE; ++k) {
-          const int i = lane + nl * k;
-          if (i < SM::NIN) nxt[i] = pre[sl][k];
-        }
-      }
-    });
-    ex.sync();
-  }
-  ex.each([&](int lane, int sl) {
-#if defined(EMPC_STAMPS) && defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
-    if (b == 0 && lane == 1)
-      for (int i = 0; i < 16; ++i) D.dbg[i] = stamps[i];
-#endif
-    if (lane >= NA) return;
-    const size_t slot = (size_t)b * NA + lane;
-    D.try_cost[slot] = L[sl].cost_try;
-    D.try_dv[slot] = L[sl].dv;
-    D.try_ok[slot] = L[sl].ok;
-  });
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -20,7 +20,6 @@
 #include "empc_prep.hpp"
 #include "empc_linearize2.hpp"
 #include "empc_backward2.hpp"
-#include "empc_rollout2.hpp"
 
 using namespace empc;
 
@@ -52,14 +51,6 @@ __global__ void __launch_bounds__(64) k_rollout(DevBuffers D) {
   rollout_thread<DM, CT>(D, b, ai);
 }
 
-// one wavefront per trajectory, lanes = step lengths, knot inputs and cost tables staged in LDS by the whole wave
-template <class DM, bool CT>
-__global__ void __launch_bounds__(64) k_rollout4(DevBuffers D) {
-  extern __shared__ double smem_roll4[];
-  LaneExec ex{(int)threadIdx.x};
-  rollout_wave<DM, CT>(ex, D, blockIdx.x, 64, smem_roll4);
-}
-
 // the shipped rollout: one wavefront per trajectory, lanes = step lengths, feedback product by the whole wave
 template <class DM, bool CT>
 __global__ void __launch_bounds__(64) k_rollout5(DevBuffers D) {
@@ -67,21 +58,6 @@ __global__ void __launch_bounds__(64) k_rollout5(DevBuffers D) {
   static_assert(DM::NU <= 64, "feedback rows must fit one wavefront");
   LaneExec ex{(int)threadIdx.x};
   rollout_wave5<DM, CT>(ex, D, blockIdx.x, 64, smem_roll5);
-}
-
-// cooperative rollout: LPR lanes per (trajectory, step length) unit, 64 / LPR units per wavefront
-constexpr int EMPC_LPR = 16;
-static_assert(EMPC_LPR - 1 >= EMPC_MAX_COSTS, "one State-cost class / frame cost per lane");
-template <class DM, bool CT>
-__global__ void __launch_bounds__(64) k_rollout2(DevBuffers D) {
-  extern __shared__ double smem_roll[];
-  static_assert(DM::NV + 1 <= EMPC_LPR && DM::NU <= EMPC_LPR, "unit too narrow for this model");
-  constexpr int UPB = 64 / EMPC_LPR;
-  const int unit = blockIdx.x * UPB + threadIdx.x / EMPC_LPR;
-  if (unit >= D.B * D.NA) return;
-  const int b = unit / D.NA, ai = unit % D.NA;
-  LaneExec ex{(int)(threadIdx.x % EMPC_LPR)};
-  rollout_unit2<DM, CT>(ex, D, b, ai, EMPC_LPR, smem_roll + (size_t)(threadIdx.x / EMPC_LPR) * Roll2Smem<DM>::SIZE);
 }
 
 template <class DM, bool CT, int LPU, int BLK>
@@ -257,26 +233,14 @@ static void launch_backward(DevBuffers D, hipStream_t s) {
 template <class DM, bool CT>
 static void launch_rollout(DevBuffers D, hipStream_t s) {
   const int n = D.B * D.NA;
-#ifdef EMPC_ABL
-  {
-    const char* e = getenv("EMPC_ABL");
-    int v = e ? atoi(e) : 0;
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_abl), &v, sizeof(int));
-  }
-#endif
   static const int version = [] {
-    const char* e = getenv("EMPC_ROLLOUT");
+    const char* e = getenv("EMPC_ROLLOUT");  // 1 = per-lane form (also the fallback for more than MAX_ALPHAS step lengths)
     return e ? atoi(e) : 5;
   }();
-  if (version == 1) {
+  if (version == 1 || D.NA > MAX_ALPHAS) {
     hipLaunchKernelGGL((k_rollout<DM, CT>), dim3((n + 63) / 64), dim3(64), 0, s, D);
-  } else if (version == 5 && D.NA <= MAX_ALPHAS) {
-    hipLaunchKernelGGL((k_rollout5<DM, CT>), dim3(D.B), dim3(64), sizeof(double) * Roll5Smem<DM>::SIZE, s, D);
-  } else if (version == 4 && D.NA <= 64) {
-    hipLaunchKernelGGL((k_rollout4<DM, CT>), dim3(D.B), dim3(64), sizeof(double) * Roll4Smem<DM>::SIZE, s, D);
   } else {
-    constexpr int UPB = 64 / EMPC_LPR;
-    hipLaunchKernelGGL((k_rollout2<DM, CT>), dim3((n + UPB - 1) / UPB), dim3(64), sizeof(double) * Roll2Smem<DM>::SIZE * UPB, s, D);
+    hipLaunchKernelGGL((k_rollout5<DM, CT>), dim3(D.B), dim3(64), sizeof(double) * Roll5Smem<DM>::SIZE, s, D);
   }
 }
 template <class DM>

@@ -9,7 +9,6 @@
 #include "../../eagle-mpc_amd/csrc/empc_prep.hpp"
 #include "../../eagle-mpc_amd/csrc/empc_linearize2.hpp"
 #include "../../eagle-mpc_amd/csrc/empc_backward2.hpp"
-#include "../../eagle-mpc_amd/csrc/empc_rollout2.hpp"
 
 using namespace empc;
 
@@ -144,11 +143,10 @@ static void emu_backward(Emu& e) {
     }
   }
 }
-static int g_roll_version = 2;
+static int g_roll_version = 5;
 template <class DM>
 static void emu_rollout(Emu& e) {
   const bool ct = e.H.P.has_contact != 0;
-  std::vector<double> smem(Roll2Smem<DM>::SIZE);
   for (int b = 0; b < e.B; ++b)
     for (int ai = 0; ai < e.NA; ++ai) {
       if (g_roll_version == 5) {
@@ -162,30 +160,6 @@ static void emu_rollout(Emu& e) {
           }
         }
         rollout_wave5<DM, false>(ex, e.D, b, 64, smem5.data());
-        continue;
-      }
-      if (g_roll_version == 4) {
-        if (ai > 0) continue;  // one call per trajectory: the 64 lanes cover every step length
-        std::vector<double> smem4(Roll4Smem<DM>::SIZE);
-        CpuExec<64> ex{64};
-        if constexpr (DM::NB == 4) {
-          if (ct) {
-            rollout_wave<DM, true>(ex, e.D, b, 64, smem4.data());
-            continue;
-          }
-        }
-        rollout_wave<DM, false>(ex, e.D, b, 64, smem4.data());
-        continue;
-      }
-      if (g_roll_version == 2) {
-        CpuExec<64> ex{16};  // the shipped cooperative form: 16 lanes per (trajectory, step length)
-        if constexpr (DM::NB == 4) {
-          if (ct) {
-            rollout_unit2<DM, true>(ex, e.D, b, ai, 16, smem.data());
-            continue;
-          }
-        }
-        rollout_unit2<DM, false>(ex, e.D, b, ai, 16, smem.data());
         continue;
       }
       if constexpr (DM::NB == 4) {

@@ -57,7 +57,7 @@ def candidate(d, seed):
     return xs, us
 
 
-@pytest.mark.parametrize("lin,bwd,roll", [(2, 2, 5), (2, 1, 1), (2, 1, 4), (2, 1, 2)])
+@pytest.mark.parametrize("lin,bwd,roll", [(2, 2, 5), (2, 1, 1)])
 @pytest.mark.parametrize("name", ["hover", "displacement", "push_slide", "eagle_catch"])
 def test_kernel_bodies_vs_oracle(empc, problems, emu, name, lin, bwd, roll):
     _, problem = problems[name]

@@ -42,3 +42,4 @@ cnt = (C.c_ulonglong * 24)()
 empc.lib().empc_solver_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
 empc.lib().empc_solver_debug_counters(s._h, cnt, 24)
 print('stage cycles (EMPC_STAMPS builds; rollout v1, trajectory 0, alpha 1/2): feedback|prep|rnea|crba|chol|kkt|euler|costs|-|tail', list(cnt)[:10])
+
