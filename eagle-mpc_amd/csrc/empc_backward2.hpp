@@ -38,6 +38,10 @@ EMPC_HD void backward_traj2(Exec& ex, const DevBuffers& D, int b, double* smem) 
   constexpr int CWE = (nm <= 32) ? 32 : 64; // ... or 64 lanes for the largest robots
   constexpr int NG = NL / CWE;              // row groups
   constexpr int PRE = (REC + NL - 1) / NL;  // prefetch registers per lane
+#ifndef EMPC_BWD_RP
+#define EMPC_BWD_RP 2
+#endif
+  constexpr int RP = EMPC_BWD_RP;           // rows per pass of the product stages
   (void)CW;
   TrajState& st = D.st[b];
   if (st.phase == PHASE_DONE) return;
@@ -163,11 +167,24 @@ EMPC_HD void backward_traj2(Exec& ex, const DevBuffers& D, int b, double* smem) 
         double Acol[n];
 #pragma unroll
         for (int k2 = 0; k2 < n; ++k2) Acol[k2] = rec[DM::OFF_A + k2 * nm + c];
-        for (int i = g; i < n; i += NG) {
-          double a_ = 0;
+        // RP rows per pass: RP independent accumulation chains hide each other's LDS and FMA latency
+        for (int i = g; i < n; i += RP * NG) {
+          int ri[RP];
+          double acc[RP];
 #pragma unroll
-          for (int k2 = 0; k2 < n; ++k2) a_ += V[i * n + k2] * Acol[k2];
-          W[i * nm + c] = a_;
+          for (int r = 0; r < RP; ++r) {
+            ri[r] = (i + r * NG < n) ? i + r * NG : i;  // surplus rows recompute row i and are not stored
+            acc[r] = 0.0;
+          }
+#pragma unroll
+          for (int k2 = 0; k2 < n; ++k2) {
+#pragma unroll
+            for (int r = 0; r < RP; ++r) acc[r] += V[ri[r] * n + k2] * Acol[k2];
+          }
+          W[i * nm + c] = acc[0];
+#pragma unroll
+          for (int r = 1; r < RP; ++r)
+            if (ri[r] != i) W[ri[r] * nm + c] = acc[r];
         }
       });
       ex.sync();
@@ -178,18 +195,25 @@ EMPC_HD void backward_traj2(Exec& ex, const DevBuffers& D, int b, double* smem) 
         double Wcol[n];
 #pragma unroll
         for (int k2 = 0; k2 < n; ++k2) Wcol[k2] = W[k2 * nm + c];
-        for (int rr = g; rr < nm; rr += NG) {
-          if (rr >= n && c < n) continue;
-          double a_;
-          if (rr < n)
-            a_ = rec[DM::OFF_HX + rr * nm + c];
-          else
-            a_ = rec[DM::OFF_LUU + (rr - n) * m + (c - n)];
+        // RP rows per pass (see W); rows of the uu block are skipped for the x columns, as before
+        const int rmax = (c < n) ? n : nm;
+        for (int rr = g; rr < rmax; rr += RP * NG) {
+          int ri[RP];
+          double acc[RP];
+#pragma unroll
+          for (int r = 0; r < RP; ++r) {
+            ri[r] = (rr + r * NG < rmax) ? rr + r * NG : rr;
+            acc[r] = (ri[r] < n) ? rec[DM::OFF_HX + ri[r] * nm + c] : rec[DM::OFF_LUU + (ri[r] - n) * m + (c - n)];
+          }
 #pragma unroll
           for (int k2 = 0; k2 < n; ++k2) {
-            a_ += rec[DM::OFF_A + k2 * nm + rr] * Wcol[k2];
+#pragma unroll
+            for (int r = 0; r < RP; ++r) acc[r] += rec[DM::OFF_A + k2 * nm + ri[r]] * Wcol[k2];
           }
-          Q[rr * nm + c] = a_;
+          Q[rr * nm + c] = acc[0];
+#pragma unroll
+          for (int r = 1; r < RP; ++r)
+            if (ri[r] != rr) Q[ri[r] * nm + c] = acc[r];
         }
         if (g == NG - 1) {
           double a_ = (c < n) ? rec[DM::OFF_LX + c] : rec[DM::OFF_LU + (c - n)];
@@ -252,11 +276,23 @@ EMPC_HD void backward_traj2(Exec& ex, const DevBuffers& D, int b, double* smem) 
           double Kcol[m];
 #pragma unroll
           for (int l = 0; l < m; ++l) Kcol[l] = Ks[l * n + c];
-          for (int i = g; i < n; i += NG) {
-            double a_ = Q[i * nm + c];
+          for (int i = g; i < n; i += RP * NG) {
+            int ri[RP];
+            double acc[RP];
 #pragma unroll
-            for (int l = 0; l < m; ++l) a_ -= Q[i * nm + n + l] * Kcol[l];
-            W[i * nm + c] = a_;
+            for (int r = 0; r < RP; ++r) {
+              ri[r] = (i + r * NG < n) ? i + r * NG : i;
+              acc[r] = Q[ri[r] * nm + c];
+            }
+#pragma unroll
+            for (int l = 0; l < m; ++l) {
+#pragma unroll
+              for (int r = 0; r < RP; ++r) acc[r] -= Q[ri[r] * nm + n + l] * Kcol[l];
+            }
+            W[i * nm + c] = acc[0];
+#pragma unroll
+            for (int r = 1; r < RP; ++r)
+              if (ri[r] != i) W[ri[r] * nm + c] = acc[r];
           }
           if (g == NG - 1) {
             double a_ = qv[c];

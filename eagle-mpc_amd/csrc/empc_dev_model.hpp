@@ -657,6 +657,27 @@ EMPC_HD void node_nominal(const EMPC_K DevProblem& P, const SetT& set, double sm
       ncap = (ncap < NCAP) ? ncap + 1 : ncap;
     }
   }
+  const bool use_contact = CT && P.has_contact && set.ncontacts > 0;
+  int ccap = 0;
+  if constexpr (CT) {
+    if (use_contact) {  // the contact frame rides along in the bias pass (placement, velocity, drift acceleration)
+      const int cframe = set.contacts[0].frame;
+      bool seen = false;
+#pragma unroll
+      for (int k = 0; k < NCAP; ++k)
+        if (k < ncap && capf[k] == cframe) {
+          seen = true;
+          ccap = k;
+        }
+      if (!seen) {
+#pragma unroll
+        for (int k = 0; k < NCAP; ++k)
+          if (k == ncap) capf[k] = cframe;
+        ccap = ncap;
+        ncap = (ncap < NCAP) ? ncap + 1 : ncap;
+      }
+    }
+  }
   FrameCap<double> caps[NCAP];
   EMPC_STAMP(1);  // squash, tau, quaternion, joint sin/cos, frame scan
   // bias forces h = RNEA(q, v, 0)
@@ -676,42 +697,87 @@ EMPC_HD void node_nominal(const EMPC_K DevProblem& P, const SetT& set, double sm
   chol_solve_packed<NV>(L, a);
   EMPC_STAMP(4);  // Cholesky + solve
   double lam[6] = {0, 0, 0, 0, 0, 0};
-  const bool use_contact = CT && P.has_contact && set.ncontacts > 0;
   if constexpr (CT) if (use_contact) {
     // ContactModel3D/6D: [M Jc^T; Jc 0][a; -lam] = [tau - h; -a0]
     const auto& ct = set.contacts[0];
     const int nc = (ct.type == EMPC_CONTACT_3D) ? 3 : 6;
-    int cf[1] = {ct.frame};
-    FrameCap<double> ck[1];
-    double dummy[NV];
-    // drift with qdd = 0, no gravity
-    rnea_chain<NB, double>(m, R0, q, cs, sn, v, zero, false, -1, nullptr, dummy, 1, cf, ck);
-    double a0[6];
+    FrameCap<double> ck = caps[0];
+#pragma unroll
+    for (int kk = 1; kk < NCAP; ++kk)
+      if (kk == ccap) ck = caps[kk];
+    // drift (frame acceleration at qdd = 0, no gravity): the bias pass carries gravity as a base acceleration -g, which
+    // reaches every frame as the pure translation R_f^T (-g); take it out again
+    double ng[3] = {-m.gravity[0], -m.gravity[1], -m.gravity[2]}, gf[3], a0[6];
+    matTvec3<double>(ck.R, ng, gf);
     if (nc == 3) {
       double wxv[3];
-      cross3<double>(ck[0].v + 3, ck[0].v, wxv);
-      for (int r = 0; r < 3; ++r) a0[r] = ck[0].a[r] + wxv[r];
+      cross3<double>(ck.v + 3, ck.v, wxv);
+      for (int r = 0; r < 3; ++r) a0[r] = (ck.a[r] - gf[r]) + wxv[r];
     } else {
-      for (int r = 0; r < 6; ++r) a0[r] = ck[0].a[r];
+      for (int r = 0; r < 3; ++r) a0[r] = ck.a[r] - gf[r];
+      for (int r = 3; r < 6; ++r) a0[r] = ck.a[r];
     }
     if (ct.gains[0] != 0.0 && nc == 3) {
       double dp[3], dpl[3];
-      for (int r = 0; r < 3; ++r) dp[r] = ck[0].p[r] - ct.ref_p[r];
-      matTvec3<double>(ck[0].R, dp, dpl);
+      for (int r = 0; r < 3; ++r) dp[r] = ck.p[r] - ct.ref_p[r];
+      matTvec3<double>(ck.R, dp, dpl);
       for (int r = 0; r < 3; ++r) a0[r] += ct.gains[0] * dpl[r];
     }
     if (ct.gains[1] != 0.0)
-      for (int r = 0; r < nc; ++r) a0[r] += ct.gains[1] * ck[0].v[r];
-    // Jc columns: LOCAL frame velocity for unit generalized velocities
+      for (int r = 0; r < nc; ++r) a0[r] += ct.gains[1] * ck.v[r];
+    // Jc: LOCAL frame Jacobian from the kinematics (column j = [R_f^T (z_j x (p_f - o_j)); R_f^T z_j] for a rotation about
+    // the world axis z_j through o_j, R_f^T e_j for the base translations), joints after the frame's body contribute nothing
     double Jc[6][NV], MiJt[6][NV];
+    {
+      const int bf = m.frame_body[ct.frame];
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      double ej[NV];
+      for (int j = 0; j < 3; ++j) {
+        double w[3] = {R0[j], R0[3 + j], R0[6 + j]}, lin[3];
+        matTvec3<double>(ck.R, w, lin);
 #pragma unroll
-      for (int i = 0; i < NV; ++i) ej[i] = (i == j) ? 1.0 : 0.0;
-      FrameCap<double> cj[1];
-      rnea_chain<NB, double>(m, R0, q, cs, sn, ej, zero, false, -1, nullptr, dummy, 1, cf, cj);
-      for (int r = 0; r < nc; ++r) Jc[r][j] = cj[0].v[r];
+        for (int r = 0; r < 3; ++r) {
+          Jc[r][j] = lin[r];
+          Jc[3 + r][j] = 0.0;
+        }
+      }
+      double Rw[9], pw[3];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) Rw[i] = R0[i];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) pw[i] = q[i];
+#pragma unroll
+      for (int j = 3; j < NV; ++j) {
+        double z[3];
+        bool on_path = true;
+        if (j < 6) {
+          z[0] = R0[j - 3];
+          z[1] = R0[3 + j - 3];
+          z[2] = R0[6 + j - 3];
+        } else {
+          const int b = j - 6 + 1;
+          double Rj[9], XR[9], Rr[3], Rn[9];
+          axis_rot<double>(m.axis[b], cs[b - 1], sn[b - 1], Rj);
+          matmul3<double>(m.jplace_R[b], Rj, XR);
+          matvec3<double>(Rw, m.jplace_p[b], Rr);
+          matmul3<double>(Rw, XR, Rn);
+#pragma unroll
+          for (int i = 0; i < 9; ++i) Rw[i] = Rn[i];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) pw[i] += Rr[i];
+          double ax[3] = {m.axis[b][0], m.axis[b][1], m.axis[b][2]};
+          matvec3<double>(Rw, ax, z);
+          on_path = (b <= bf);
+        }
+        double d[3] = {ck.p[0] - pw[0], ck.p[1] - pw[1], ck.p[2] - pw[2]}, zxd[3], lin[3], ang[3];
+        cross3<double>(z, d, zxd);
+        matTvec3<double>(ck.R, zxd, lin);
+        matTvec3<double>(ck.R, z, ang);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          Jc[r][j] = on_path ? lin[r] : 0.0;
+          Jc[3 + r][j] = on_path ? ang[r] : 0.0;
+        }
+      }
     }
     double G[21];  // packed nc x nc
     for (int r = 0; r < nc; ++r) {
