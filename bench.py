@@ -27,7 +27,12 @@ CONFIGS = {
     "displacement": ("hexacopter370_flying_arm_3/trajectories/displacement.yaml", 80),
     "eagle_catch": ("hexacopter370_flying_arm_3/trajectories/eagle_catch.yaml", 32),
     "push_slide": ("hextilt_flying_arm_5/trajectories/push_slide.yaml", 13),
+    # BASELINE.json configs[4]: closed-loop Carrot MPC on the displacement trajectory, 50-knot horizon, RK4 plants
+    "carrot_mpc": ("hexacopter370_flying_arm_3/trajectories/displacement.yaml", 80),
 }
+MPC_YAML = os.path.join(ROOT, "eagle-mpc_amd", "data", "mpc", "carrot_50knots.yaml")
+MPC_CYCLES_PER_STEP = 20   # one bench step of the carrot_mpc config = 20 controller cycles (updateProblem, solve, plant)
+MPC_DT_SIM = 2             # ms, examples/python/mpc.py:41
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -48,7 +53,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=1024, help="rollouts per GPU")
+    ap.add_argument("--batch", type=int, default=None, help="rollouts per GPU (default 1024; 256 for carrot_mpc)")
     ap.add_argument("--config", default="displacement", choices=sorted(CONFIGS))
     ap.add_argument("--maxiter", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -74,6 +79,8 @@ def main():
         dist = dist_mod
         dist.init_process_group(backend="nccl", rank=rank, world_size=world)
 
+    if args.batch is None:
+        args.batch = 256 if args.config == "carrot_mpc" else 1024
     rel, dt = CONFIGS[args.config]
     traj = empc.Trajectory()
     traj.autoSetup(empc.yaml_path(rel))
@@ -85,9 +92,39 @@ def main():
     sharding = importlib.import_module("eagle_mpc_amd.sharding")
     x0_all = empc.perturbed_x0s(problem.x0, B * world, nq=d.model.nq)
     x0s = sharding.shard(x0_all, world, rank)
-    solver = empc.SolverSbFDDP(problem, batch=B, device=local_rank)
+    solver = empc.SolverSbFDDP(problem, batch=B, device=local_rank) if args.config != "carrot_mpc" else None
+    mpc_state = {"t": 0}
+    if args.config == "carrot_mpc":
+        # plan once (one rollout), then B controllers-in-one track it from perturbed plant states
+        planner = empc.SolverSbFDDP(problem, batch=1, device=local_rank)
+        planner.solve([], [], args.maxiter)
+        xs_plan, us_plan = np.array(planner.xs), np.array(planner.us)
+        mpc = empc.CarrotMpc(traj, xs_plan, dt, MPC_YAML, batch=B, device=local_rank)
+        mpc.updateProblem(0)
+        solver = mpc.solver
+        d = mpc.problem.desc
+        solver.plant_states = sharding.shard(empc.perturbed_x0s(xs_plan[0], B * world, nq=d.model.nq, amplitude=0.02), world, rank)
+        solver.solve(xs_plan[:d.T + 1], us_plan[:d.T], args.maxiter, x0s="plant")
+        solver.convergence_init = 1e-3
+
+    def mpc_step():
+        agg_s = {}
+        for _ in range(MPC_CYCLES_PER_STEP):
+            mpc.updateProblem(mpc_state["t"])
+            solver.solve("previous", "previous", mpc.iters, x0s="plant")
+            st = solver.stats()
+            for k, v in st.items():
+                agg_s[k] = agg_s.get(k, 0) + v
+            solver.plant_step(MPC_DT_SIM)
+            mpc_state["t"] += MPC_DT_SIM
+        if dist is not None:
+            rows = sharding.pack_results(solver.xs_batch, solver.us_squash_batch, solver.cost_batch, solver.iter_batch)
+            sharding.gather_results(dist, rows, world, rank, device="cuda", global_batch=B * world)
+        return agg_s
 
     def one_step():
+        if args.config == "carrot_mpc":
+            return mpc_step()
         solver.solve([], [], args.maxiter, x0s=x0s)
         if dist is not None:
             # the only exchange of the algorithm: results to rank 0 (RCCL gather over xGMI)
@@ -135,7 +172,8 @@ def main():
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic = None
         prof = os.path.join(ROOT, "profiles", "traffic_%s.json" % dom)
-        if os.path.exists(prof):
+        # the committed PMC measurement belongs to the default workload only
+        if os.path.exists(prof) and args.config == "displacement" and B == 1024:
             try:
                 traffic = json.load(open(prof)).get("hbm_bytes_per_launch")
             except Exception:
@@ -153,8 +191,11 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "%s dt=%dms T=%d batch=%d/GPU SolverSbFDDP.solve(maxiter=%d), perturbed x0" %
-                                   (rel, dt, d.T, B, args.maxiter),
+            "config": {"workload": ("%s dt=%dms T=%d batch=%d/GPU SolverSbFDDP.solve(maxiter=%d), perturbed x0" %
+                                    (rel, dt, d.T, B, args.maxiter)) if args.config != "carrot_mpc" else
+                                   ("CarrotMpc closed loop on %s: %d-knot horizon dt=%dms, %d plants/GPU (RK4, %d ms), %d cycles/step, "
+                                    "%d iterations/cycle, warm start and plant states device-resident" %
+                                    (rel, d.T + 1, mpc.dt, B, MPC_DT_SIM, MPC_CYCLES_PER_STEP, mpc.iters)),
                        "nx": d.nx, "ndx": d.ndx, "nu": d.nu, "parallelism": "batch-sharded x%d" % world},
             "trajectory_iters_per_s": iters_total / elapsed,
             "mean_iters_per_trajectory": iters_total / (B * world * args.steps),
@@ -168,7 +209,10 @@ def main():
                                    "achieved_GBs": iters_total * d.T * words["iteration"] * 8 / elapsed / 1e9 / world,
                                    "frac_of_8TBs": iters_total * d.T * words["iteration"] * 8 / elapsed / 1e9 / world / HBM_PEAK_GBS},
         }
-        if not args.no_cpu_baseline:
+        if args.config == "carrot_mpc":
+            out["mpc_cycles_per_s"] = args.steps * MPC_CYCLES_PER_STEP / elapsed
+            out["plant_controller_cycles_per_s"] = args.steps * MPC_CYCLES_PER_STEP * B * world / elapsed
+        if not args.no_cpu_baseline and args.config != "carrot_mpc":
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_binding as ob  # the oracle timed as the CPU baseline ("port"), never part of the product path
             cores = os.cpu_count() or 1

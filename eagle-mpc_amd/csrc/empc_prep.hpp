@@ -111,8 +111,15 @@ inline void prepare_problem(const EmpcProblemDesc& d, const EmpcSolverParams& pr
       for (int k = 0; k < nf; ++k) seen = seen || frames[k] == c.frame;
       if (!seen) frames[nf++] = c.frame;
     }
+    if (s.ncontacts >= 1) {  // the contact frame is captured too
+      bool seen = false;
+      for (int k = 0; k < nf; ++k) seen = seen || frames[k] == s.contacts[0].frame;
+      if (!seen) ++nf;
+    }
     if (nf > NCAP) throw std::runtime_error("a cost set references more distinct frames than the kernels capture");
     if (s.ncontacts > 1) throw std::runtime_error("more than one contact per stage is not supported by the kernels");
+    if (s.ncontacts == 1 && s.contacts[0].type != EMPC_CONTACT_3D)
+      throw std::runtime_error("only ContactModel3D is implemented in the linearize kernel (ContactModel6D is not)");
   }
 }
 
