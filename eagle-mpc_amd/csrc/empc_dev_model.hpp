@@ -426,6 +426,13 @@ EMPC_HD double act_weight(const CostT& c, int i, double smooth, const EMPC_K Dev
   return c.act_w[i];
 }
 
+// prepare_problem marks the cost sets that capture operational frames (active frame costs or a contact) in bit 0 of
+// costs[0].reserved; linearize runs a lean body for the others
+template <class SetT>
+EMPC_HD bool set_uses_frames(const SetT& set) {
+  return set.ncosts > 0 && (set.costs[0].reserved & 1) != 0;
+}
+
 // Sum of the activation values of the first nr (<= NR) residual components -- the value-only path of the rollouts.
 // The activation type is branched on ONCE and each case is straight-line code, so the parameter loads (weights, bounds)
 // of all components are issued together instead of one dependent scalar load per component (measured: 1/3 of the
@@ -657,6 +664,26 @@ EMPC_HD void node_nominal(const EMPC_K DevProblem& P, const SetT& set, double sm
       ncap = (ncap < NCAP) ? ncap + 1 : ncap;
     }
   }
+  // State and control costs first: they need only x and s, so their residuals and parameter loads are out of the way
+  // before the dynamics claim the registers (A.6).  Frame costs follow the bias pass, the friction cone the contact solve.
+  double ell = 0;
+  {
+    double rstate[DM::NDX];  // residual of the most recent State cost (shared between costs with one reference)
+    int rstate_of = -1;
+    for (int ci = 0; ci < set.ncosts; ++ci) {
+      const auto& c = set.costs[ci];
+      if (!c.active) continue;
+      if (c.type == EMPC_COST_STATE) {
+        if (!(c.ref_share >= 0 && c.ref_share == rstate_of)) {
+          state_diff<DM>(c.ref, x, rstate, nullptr);
+          rstate_of = (c.ref_share >= 0) ? c.ref_share : ci;
+        }
+        ell += c.weight * activation_value<DM::NDX>(c, rstate, DM::NDX);
+      } else if (c.type == EMPC_COST_CONTROL) {
+        ell += c.weight * control_cost_value<NU>(c, s, smooth, P);
+      }
+    }
+  }
   const bool use_contact = CT && P.has_contact && set.ncontacts > 0;
   int ccap = 0;
   if constexpr (CT) {
@@ -686,6 +713,50 @@ EMPC_HD void node_nominal(const EMPC_K DevProblem& P, const SetT& set, double sm
   for (int i = 0; i < NV; ++i) zero[i] = 0.0;
   rnea_chain<NB, double>(m, R0, q, cs, sn, v, zero, true, -1, nullptr, h, ncap, capf, caps);
   EMPC_STAMP(2);  // RNEA bias
+  // frame costs right after the pass that captured the frames, so the captures (24 doubles each) die before the inertia
+  // matrix and its factor come alive; their sum joins the other costs at the end
+  double ell_frames = 0;
+  for (int ci = 0; ci < set.ncosts; ++ci) {
+    const auto& c = set.costs[ci];
+    if (!c.active || c.type == EMPC_COST_STATE || c.type == EMPC_COST_CONTROL || c.type == EMPC_COST_CONTACT_FRICTION_CONE)
+      continue;
+    double cval = 0;
+    {
+      FrameCap<double> fk = caps[0];
+#pragma unroll
+      for (int kk = 1; kk < NCAP; ++kk)
+        if (kk < ncap && capf[kk] == c.frame) fk = caps[kk];
+      double r[6];
+      int nr = 6;
+      if (c.type == EMPC_COST_FRAME_PLACEMENT) {
+        double rR[9], dp[3], rp[3], qq[4];
+        matTmul3<double>(c.ref + 3, fk.R, rR);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) dp[i] = fk.p[i] - c.ref[i];
+        matTvec3<double>(c.ref + 3, dp, rp);
+        R_to_quat(rR, qq);
+        log6_quat(qq, rp, r);
+      } else if (c.type == EMPC_COST_FRAME_ROTATION) {
+        double rR[9], qq[4];
+        matTmul3<double>(c.ref, fk.R, rR);
+        R_to_quat(rR, qq);
+        quat_log3(qq, r);
+        nr = 3;
+      } else if (c.type == EMPC_COST_FRAME_TRANSLATION) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) r[i] = fk.p[i] - c.ref[i];
+        nr = 3;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) r[i] = fk.v[i] - c.ref[i];
+      }
+      if (nr == 3) {
+        r[3] = r[4] = r[5] = 0.0;
+      }
+      cval = activation_value<6>(c, r, nr);
+    }
+    ell_frames += c.weight * cval;
+  }
   // joint-space inertia (packed lower triangle) by the composite-rigid-body algorithm
   double L[DM::NTRI];
   crba_chain<NB>(m, cs, sn, L);
@@ -826,69 +897,23 @@ EMPC_HD void node_nominal(const EMPC_K DevProblem& P, const SetT& set, double sm
   state_integrate<DM>(x, dxe, xnext, nullptr);
   EMPC_STAMP(6);  // Euler step
 
-  // costs (A.6)
-  double ell = 0;
-  double rstate[DM::NDX];  // residual of the most recent State cost (shared between costs with one reference)
-  int rstate_of = -1;
+  // friction-cone costs need the contact force
   for (int ci = 0; ci < set.ncosts; ++ci) {
     const auto& c = set.costs[ci];
-    if (!c.active) continue;
+    if (!c.active || c.type != EMPC_COST_CONTACT_FRICTION_CONE) continue;
+    double AR[5][3];
+    double nsf[3] = {c.ref[0], c.ref[1], c.ref[2]};
+    cone_rows(nsf, c.ref[3], AR);
     double cval = 0;
-    if (c.type == EMPC_COST_STATE) {
-      double* r = rstate;
-      if (!(c.ref_share >= 0 && c.ref_share == rstate_of)) {
-        state_diff<DM>(c.ref, x, r, nullptr);
-        rstate_of = (c.ref_share >= 0) ? c.ref_share : ci;
-      }
-      cval = activation_value<DM::NDX>(c, r, DM::NDX);
-    } else if (c.type == EMPC_COST_CONTROL) {
-      cval = control_cost_value<NU>(c, s, smooth, P);
-    } else if (c.type == EMPC_COST_CONTACT_FRICTION_CONE) {
-      double AR[5][3];
-      double nsf[3] = {c.ref[0], c.ref[1], c.ref[2]};
-      cone_rows(nsf, c.ref[3], AR);
-      for (int i = 0; i < 5; ++i) {
-        double r = use_contact ? (AR[i][0] * lam[0] + AR[i][1] * lam[1] + AR[i][2] * lam[2]) : 0.0;
-        double av, Ar, Arr;
-        activation1(c.activation, r, c.act_w[i], c.lb[i], c.ub[i], av, Ar, Arr);
-        cval += av;
-      }
-    } else {
-      FrameCap<double> fk = caps[0];
-#pragma unroll
-      for (int kk = 1; kk < NCAP; ++kk)
-        if (kk < ncap && capf[kk] == c.frame) fk = caps[kk];
-      double r[6];
-      int nr = 6;
-      if (c.type == EMPC_COST_FRAME_PLACEMENT) {
-        double rR[9], dp[3], rp[3], qq[4];
-        matTmul3<double>(c.ref + 3, fk.R, rR);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) dp[i] = fk.p[i] - c.ref[i];
-        matTvec3<double>(c.ref + 3, dp, rp);
-        R_to_quat(rR, qq);
-        log6_quat(qq, rp, r);
-      } else if (c.type == EMPC_COST_FRAME_ROTATION) {
-        double rR[9], qq[4];
-        matTmul3<double>(c.ref, fk.R, rR);
-        R_to_quat(rR, qq);
-        quat_log3(qq, r);
-        nr = 3;
-      } else if (c.type == EMPC_COST_FRAME_TRANSLATION) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) r[i] = fk.p[i] - c.ref[i];
-        nr = 3;
-      } else {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) r[i] = fk.v[i] - c.ref[i];
-      }
-      if (nr == 3) {
-        r[3] = r[4] = r[5] = 0.0;
-      }
-      cval = activation_value<6>(c, r, nr);
+    for (int i = 0; i < 5; ++i) {
+      double r = use_contact ? (AR[i][0] * lam[0] + AR[i][1] * lam[1] + AR[i][2] * lam[2]) : 0.0;
+      double av, Ar, Arr;
+      activation1(c.activation, r, c.act_w[i], c.lb[i], c.ub[i], av, Ar, Arr);
+      cval += av;
     }
     ell += c.weight * cval;
   }
+  ell += ell_frames;
   const double cscale = (terminal && !P.prm.terminal_dt_scaling) ? 1.0 : dt;
   cost_out = cscale * ell;
   EMPC_STAMP(7);  // costs

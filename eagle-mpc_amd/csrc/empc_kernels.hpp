@@ -60,6 +60,7 @@ struct DevBuffers {
   int* n_active;    // [1]
   unsigned long long* dbg;  // [64] cycle stamps of diagnostic builds (EMPC_STAMPS); unused otherwise
   int B, T, NA;
+  int any_frames;   // some cost set of the problem captures operational frames (linearize launches its full body too)
   double gaptol;    // feasibility tolerance actually used: max(th_gaptol, 1e-13)
 };
 

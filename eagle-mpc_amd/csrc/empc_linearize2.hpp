@@ -407,7 +407,11 @@ EMPC_HD void lin2_frame_jcol(const EMPC_K EmpcModelDesc& m, const double* N, int
   matTvec3<double>(Rf, z, col + 3);
 }
 
-template <class DM, bool CT, class Exec>
+// FR: this instantiation handles the units whose cost set captures operational frames (frame costs or a contact);
+// FR = false is the lean body for all other units -- the frame Jacobian / velocity-derivative columns (72 registers per
+// lane) do not exist in it.  The kernel is launched once per flavour; a unit returns at once from the wrong one
+// (flag bit 0 of costs[0].reserved, set by prepare_problem).
+template <class DM, bool CT, bool FR, class Exec>
 EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lpu, double* N) {
   typedef Lin2Smem<DM> SM;
   constexpr int NB = DM::NB, NV = DM::NV, NQ = DM::NQ, NX = DM::NX, NDX = DM::NDX, NU = DM::NU, NROT = DM::NROT;
@@ -424,10 +428,11 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
   const bool feas = st.is_feasible != 0;
   double* out = D.tape + ((size_t)b * (T + 1) + t) * REC;
 
+  if (set_uses_frames(set) != FR) return;
   // captured frames (uniform over the unit)
   int capf[NCAP] = {0, 0};
   int ncap = 0;
-  for (int ci = 0; ci < set.ncosts; ++ci) {
+  for (int ci = 0; FR && ci < set.ncosts; ++ci) {
     const EMPC_K EmpcCost& c = set.costs[ci];
     if (!c.active || c.frame < 0 || c.type == EMPC_COST_CONTACT_FRICTION_CONE) continue;
     bool seen = false;
@@ -442,7 +447,7 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
   }
 
   // contact of this node (ContactModel3D only on the device)
-  const bool use_contact = CT && P.has_contact && set.ncontacts > 0;
+  const bool use_contact = FR && CT && P.has_contact && set.ncontacts > 0;
   int cframe = -1, cbody = -1, ccap = 0;
   if (use_contact) {
     cframe = set.contacts[0].frame;
@@ -929,7 +934,7 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
     }
   });
   // round 3: frame costs, one at a time
-  for (int ci = 0; ci < set.ncosts; ++ci) {
+  for (int ci = 0; FR && ci < set.ncosts; ++ci) {
     const EMPC_K EmpcCost& c = set.costs[ci];
     if (!c.active || c.frame < 0 || c.type == EMPC_COST_CONTACT_FRICTION_CONE || c.type == EMPC_COST_STATE ||
         c.type == EMPC_COST_CONTROL)

@@ -101,7 +101,7 @@ inline void prepare_problem(const EmpcProblemDesc& d, const EmpcSolverParams& pr
         }
     }
   // frame-capture capacity per cost set
-  for (const auto& s : H.sets) {
+  for (auto& s : H.sets) {
     int frames[EMPC_MAX_COSTS], nf = 0;
     for (int i = 0; i < s.ncosts; ++i) {
       const EmpcCost& c = s.costs[i];
@@ -110,6 +110,10 @@ inline void prepare_problem(const EmpcProblemDesc& d, const EmpcSolverParams& pr
       bool seen = false;
       for (int k = 0; k < nf; ++k) seen = seen || frames[k] == c.frame;
       if (!seen) frames[nf++] = c.frame;
+    }
+    if (s.ncosts > 0) {  // flag read by linearize (set_uses_frames)
+      EmpcCostSet& ms = s;
+      ms.costs[0].reserved = (ms.costs[0].reserved & ~1) | ((nf > 0 || s.ncontacts >= 1) ? 1 : 0);
     }
     if (s.ncontacts >= 1) {  // the contact frame is captured too
       bool seen = false;
@@ -128,6 +132,13 @@ inline void prepare_problem(const EmpcProblemDesc& d, const EmpcSolverParams& pr
 namespace empc {
 // State of one trajectory at the start of SolverSbFDDP::solve (src/sbfddp.cpp:198-210).  `prev` carries the members
 // that the reference keeps across solve() calls (cost_, cost_prev_, stop_).
+// does any cost set capture operational frames?  (flag written by prepare_problem)
+inline int problem_uses_frames(const HostProblem& H) {
+  for (const auto& s : H.sets)
+    if (s.ncosts > 0 && (s.costs[0].reserved & 1)) return 1;
+  return 0;
+}
+
 inline void init_traj_state(TrajState& s, const EmpcSolverParams& prm, int maxiter, bool is_feasible_arg,
                             const TrajState* prev) {
   TrajState z;

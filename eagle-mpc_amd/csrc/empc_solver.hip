@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(64) k_rollout5(DevBuffers D) {
   rollout_wave5<DM, CT>(ex, D, blockIdx.x, 64, smem_roll5);
 }
 
-template <class DM, bool CT, int LPU, int BLK>
+template <class DM, bool CT, int LPU, int BLK, bool FR>
 // Two wavefronts per SIMD: at the compiler's own choice (326 registers, one wavefront per SIMD) the kernel sits at
 // ~1 resident wave per SIMD with 37 % of its time in waits; capping the budget at 256 registers costs ~250 spilled
 // values but doubles the resident waves: 2.02 -> 1.42 ms per launch (profiles/README.md).
@@ -80,7 +80,7 @@ k_linearize(DevBuffers D) {
   const TrajState& st = D.st[b];
   if (st.phase == PHASE_DONE || !st.need_lin) return;
   LaneExec ex{lane};
-  linearize_unit2<DM, CT>(ex, D, b, t, LPU, smem_lin + (size_t)(threadIdx.x / LPU) * USZ);
+  linearize_unit2<DM, CT, FR>(ex, D, b, t, LPU, smem_lin + (size_t)(threadIdx.x / LPU) * USZ);
 }
 
 // workgroup-wide executor: barriers are real workgroup barriers
@@ -202,16 +202,18 @@ static void launch_linearize_blk(DevBuffers D, hipStream_t s) {
   static const bool once = [&] {
     if (getenv("EMPC_DEBUG_OCC")) {
       int nb = -1;
-      hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_linearize<DM, CT, LPU, BLK>, BLK, smem);
+      hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_linearize<DM, CT, LPU, BLK, false>, BLK, smem);
       hipFuncAttributes fa;
-      hipError_t e2 = hipFuncGetAttributes(&fa, (const void*)k_linearize<DM, CT, LPU, BLK>);
+      hipError_t e2 = hipFuncGetAttributes(&fa, (const void*)k_linearize<DM, CT, LPU, BLK, false>);
       fprintf(stderr, "[empc] k_linearize BLK=%d dyn smem=%zu B: max active blocks/CU=%d (%s); regs=%d static smem=%zu local=%zu (%s)\n", BLK,
               smem, nb, hipGetErrorString(e), fa.numRegs, fa.sharedSizeBytes, fa.localSizeBytes, hipGetErrorString(e2));
     }
     return true;
   }();
   (void)once;
-  hipLaunchKernelGGL((k_linearize<DM, CT, LPU, BLK>), dim3((n + UPB - 1) / UPB), dim3(BLK), smem, s, D);
+  // lean body for the units without operational frames, full body for the rest; each unit runs in exactly one of them
+  hipLaunchKernelGGL((k_linearize<DM, CT, LPU, BLK, false>), dim3((n + UPB - 1) / UPB), dim3(BLK), smem, s, D);
+  if (D.any_frames) hipLaunchKernelGGL((k_linearize<DM, CT, LPU, BLK, true>), dim3((n + UPB - 1) / UPB), dim3(BLK), smem, s, D);
 }
 template <class DM, bool CT>
 static void launch_linearize(DevBuffers D, hipStream_t s) {
@@ -453,6 +455,7 @@ EmpcSolver* empc_solver_create(const EmpcProblemDesc* problem, const EmpcSolverP
   D.T = s->T;
   D.NA = s->NA;
   D.gaptol = std::max(prm.th_gaptol, 1e-13);
+  D.any_frames = problem_uses_frames(s->H);
   s->dscratch = s->dalloc<double>(B * T * k.nu);
   s->dplant_x = s->dalloc<double>(B * k.nx);
   s->dplant_u = s->dalloc<double>(B * k.nu);
@@ -514,6 +517,7 @@ int empc_solver_update_problem(EmpcSolver* s, const EmpcProblemDesc* problem) {
   s->use();
   const EmpcSolverParams prm = s->H.P.prm;
   prepare_problem(*problem, prm, s->H);
+  s->D.any_frames = problem_uses_frames(s->H);
   upload_problem(s);
   return EMPC_OK;
   EMPC_CATCH(RET_INT)

@@ -93,6 +93,7 @@ static void emu_alloc(Emu& e) {
   D.T = T;
   D.NA = NA;
   D.gaptol = e.H.P.prm.th_gaptol > 1e-13 ? e.H.P.prm.th_gaptol : 1e-13;
+  D.any_frames = problem_uses_frames(e.H);
   for (int b = 0; b < B; ++b) std::memcpy(&e.x0[(size_t)b * DM::NX], e.H.x0.data(), sizeof(double) * DM::NX);
 }
 
@@ -122,11 +123,13 @@ static void emu_linearize(Emu& e) {
       CpuExec<64> ex{LPU};
       if constexpr (DM::NB == 4) {
         if (e.H.P.has_contact) {
-          linearize_unit2<DM, true>(ex, e.D, b, t, LPU, smem.data());
+          linearize_unit2<DM, true, false>(ex, e.D, b, t, LPU, smem.data());
+          linearize_unit2<DM, true, true>(ex, e.D, b, t, LPU, smem.data());
           continue;
         }
       }
-      linearize_unit2<DM, false>(ex, e.D, b, t, LPU, smem.data());
+      linearize_unit2<DM, false, false>(ex, e.D, b, t, LPU, smem.data());
+      linearize_unit2<DM, false, true>(ex, e.D, b, t, LPU, smem.data());
     }
 }
 static int g_bwd_version = 2;
