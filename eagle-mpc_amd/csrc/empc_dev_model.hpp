@@ -415,6 +415,19 @@ EMPC_HD void activation1(int act, double r, double w, double lb, double ub, doub
     Arr = ww * ind;
   }
 }
+// activation1 without branches (selects only): for lanes that evaluate DIFFERENT costs side by side, where a branch on
+// the activation type would serialise the lanes.  Same formulas, bit for bit (the neutral weight is an exact 1.0).
+EMPC_HD void activation_sel(int act, double r, double w, double lb, double ub, double& a, double& Ar, double& Arr) {
+  const bool barrier = (act == EMPC_ACT_QUADRATIC_BARRIER || act == EMPC_ACT_WEIGHTED_QUADRATIC_BARRIER);
+  const double ww = (act == EMPC_ACT_QUAD || act == EMPC_ACT_QUADRATIC_BARRIER) ? 1.0 : w;
+  const double lo = fmin(r - lb, 0.0);
+  const double hi = fmax(r - ub, 0.0);
+  const double ind = ((r - lb <= 0.0) ? 1.0 : 0.0) + ((r - ub >= 0.0) ? 1.0 : 0.0);
+  const double aq = (act == EMPC_ACT_QUAD) ? 0.5 * r * r : 0.5 * ww * r * r;
+  a = barrier ? 0.5 * ww * lo * lo + 0.5 * ww * hi * hi : aq;
+  Ar = barrier ? ww * (lo + hi) : ((act == EMPC_ACT_QUAD) ? r : ww * r);
+  Arr = barrier ? ww * ind : ww;
+}
 // weight of component i of cost c, with the barrier cost's weights derived from the trajectory's current smooth
 // (SolverSbFDDP::barrierUpdate, src/sbfddp.cpp:464-477)
 template <class CostT>

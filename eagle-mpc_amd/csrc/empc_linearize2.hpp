@@ -407,6 +407,20 @@ EMPC_HD void lin2_frame_jcol(const EMPC_K EmpcModelDesc& m, const double* N, int
   matTvec3<double>(Rf, z, col + 3);
 }
 
+#if defined(EMPC_STAMPS) && defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+#define LIN_STAMP(i)                                              \
+  do {                                                            \
+    __builtin_amdgcn_sched_barrier(0);                            \
+    const unsigned long long now_ = __builtin_readcyclecounter(); \
+    lst[i] += now_ - lst[15];                                     \
+    lst[15] = now_;                                               \
+    __builtin_amdgcn_sched_barrier(0);                            \
+  } while (0)
+#else
+#define LIN_STAMP(i) \
+  do {               \
+  } while (0)
+#endif
 // FR: this instantiation handles the units whose cost set captures operational frames (frame costs or a contact);
 // FR = false is the lean body for all other units -- the frame Jacobian / velocity-derivative columns (72 registers per
 // lane) do not exist in it.  The kernel is launched once per flavour; a unit returns at once from the wrong one
@@ -468,6 +482,11 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
     }
   }
 
+#if defined(EMPC_STAMPS) && defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+  unsigned long long lst[16];
+  for (int i = 0; i < 16; ++i) lst[i] = 0;
+  lst[15] = __builtin_readcyclecounter();
+#endif
   // ---- S0: load x, s, a ------------------------------------------------------------------------------------
   ex.each([&](int lane, int sl) {
     const double* xg = D.xs + ((size_t)b * (T + 1) + t) * NX;
@@ -476,12 +495,16 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
     for (int i = lane; i < NX; i += lpu) N[SM::OFF_X + i] = xg[i];
     for (int i = lane; i < NV; i += lpu) N[SM::OFF_A + i] = ag[i];
     for (int i = lane; i < NU; i += lpu) N[SM::OFF_S + i] = terminal ? 0.0 : ug[i];
+    // the next nominal state (origin of the gap) travels with the same batch of loads; parked in the gap slot
+    if (!terminal && !feas)
+      for (int i = lane; i < NX; i += lpu) N[SM::OFF_GAP + i] = xg[NX + i];
     if (lane == 0) N[SM::OFF_RED] = 0.0;  // cost accumulator
     if (CT && lane < 6) {
       N[SM::OFF_LAM + lane] = use_contact ? ag[NV + lane] : 0.0;
     }
   });
   ex.sync();
+  LIN_STAMP(0);
   // ---- S1: squash (lanes < NU), joint sin/cos (next NJ lanes), base rotation (last lane) -------------------------
   ex.each([&](int lane, int sl) {
     if (lane < NU) {
@@ -517,6 +540,7 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
     }
   });
   ex.sync();
+  LIN_STAMP(1);
   // ---- S2: nominal chain (lane 0) || Euler step and its Lie Jacobians (lane 1) ----------------------------------
   ex.each([&](int lane, int sl) {
     if (lane == 0) {
@@ -592,7 +616,9 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
       if (!terminal) {
         double gap[NDX];
         if (!feas) {
-          const double* xn = D.xs + ((size_t)b * (T + 1) + t + 1) * NX;
+          double xn[NX];
+#pragma unroll
+          for (int i = 0; i < NX; ++i) xn[i] = N[SM::OFF_GAP + i];  // staged at S0
           state_diff<DM>(xn, xnext, gap, nullptr);
         }
 #pragma unroll
@@ -607,6 +633,7 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
     }
   });
   ex.sync();
+  LIN_STAMP(2);
   // ---- S3: tangent recursion; inertia columns to LDS ---------------------------------------------------------
   double dtau_l[Exec::SLOTS][NV];
   double jc_l[Exec::SLOTS][NCAP][6], dvc_l[Exec::SLOTS][NCAP][6];
@@ -679,6 +706,7 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
     }
   });
   ex.sync();
+  LIN_STAMP(3);
   // ---- S4: Cholesky of M (lane 0), in place, reciprocal diagonal --------------------------------------------------
   ex.each([&](int lane, int sl) {
     if (lane != 0) return;
@@ -739,6 +767,7 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
       ex.sync();
     }
   }
+  LIN_STAMP(4);
   // ---- S5: M^-1 solves, Euler Jacobian columns -> tape ------------------------------------------------------------
   ex.each([&](int lane, int sl) {
     const bool xlane = lane < NDX;
@@ -833,6 +862,7 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
     }
   });
 
+  LIN_STAMP(5);
   // ---- S6: costs. Column accumulators live in registers: x lanes hold column `lane` of Lxx, u lanes column k of Luu.
   double hx_l[Exec::SLOTS][NDX];  // column of Lxx (x lanes) -- or of Luu in the first NU entries (u lanes)
   double lx_l[Exec::SLOTS];
@@ -846,8 +876,34 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
       for (int i = 0; i < NDX; ++i) hxu_l[sl][i] = 0.0;
     }
   });
-  // round 1: State costs, nominal parts by one lane per cost (same code), up to NSLOT at a time
+  // round 1: State costs, nominal parts by one lane per cost (same code), up to NSLOT at a time.  The parameters of the
+  // NSLOT costs (reference, weights, bounds) are first copied into LDS by the whole unit -- coalesced, one memory latency
+  // -- into the body / inertia / Lie-Jacobian / xnext / gap area, which is dead from here on; a per-lane load / wait / branch per
+  // component cost a third of the kernel (profiles/r01_rollout_ablation.txt).
+  constexpr int CPAR = NX + 3 * NDX;  // ref | act_w | lb | ub
+  static_assert(SM::NSLOT * CPAR <= SM::OFF_FR - SM::OFF_BODY, "cost parameter staging does not fit the dead LDS area");
   for (int base = 0; base < set.ncosts; base += SM::NSLOT) {
+    ex.sync();
+    ex.each([&](int lane, int sl) {
+      for (int q = 0; q < SM::NSLOT && base + q < set.ncosts; ++q) {
+        const EMPC_K EmpcCost& cq = set.costs[base + q];
+        if (!cq.active || cq.type != EMPC_COST_STATE) continue;
+        double* Pq = N + SM::OFF_BODY + q * CPAR;
+        for (int i = lane; i < CPAR; i += lpu) {
+          double v;
+          if (i < NX)
+            v = cq.ref[i];
+          else if (i < NX + NDX)
+            v = cq.act_w[i - NX];
+          else if (i < NX + 2 * NDX)
+            v = cq.lb[i - NX - NDX];
+          else
+            v = cq.ub[i - NX - 2 * NDX];
+          Pq[i] = v;
+        }
+      }
+    });
+    ex.sync();
     ex.each([&](int lane, int sl) {
       if (lane >= SM::NSLOT || base + lane >= set.ncosts) return;
       const EMPC_K EmpcCost& c = set.costs[base + lane];
@@ -856,21 +912,28 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
         S[3 * NDX + 36] = 0.0;
         return;
       }
-      double r[NDX], dpl[3], J6[36];
-      state_diff<DM>(c.ref, N + SM::OFF_X, r, dpl);
-      Jlog6(r, dpl, J6);
+      const int act = c.activation;
+      const double wgt = c.weight;
+      const double* xref = N + SM::OFF_BODY + lane * CPAR;
+      const double* pw = xref + NX;
+      const double* plb = pw + NDX;
+      const double* pub = plb + NDX;
+      // residual and log Jacobian go straight to their LDS slot (r | Ar | Arr | J6 | value): no 54-double register
+      // arrays next to the column accumulators
+      double* r = S;
+      double dpl[3];
+      state_diff<DM>(xref, N + SM::OFF_X, r, dpl);
+      Jlog6(r, dpl, S + 3 * NDX);
       double cv = 0;
 #pragma unroll
       for (int i = 0; i < NDX; ++i) {
         double av, Ar, Arr;
-        activation1(c.activation, r[i], c.act_w[i], c.lb[i], c.ub[i], av, Ar, Arr);
+        activation_sel(act, r[i], pw[i], plb[i], pub[i], av, Ar, Arr);
         cv += av;
-        S[NDX + i] = c.weight * Ar;
-        S[2 * NDX + i] = c.weight * Arr;
+        S[NDX + i] = wgt * Ar;
+        S[2 * NDX + i] = wgt * Arr;
       }
-#pragma unroll
-      for (int i = 0; i < 36; ++i) S[3 * NDX + i] = J6[i];
-      S[3 * NDX + 36] = c.weight * cv;
+      S[3 * NDX + 36] = wgt * cv;
     });
     ex.sync();
     ex.each([&](int lane, int sl) {
@@ -907,6 +970,7 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
     });
     ex.sync();
   }
+  LIN_STAMP(6);
   // round 2: Control costs (including the barrier): component k on u lane k
   ex.each([&](int lane, int sl) {
     const int k = lane - 2 * NV;
@@ -933,6 +997,7 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
       N[SM::OFF_RED] += a_;
     }
   });
+  LIN_STAMP(7);
   // round 3: frame costs, one at a time
   for (int ci = 0; FR && ci < set.ncosts; ++ci) {
     const EMPC_K EmpcCost& c = set.costs[ci];
@@ -1119,6 +1184,7 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
     }
   }
   ex.sync();
+  LIN_STAMP(8);
   // ---- S7: scale and store ---------------------------------------------------------------------------------------------
   const double cscale = (terminal && !P.prm.terminal_dt_scaling) ? 1.0 : dt;
   ex.each([&](int lane, int sl) {
@@ -1141,6 +1207,14 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
     }
     if (lane == 0) out[DM::OFF_COST] = N[SM::OFF_RED] * cscale;
   });
+  LIN_STAMP(9);
+#if defined(EMPC_STAMPS) && defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+  if (b == 0 && t == 10)
+    ex.each([&](int lane, int sl) {
+      if (lane == 0)
+        for (int i = 0; i < 10; ++i) D.dbg[32 + i] = lst[i];
+    });
+#endif
 }
 
 }  // namespace empc

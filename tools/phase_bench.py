@@ -38,8 +38,10 @@ units = {"linearize": B * (d.T + 1), "backward": B * d.T, "rollout": B * 10 * (d
 out = {k: {"ms": v, "GBs": units[k] * w[k] * 8 / (v * 1e-3) / 1e9} for k, v in res.items()}
 print(json.dumps(out))
 import ctypes as C
-cnt = (C.c_ulonglong * 24)()
+cnt = (C.c_ulonglong * 48)()
 empc.lib().empc_solver_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
-empc.lib().empc_solver_debug_counters(s._h, cnt, 24)
+empc.lib().empc_solver_debug_counters(s._h, cnt, 48)
 print('stage cycles (EMPC_STAMPS builds; rollout v1, trajectory 0, alpha 1/2): feedback|prep|rnea|crba|chol|kkt|euler|costs|-|tail', list(cnt)[:10])
 
+
+print('linearize stage cycles (unit b=0,t=10): S0 load|S1 squash/trig|S2 nominal+Euler|S3 tangent|S4 chol|S5 solves+Fx,Fu|S6 state costs|ctrl costs|frame costs|S7 store', list(cnt)[32:42])
