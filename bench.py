@@ -204,6 +204,8 @@ def main():
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_unit": words[dom] * 8, "units_per_launch": units / max(nlaunch, 1),
+                         "unit_definition": "(trajectory, step length, knot): one launch rolls out all %d step lengths of "
+                                            "the line search" % solver.stats_na() if dom == "rollout" else "(trajectory, knot)",
                          "avg_launch_ms": avg_ms},
             "iteration_roofline": {"algorithmic_bytes_per_traj_knot_iter": words["iteration"] * 8,
                                    "achieved_GBs": iters_total * d.T * words["iteration"] * 8 / elapsed / 1e9 / world,

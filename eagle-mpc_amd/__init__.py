@@ -239,6 +239,7 @@ class SolverSbFDDP:
         _check(lib().empc_solver_dims(self._h, *[C.byref(x) for x in v]))
         _, self.T, self.nx, self.ndx, self.nu, self.rec = [x.value for x in v]
         self._convergence_init = prm.convergence_init
+        self._n_alphas = prm.n_alphas
 
     # -- reference API -------------------------------------------------------------------------------------
     def solve(self, init_xs=None, init_us=None, maxiter=100, is_feasible=False, regInit=1e-9, x0s=None):
@@ -354,6 +355,10 @@ class SolverSbFDDP:
     iter = property(lambda self: int(self.iter_batch[0]))
     cost = property(lambda self: float(self.cost_batch[0]))
     stop = property(lambda self: float(self.stop_batch[0]))
+
+    def stats_na(self):
+        """step lengths tried per line search (SolverParams.n_alphas of this solver)"""
+        return int(self._n_alphas)
 
     def stats(self):
         s = T.SolveStats()

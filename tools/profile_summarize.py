@@ -15,11 +15,13 @@ import json
 import os
 import sys
 
-KERNELS = ("k_linearize", "k_backward", "k_rollout", "k_select", "k_calc", "k_squash_out", "k_plant_rk4")
+KERNELS = ("k_linearize_full", "k_linearize", "k_backward", "k_rollout", "k_select", "k_calc", "k_squash_out", "k_plant_rk4")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def short(name):
+    if "k_linearize" in name:  # two bodies per sweep: lean (no operational frames) and full
+        return "k_linearize_full" if "true>(" in name.replace(" ", "") else "k_linearize"
     for k in KERNELS:
         if k in name:
             return k
@@ -30,7 +32,7 @@ def stats(src, out):
     files = glob.glob(os.path.join(src, "**", "*kernel_stats.csv"), recursive=True)
     if not files:
         raise SystemExit("no *kernel_stats.csv under " + src)
-    rows = list(csv.DictReader(open(files[0])))
+    rows = list(csv.DictReader(open(max(files, key=os.path.getmtime))))  # newest run in the directory
     with open(out, "w", newline="") as f:
         w = csv.writer(f)
         w.writerow(["kernel", "calls", "total_ms", "avg_ms", "min_ms", "max_ms", "percent", "full_name"])
@@ -46,7 +48,7 @@ def counters(src, counter):
     if not files:
         raise SystemExit("no *counter_collection.csv under " + src)
     agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(files[0])):
+    for r in csv.DictReader(open(max(files, key=os.path.getmtime))):
         if r["Counter_Name"] == counter:
             agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
     return agg
@@ -55,6 +57,10 @@ def counters(src, counter):
 def traffic(fetch_dir, write_dir, tag):
     fe = counters(fetch_dir, "FETCH_SIZE")
     wr = counters(write_dir, "WRITE_SIZE")
+    if "k_linearize_full" in fe and "k_linearize_full" in wr:  # one linearize step of a sweep = both bodies
+        n = min(len(fe["k_linearize"]), len(fe["k_linearize_full"]), len(wr["k_linearize"]), len(wr["k_linearize_full"]))
+        fe["k_linearize"] = [a + b for a, b in zip(fe["k_linearize"][:n], fe["k_linearize_full"][:n])]
+        wr["k_linearize"] = [a + b for a, b in zip(wr["k_linearize"][:n], wr["k_linearize_full"][:n])]
     for k in ("k_linearize", "k_backward", "k_rollout"):
         if k not in fe or k not in wr:
             continue
@@ -83,7 +89,7 @@ def sq(dirs, out):
             raise SystemExit("no *counter_collection.csv under " + d)
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         meta = {}
-        for r in csv.DictReader(open(files[0])):
+        for r in csv.DictReader(open(max(files, key=os.path.getmtime))):
             k = short(r["Kernel_Name"])
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
             meta[k] = (r["VGPR_Count"], r["Accum_VGPR_Count"], r["SGPR_Count"], r["LDS_Block_Size"], r["Workgroup_Size"], r["Grid_Size"])
