@@ -2,7 +2,8 @@
 //
 //   linearize_unit2 HOT-A  (empc_linearize2.hpp) one (trajectory, node) unit per half wavefront: IAM calcDiff
 //   backward_traj2  HOT-B  (empc_backward2.hpp) one wavefront per trajectory: Riccati sweep, gains, expected improvement
-//   rollout_thread  HOT-C  one lane per (trajectory, step length): nonlinear forward pass
+//   rollout_wave5   HOT-C  one wavefront per trajectory, lanes = step lengths, feedback product by the whole wave
+//   rollout_thread         the same forward pass with one lane per (trajectory, step length): fallback / cross-check
 //   calc_thread            one lane per (trajectory, node): IAM calc at the current candidate (phase starts)
 //   select_traj            line-search acceptance, regularisation, stopping tests, continuation schedule
 //
@@ -13,8 +14,6 @@
 // Reference semantics: src/sbfddp.cpp (solve loop, acceptance rules, barrier/squash schedule) and SURVEY.md
 // Appendix A.1-A.7 (Crocoddyl / Pinocchio behaviour).  Everything is FP64.
 #pragma once
-#include <type_traits>
-
 #include "empc_dev_model.hpp"
 
 namespace empc {
