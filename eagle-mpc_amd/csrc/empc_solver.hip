@@ -694,51 +694,74 @@ int empc_solver_solve(EmpcSolver* s, int maxiter, int is_feasible) {
   HIP_CHECK(hipEventCreate(&t_end));
   HIP_CHECK(hipEventRecord(t_begin, s->stream));
   const int hard_cap = 4 * (3 * (maxiter + 1) + 8);  // (passes + clean-up) x maxiter can never be exceeded
+  // Every chunk runs its own sweep loop on its own stream; the host only retires a chunk's sweep (reads its active count)
+  // and queues the next one.  Chunks start staggered -- chunk c waits for chunk c-1's first backward pass -- so that the
+  // throughput-bound linearize of one chunk overlaps the latency-bound backward / rollout of the others instead of
+  // meeting the same kernel of its neighbours.
+  std::vector<int> pending(nchunks, 0), sweeps(nchunks, 0);
+  auto enqueue = [&](Chunk& c) {
+    HIP_CHECK(hipMemsetAsync(c.D.n_active, 0, sizeof(int), c.stream));
+    HIP_CHECK(hipEventRecord(c.ev[0], c.stream));
+    k.calc(c.D, c.stream);
+    HIP_CHECK(hipEventRecord(c.ev[1], c.stream));
+    k.linearize(c.D, c.stream);
+    HIP_CHECK(hipEventRecord(c.ev[2], c.stream));
+    k.backward(c.D, c.stream);
+    HIP_CHECK(hipEventRecord(c.ev[3], c.stream));
+    k.rollout(c.D, c.stream);
+    HIP_CHECK(hipEventRecord(c.ev[4], c.stream));
+    k.select(c.D, c.stream);
+    HIP_CHECK(hipEventRecord(c.ev[5], c.stream));
+    HIP_CHECK(hipMemcpyAsync(s->h_active + c.idx, c.D.n_active, sizeof(int), hipMemcpyDeviceToHost, c.stream));
+    pending[c.idx] = 1;
+  };
+  auto retire = [&](Chunk& c) {
+    HIP_CHECK(hipStreamSynchronize(c.stream));
+    auto el = [&](int a) {
+      float ms = 0;
+      return hipEventElapsedTime(&ms, c.ev[a], c.ev[a + 1]) == hipSuccess ? (double)ms : 0.0;
+    };
+    S.ms_calc += el(0);
+    S.ms_linearize += el(1);
+    S.ms_backward += el(2);
+    S.ms_rollout += el(3);
+    S.ms_select += el(4);
+    S.n_calc++;
+    S.n_linearize++;
+    S.n_backward++;
+    S.n_rollout++;
+    S.n_select++;
+    S.backward_units += (long long)c.active * s->T;
+    S.rollout_units += (long long)c.active * s->NA * (s->T + 1);
+    S.linearize_units += (long long)c.active * (s->T + 1);  // upper bound: trajectories that re-linearize this sweep
+    c.active = s->h_active[c.idx];
+    pending[c.idx] = 0;
+    sweeps[c.idx]++;
+  };
+  for (auto& c : chunks) {
+    if (c.idx > 0) HIP_CHECK(hipStreamWaitEvent(c.stream, chunks[c.idx - 1].ev[3], 0));  // stagger the first sweep
+    enqueue(c);
+  }
   int total_active = s->B;
-  while (total_active > 0 && S.sweeps < hard_cap) {
+  bool any_pending = true;
+  while (any_pending) {
+    any_pending = false;
     for (auto& c : chunks) {
-      if (c.active <= 0) continue;
-      HIP_CHECK(hipMemsetAsync(c.D.n_active, 0, sizeof(int), c.stream));
-      HIP_CHECK(hipEventRecord(c.ev[0], c.stream));
-      k.calc(c.D, c.stream);
-      HIP_CHECK(hipEventRecord(c.ev[1], c.stream));
-      k.linearize(c.D, c.stream);
-      HIP_CHECK(hipEventRecord(c.ev[2], c.stream));
-      k.backward(c.D, c.stream);
-      HIP_CHECK(hipEventRecord(c.ev[3], c.stream));
-      k.rollout(c.D, c.stream);
-      HIP_CHECK(hipEventRecord(c.ev[4], c.stream));
-      k.select(c.D, c.stream);
-      HIP_CHECK(hipEventRecord(c.ev[5], c.stream));
-      HIP_CHECK(hipMemcpyAsync(s->h_active + c.idx, c.D.n_active, sizeof(int), hipMemcpyDeviceToHost, c.stream));
-    }
-    total_active = 0;
-    for (auto& c : chunks) {
-      if (c.active <= 0) continue;
-      HIP_CHECK(hipStreamSynchronize(c.stream));
-      auto el = [&](int a) {
-        float ms = 0;
-        return hipEventElapsedTime(&ms, c.ev[a], c.ev[a + 1]) == hipSuccess ? (double)ms : 0.0;
-      };
-      S.ms_calc += el(0);
-      S.ms_linearize += el(1);
-      S.ms_backward += el(2);
-      S.ms_rollout += el(3);
-      S.ms_select += el(4);
-      S.n_calc++;
-      S.n_linearize++;
-      S.n_backward++;
-      S.n_rollout++;
-      S.n_select++;
-      S.backward_units += (long long)c.active * s->T;
-      S.rollout_units += (long long)c.active * s->NA * (s->T + 1);
-      S.linearize_units += (long long)c.active * (s->T + 1);  // upper bound: trajectories that re-linearize this sweep
-      c.active = s->h_active[c.idx];
-      total_active += c.active;
+      if (!pending[c.idx]) continue;
+      retire(c);
+      if (c.active > 0 && sweeps[c.idx] < hard_cap) {
+        enqueue(c);
+        any_pending = true;
+      }
     }
     HIP_CHECK(hipGetLastError());
-    S.sweeps++;
   }
+  total_active = 0;
+  for (auto& c : chunks) {
+    total_active += c.active;
+    S.sweeps = std::max(S.sweeps, sweeps[c.idx]);
+  }
+  for (int c = 1; c < nchunks; ++c) HIP_CHECK(hipStreamSynchronize(chunks[c].stream));
   HIP_CHECK(hipEventRecord(t_end, s->stream));
   download_states(s);
   float ms = 0;
