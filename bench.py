@@ -221,6 +221,16 @@ def main():
             n_sample = int(min(B, max(cores * 4, 8)))
             r = ob.solve_batch(d, x0s[:n_sample], args.maxiter, nthreads=cores, want_traj=False)
             cpu_iters = float((r["iter"] + 1).sum())
+            # north-star parity figure: max-abs error of the GPU trajectories against the CPU oracle on identical inputs
+            # (a few rollouts of the same batch; the oracle here is the checker, never the thing measured)
+            n_par = int(min(8, n_sample))
+            rp = ob.solve_batch(d, x0s[:n_par], args.maxiter, nthreads=min(cores, n_par), want_traj=True)
+            gx, gu, gc, gi = solver.xs_batch[:n_par], solver.us_batch[:n_par], solver.cost_batch[:n_par], solver.iter_batch[:n_par]
+            out["parity"] = {"rollouts": n_par, "xs_max_abs_err": float(np.abs(gx - rp["xs"]).max()),
+                             "us_max_abs_err": float(np.abs(gu - rp["us"]).max()),
+                             "cost_max_rel_err": float((np.abs(gc - rp["cost"]) / (1.0 + np.abs(rp["cost"]))).max()),
+                             "iterations_equal": bool((gi == rp["iter"]).all()), "tolerance": 1e-4,
+                             "reference": "oracle/liboracle.so (CPU restatement; parity unpinned, DESIGN.md)"}
             out["cpu_baseline"] = {"value": cpu_iters / B / r["seconds"], "unit": out["unit"], "cores": cores, "kind": "port",
                                    "sample": "%d of the %d rollouts of rank 0, OpenMP over rollouts, oracle/liboracle.so "
                                              "(FP64 C++ restatement, not Crocoddyl)" % (n_sample, B),
