@@ -20,6 +20,7 @@
 #include "empc_prep.hpp"
 #include "empc_linearize2.hpp"
 #include "empc_backward2.hpp"
+#include "empc_backward3.hpp"
 
 using namespace empc;
 
@@ -101,6 +102,15 @@ struct BlockExec {
   __device__ __forceinline__ bool any(F&& f) {
     return __syncthreads_or(f(lane, 0) ? 1 : 0) != 0;
   }
+  // one v_mfma_f64_16x16x4_f64 of the wavefront: acc[im][in] += A-operand a[ia] x B-operand b[ib] (per-lane values)
+  template <class A, class B, class C>
+  __device__ __forceinline__ void mfma(A& a, int ia, B& b, int ib, C& c, int im, int in) {
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    d4 v = {c[0][im][in][0], c[0][im][in][1], c[0][im][in][2], c[0][im][in][3]};
+    v = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][ia], b[0][ib], v, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c[0][im][in][r] = v[r];
+  }
 };
 
 #ifndef EMPC_BWD_NL
@@ -112,6 +122,14 @@ __global__ void __launch_bounds__(EMPC_BWD_NL) k_backward(DevBuffers D) {
   const int b = blockIdx.x;
   BlockExec ex{(int)threadIdx.x};
   backward_traj2<DM, EMPC_BWD_NL>(ex, D, b, smem_bwd);
+}
+
+// matrix-core form of the backward pass (one wavefront per trajectory)
+template <class DM>
+__global__ void __launch_bounds__(64) k_backward3(DevBuffers D) {
+  extern __shared__ double smem_bwd3[];
+  BlockExec ex{(int)threadIdx.x};
+  backward_traj3<DM>(ex, D, blockIdx.x, smem_bwd3);
 }
 
 template <class DM>
@@ -230,7 +248,14 @@ static void launch_linearize(DevBuffers D, hipStream_t s) {
 }
 template <class DM>
 static void launch_backward(DevBuffers D, hipStream_t s) {
-  hipLaunchKernelGGL(k_backward<DM>, dim3(D.B), dim3(EMPC_BWD_NL), sizeof(double) * Bwd2Smem<DM>::SIZE, s, D);
+  static const int version = [] {
+    const char* e = getenv("EMPC_BACKWARD");  // 2 = vector form, 3 = matrix-core form
+    return e ? atoi(e) : 3;
+  }();
+  if (version == 2)
+    hipLaunchKernelGGL(k_backward<DM>, dim3(D.B), dim3(EMPC_BWD_NL), sizeof(double) * Bwd2Smem<DM>::SIZE, s, D);
+  else
+    hipLaunchKernelGGL(k_backward3<DM>, dim3(D.B), dim3(64), sizeof(double) * Bwd3Smem<DM>::SIZE, s, D);
 }
 template <class DM, bool CT>
 static void launch_rollout(DevBuffers D, hipStream_t s) {

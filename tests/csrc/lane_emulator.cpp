@@ -9,6 +9,7 @@
 #include "../../eagle-mpc_amd/csrc/empc_prep.hpp"
 #include "../../eagle-mpc_amd/csrc/empc_linearize2.hpp"
 #include "../../eagle-mpc_amd/csrc/empc_backward2.hpp"
+#include "../../eagle-mpc_amd/csrc/empc_backward3.hpp"
 
 using namespace empc;
 
@@ -26,6 +27,20 @@ struct CpuExec {
     bool r = false;
     for (int l = 0; l < nl; ++l) r = f(l, l) || r;
     return r;
+  }
+  // v_mfma_f64_16x16x4_f64 semantics on per-lane operands: A[i = l % 16][k = l / 16], B[k = l / 16][j = l % 16],
+  // D[i = 4 r + l / 16][j = l % 16] (layout verified on gfx950 by tools/probes/mfma_f64_layout.hip)
+  template <class A, class B, class C>
+  void mfma(A& a, int ia, B& b, int ib, C& c, int im, int in) {
+    double Dm[16][16];
+    for (int i = 0; i < 16; ++i)
+      for (int j = 0; j < 16; ++j) {
+        double s = c[(i % 4) * 16 + j][im][in][i / 4];
+        for (int k = 0; k < 4; ++k) s += a[k * 16 + i][ia] * b[k * 16 + j][ib];
+        Dm[i][j] = s;
+      }
+    for (int i = 0; i < 16; ++i)
+      for (int j = 0; j < 16; ++j) c[(i % 4) * 16 + j][im][in][i / 4] = Dm[i][j];
   }
 };
 
@@ -136,7 +151,13 @@ static int g_bwd_version = 2;
 template <class DM>
 static void emu_backward(Emu& e) {
   std::vector<double> smem(Bwd2Smem<DM>::SIZE);
+  std::vector<double> smem3(Bwd3Smem<DM>::SIZE);
   for (int b = 0; b < e.B; ++b) {
+    if (g_bwd_version == 3) {
+      CpuExec<64> ex{64};
+      backward_traj3<DM>(ex, e.D, b, smem3.data());  // the shipped matrix-core form
+      continue;
+    }
     if (g_bwd_version == 2) {
       CpuExec<256> ex{256};
       backward_traj2<DM, 256>(ex, e.D, b, smem.data());  // four-wavefront tiling
