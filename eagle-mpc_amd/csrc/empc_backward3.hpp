@@ -12,13 +12,26 @@
 
 namespace empc {
 
+#if defined(EMPC_STAMPS) && defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+#define BWD_STAMP(i)                                              \
+  do {                                                            \
+    const unsigned long long now_ = __builtin_readcyclecounter(); \
+    bst[i] += now_ - bst[15];                                     \
+    bst[15] = now_;                                               \
+  } while (0)
+#else
+#define BWD_STAMP(i) \
+  do {               \
+  } while (0)
+#endif
+
 template <class DM>
 struct Bwd3Smem {
   static constexpr int n = DM::NDX, m = DM::NU, nm = n + m;
   static constexpr int WLD = ((nm + 1 + 15) / 16) * 16;  // W rows hold nm columns + the Vx' column, padded to whole tiles
   static constexpr int QLD = nm + 1;
   static constexpr int OFF_REC = 0;
-  static constexpr int OFF_V = DM::REC;
+  static constexpr int OFF_V = (DM::REC + 63) / 64 * 64;  // the record is staged in whole 64-double rows
   static constexpr int OFF_VX = OFF_V + n * n;
   static constexpr int OFF_W = OFF_VX + n;        // n x nm
   static constexpr int OFF_Q = OFF_W + n * WLD;   // nm x nm (leading dimension QLD)
@@ -27,6 +40,7 @@ struct Bwd3Smem {
   static constexpr int OFF_KF = OFF_K + m * n;    // k (m), Quuk (m)
   static constexpr int OFF_RED = OFF_KF + 2 * m;  // 4 x 32 partial sums
   static constexpr int OFF_FLAG = OFF_RED + 128;
+  static constexpr int OFF_DUMP = OFF_FLAG + 6;   // write-only word: accumulator entries outside a matrix land here
   static constexpr int OFF_PRO = OFF_FLAG + 8;    // prologue reductions: 3 x 256
   static constexpr int SIZE = (OFF_PRO + 3 * 256 + 1) / 2 * 2;
 };
@@ -100,6 +114,29 @@ EMPC_HD void backward_traj3(Exec& ex, const DevBuffers& D, int b, double* smem) 
   }
   const bool infeas = !is_feasible;
 
+  // where each accumulator entry of the Q stage starts from: H = [[Lxx Lxu | Lx], [. Luu | Lu]] inside the record
+  int hidx[Exec::SLOTS][(DM::NDX + DM::NU + 15) / 16][(DM::NDX + DM::NU + 1 + 15) / 16][4];
+  ex.each([&](int lane, int sl) {
+    const int lj = lane % 16, lq = lane / 16;
+#pragma unroll
+    for (int mt = 0; mt < MTQ; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NTQ; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * mt + 4 * r + lq, j = 16 * nt + lj;
+          int idx = -1;
+          if (i < n && j < nm)
+            idx = DM::OFF_HX + i * nm + j;
+          else if (i < n && j == nm)
+            idx = DM::OFF_LX + i;
+          else if (i >= n && i < nm && j >= n && j < nm)
+            idx = DM::OFF_LUU + (i - n) * m + (j - n);
+          else if (i >= n && i < nm && j == nm)
+            idx = DM::OFF_LU + (i - n);
+          hidx[sl][mt][nt][r] = idx;
+        }
+  });
   double xreg = st.xreg, ureg = st.ureg;
   double dg_u = 0, dq_u = 0, dg_f = 0, dq_f = 0, qu2 = 0;
   bool failed_final = false;
@@ -144,28 +181,26 @@ EMPC_HD void backward_traj3(Exec& ex, const DevBuffers& D, int b, double* smem) 
     ex.each([&](int lane, int sl) {
       const double* r = tape + (size_t)(T - 1) * REC;
 #pragma unroll
-      for (int q = 0; q < PRE; ++q) {
-        const int i = lane + q * NL;
-        pre[sl][q] = (i < REC) ? r[i] : 0.0;
-      }
+      for (int q = 0; q < PRE; ++q) pre[sl][q] = r[lane + q * NL];  // whole rows: the tape has one row of slack
     });
+#if defined(EMPC_STAMPS) && defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+    unsigned long long bst[16];
+    for (int i = 0; i < 16; ++i) bst[i] = 0;
+    bst[15] = __builtin_readcyclecounter();
+#endif
     for (int t = T - 1; t >= 0; --t) {
+      BWD_STAMP(7);
       ex.each([&](int lane, int sl) {
 #pragma unroll
-        for (int q = 0; q < PRE; ++q) {
-          const int i = lane + q * NL;
-          if (i < REC) rec[i] = pre[sl][q];
-        }
+        for (int q = 0; q < PRE; ++q) rec[lane + q * NL] = pre[sl][q];
         if (t > 0) {
           const double* r = tape + (size_t)(t - 1) * REC;
 #pragma unroll
-          for (int q = 0; q < PRE; ++q) {
-            const int i = lane + q * NL;
-            pre[sl][q] = (i < REC) ? r[i] : 0.0;
-          }
+          for (int q = 0; q < PRE; ++q) pre[sl][q] = r[lane + q * NL];
         }
       });
       ex.sync();
+      BWD_STAMP(0);
       // W = V' A, A = [Fx Fu]: MTN x NTQ tiles, KSN steps; out-of-range operand entries are zeros
       double accW[Exec::SLOTS][MTN][NTQ][4];
       ex.each([&](int lane, int sl) {
@@ -209,39 +244,24 @@ EMPC_HD void backward_traj3(Exec& ex, const DevBuffers& D, int b, double* smem) 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int i = 16 * mt + 4 * r + lq, j = 16 * nt + lj;
-              if (i < n && j < nm) W[i * WLD + j] = accW[sl][mt][nt][r];
+              smem[(i < n && j < nm) ? SM::OFF_W + i * WLD + j : SM::OFF_DUMP] = accW[sl][mt][nt][r];  // branch-free store
             }
         if (lane < n) W[lane * WLD + nm] = vx[lane];  // extra column: Vx' (gives Qx, Qu in column nm of Q)
       });
       ex.sync();
+      BWD_STAMP(1);
       // Q = H + A^T [W | Vx']: MTQ x NTQ tiles, KSN steps; accumulators start from H = [[Lxx Lxu | Lx], [. Luu | Lu]]
       double accQ[Exec::SLOTS][MTQ][NTQ][4];
       ex.each([&](int lane, int sl) {
-        const int lj = lane % 16, lq = lane / 16;
 #pragma unroll
         for (int mt = 0; mt < MTQ; ++mt)
 #pragma unroll
           for (int nt = 0; nt < NTQ; ++nt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const int i = 16 * mt + 4 * r + lq, j = 16 * nt + lj;
-              int idx = 0;
-              bool ok = false;
-              if (i < n && j < nm) {
-                idx = DM::OFF_HX + i * nm + j;
-                ok = true;
-              } else if (i < n && j == nm) {
-                idx = DM::OFF_LX + i;
-                ok = true;
-              } else if (i >= n && i < nm && j >= n && j < nm) {
-                idx = DM::OFF_LUU + (i - n) * m + (j - n);
-                ok = true;
-              } else if (i >= n && i < nm && j == nm) {
-                idx = DM::OFF_LU + (i - n);
-                ok = true;
-              }
-              const double v = rec[idx];
-              accQ[sl][mt][nt][r] = ok ? v : 0.0;
+              const int idx = hidx[sl][mt][nt][r];  // position of H's entry in the record, -1 outside H
+              const double v = rec[idx < 0 ? 0 : idx];
+              accQ[sl][mt][nt][r] = (idx < 0) ? 0.0 : v;
             }
       });
 #pragma unroll
@@ -277,11 +297,14 @@ EMPC_HD void backward_traj3(Exec& ex, const DevBuffers& D, int b, double* smem) 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int i = 16 * mt + 4 * r + lq, j = 16 * nt + lj;
-              if (i < nm && j < nm && !(i >= n && j < n)) Q[i * QLD + j] = accQ[sl][mt][nt][r];
-              if (i < nm && j == nm) qv[i] = accQ[sl][mt][nt][r];
+              int dst = SM::OFF_DUMP;
+              if (i < nm && j < nm && !(i >= n && j < n)) dst = SM::OFF_Q + i * QLD + j;
+              if (i < nm && j == nm) dst = SM::OFF_QV + i;
+              smem[dst] = accQ[sl][mt][nt][r];
             }
       });
       ex.sync();
+      BWD_STAMP(2);
       // computeGains in the first wavefront: LLT(Quu + ureg I); K = Quu^-1 Qxu^T ; k = Quu^-1 Qu ; Quuk
       ex.each([&](int lane, int sl) {
         if (lane >= 64) return;
@@ -323,6 +346,7 @@ EMPC_HD void backward_traj3(Exec& ex, const DevBuffers& D, int b, double* smem) 
         dq_u -= kf[i] * kf[m + i];
         qu2 += qv[n + i] * qv[n + i];
       }
+      BWD_STAMP(3);
       // gains out; Vx = Qx + K^T Quuk - 2 K^T Qu (into red); Vxx = Qxx - Qxu K on the matrix cores: the Qxx tiles are
       // still in the accumulators of the Q stage, A operand = -Qxu, B operand = K
       ex.each([&](int lane, int sl) {
@@ -367,10 +391,11 @@ EMPC_HD void backward_traj3(Exec& ex, const DevBuffers& D, int b, double* smem) 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int i = 16 * mt + 4 * r + lq, j = 16 * nt + lj;
-              if (i < n && j < n) W[i * WLD + j] = accQ[sl][mt][nt][r];
+              smem[(i < n && j < n) ? SM::OFF_W + i * WLD + j : SM::OFF_DUMP] = accQ[sl][mt][nt][r];
             }
       });
       ex.sync();
+      BWD_STAMP(4);
       // symmetrise + regularise -> V; NaN / overflow guard folded into the same pass
       const bool badV = ex.any([&](int lane, int sl) {
         bool bad = false;
@@ -382,6 +407,7 @@ EMPC_HD void backward_traj3(Exec& ex, const DevBuffers& D, int b, double* smem) 
         }
         return bad;
       });
+      BWD_STAMP(5);
       // gap contribution: Vx += Vxx f ; sums for the expected improvement
       ex.each([&](int lane, int sl) {
         if (lane >= n) return;
@@ -408,7 +434,15 @@ EMPC_HD void backward_traj3(Exec& ex, const DevBuffers& D, int b, double* smem) 
         fail = true;
         break;
       }
+      BWD_STAMP(6);
     }
+#if defined(EMPC_STAMPS) && defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+    if (b == 0)
+      ex.each([&](int lane, int sl) {
+        if (lane == 0)
+          for (int i = 0; i < 8; ++i) D.dbg[16 + i] = bst[i];
+      });
+#endif
     ex.sync();
     if (!fail) break;
     xreg *= P.prm.reg_incfactor;

@@ -461,7 +461,7 @@ EmpcSolver* empc_solver_create(const EmpcProblemDesc* problem, const EmpcSolverP
   D.xs = s->dalloc<double>(B * (T + 1) * k.nx);
   D.us = s->dalloc<double>(B * T * k.nu);
   D.acc = s->dalloc<double>(B * (T + 1) * k.nacc);
-  D.tape = s->dalloc<double>(B * (T + 1) * k.rec);
+  D.tape = s->dalloc<double>(B * (T + 1) * k.rec + 64);  // + one wavefront of slack: the backward pass prefetches whole 64-double rows
   D.K = s->dalloc<double>(B * T * k.nu * k.ndx);
   D.kff = s->dalloc<double>(B * T * k.nu);
   D.Vx = s->dalloc<double>(B * (T + 1) * k.ndx);

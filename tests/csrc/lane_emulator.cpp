@@ -69,7 +69,7 @@ static void emu_alloc(Emu& e) {
   e.xs.assign((size_t)B * (T + 1) * DM::NX, 0);
   e.us.assign((size_t)B * T * DM::NU, 0);
   e.acc.assign((size_t)B * (T + 1) * DM::NACC, 0);
-  e.tape.assign((size_t)B * (T + 1) * DM::REC, 0);
+  e.tape.assign((size_t)B * (T + 1) * DM::REC + 64, 0);  // slack for the backward pass's whole-row prefetch
   e.K.assign((size_t)B * T * DM::NU * DM::NDX, 0);
   e.kff.assign((size_t)B * T * DM::NU, 0);
   e.Vx.assign((size_t)B * (T + 1) * DM::NDX, 0);
@@ -306,7 +306,7 @@ void emu_phase_linearize(void* h, double* tape, double* acc) {
   Emu* e = static_cast<Emu*>(h);
   DISPATCH(e, emu_calc, *e);
   DISPATCH(e, emu_linearize, *e);
-  if (tape) std::memcpy(tape, e->tape.data(), sizeof(double) * e->tape.size());
+  if (tape) std::memcpy(tape, e->tape.data(), sizeof(double) * (e->tape.size() - 64));
   if (acc) {
     const int nacc = e->nv + 6;
     for (size_t u = 0; u < (size_t)e->B * (e->T + 1); ++u) std::memcpy(acc + u * e->nv, &e->acc[u * nacc], sizeof(double) * e->nv);
