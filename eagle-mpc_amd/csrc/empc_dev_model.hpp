@@ -782,9 +782,10 @@ EMPC_HD void node_nominal(const EMPC_K DevProblem& P, const SetT& set, double sm
   EMPC_STAMP(4);  // Cholesky + solve
   double lam[6] = {0, 0, 0, 0, 0, 0};
   if constexpr (CT) if (use_contact) {
-    // ContactModel3D/6D: [M Jc^T; Jc 0][a; -lam] = [tau - h; -a0]
+    // ContactModel3D: [M Jc^T; Jc 0][a; -lam] = [tau - h; -a0].  Three constraint rows, fixed at compile time
+    // (prepare_problem refuses 6D contacts): every loop below unrolls and Jc / M^-1 Jc^T stay in registers.
     const auto& ct = set.contacts[0];
-    const int nc = (ct.type == EMPC_CONTACT_3D) ? 3 : 6;
+    constexpr int nc = 3;
     FrameCap<double> ck = caps[0];
 #pragma unroll
     for (int kk = 1; kk < NCAP; ++kk)
@@ -793,25 +794,24 @@ EMPC_HD void node_nominal(const EMPC_K DevProblem& P, const SetT& set, double sm
     // reaches every frame as the pure translation R_f^T (-g); take it out again
     double ng[3] = {-m.gravity[0], -m.gravity[1], -m.gravity[2]}, gf[3], a0[6];
     matTvec3<double>(ck.R, ng, gf);
-    if (nc == 3) {
+    {
       double wxv[3];
-      cross3<double>(ck.v + 3, ck.v, wxv);
+      cross3<double>(ck.v + 3, ck.v, wxv);  // classical acceleration of the contact point
+#pragma unroll
       for (int r = 0; r < 3; ++r) a0[r] = (ck.a[r] - gf[r]) + wxv[r];
-    } else {
-      for (int r = 0; r < 3; ++r) a0[r] = ck.a[r] - gf[r];
-      for (int r = 3; r < 6; ++r) a0[r] = ck.a[r];
     }
-    if (ct.gains[0] != 0.0 && nc == 3) {
+    if (ct.gains[0] != 0.0) {
       double dp[3], dpl[3];
       for (int r = 0; r < 3; ++r) dp[r] = ck.p[r] - ct.ref_p[r];
       matTvec3<double>(ck.R, dp, dpl);
       for (int r = 0; r < 3; ++r) a0[r] += ct.gains[0] * dpl[r];
     }
     if (ct.gains[1] != 0.0)
+#pragma unroll
       for (int r = 0; r < nc; ++r) a0[r] += ct.gains[1] * ck.v[r];
     // Jc: LOCAL frame Jacobian from the kinematics (column j = [R_f^T (z_j x (p_f - o_j)); R_f^T z_j] for a rotation about
     // the world axis z_j through o_j, R_f^T e_j for the base translations), joints after the frame's body contribute nothing
-    double Jc[6][NV], MiJt[6][NV];
+    double Jc[nc][NV], MiJt[nc][NV];
     {
       const int bf = m.frame_body[ct.frame];
 #pragma unroll
@@ -819,10 +819,7 @@ EMPC_HD void node_nominal(const EMPC_K DevProblem& P, const SetT& set, double sm
         double w[3] = {R0[j], R0[3 + j], R0[6 + j]}, lin[3];
         matTvec3<double>(ck.R, w, lin);
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-          Jc[r][j] = lin[r];
-          Jc[3 + r][j] = 0.0;
-        }
+        for (int r = 0; r < 3; ++r) Jc[r][j] = lin[r];
       }
       double Rw[9], pw[3];
 #pragma unroll
@@ -852,44 +849,39 @@ EMPC_HD void node_nominal(const EMPC_K DevProblem& P, const SetT& set, double sm
           matvec3<double>(Rw, ax, z);
           on_path = (b <= bf);
         }
-        double d[3] = {ck.p[0] - pw[0], ck.p[1] - pw[1], ck.p[2] - pw[2]}, zxd[3], lin[3], ang[3];
+        double d[3] = {ck.p[0] - pw[0], ck.p[1] - pw[1], ck.p[2] - pw[2]}, zxd[3], lin[3];
         cross3<double>(z, d, zxd);
         matTvec3<double>(ck.R, zxd, lin);
-        matTvec3<double>(ck.R, z, ang);
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-          Jc[r][j] = on_path ? lin[r] : 0.0;
-          Jc[3 + r][j] = on_path ? ang[r] : 0.0;
-        }
+        for (int r = 0; r < 3; ++r) Jc[r][j] = on_path ? lin[r] : 0.0;
       }
     }
-    double G[21];  // packed nc x nc
+    double G[nc * (nc + 1) / 2];  // packed nc x nc
+#pragma unroll
     for (int r = 0; r < nc; ++r) {
 #pragma unroll
       for (int i = 0; i < NV; ++i) MiJt[r][i] = Jc[r][i];
       chol_solve_packed<NV>(L, MiJt[r]);
     }
+#pragma unroll
     for (int r = 0; r < nc; ++r)
+#pragma unroll
       for (int c = 0; c <= r; ++c) {
         double g = 0;
 #pragma unroll
         for (int i = 0; i < NV; ++i) g += Jc[r][i] * MiJt[c][i];
         G[r * (r + 1) / 2 + c] = g;
       }
-    if (nc == 3)
-      chol_packed<3>(G);
-    else
-      chol_packed<6>(G);
+    chol_packed<nc>(G);
+#pragma unroll
     for (int r = 0; r < nc; ++r) {
       double g = a0[r];
 #pragma unroll
       for (int i = 0; i < NV; ++i) g += Jc[r][i] * a[i];
       lam[r] = -g;
     }
-    if (nc == 3)
-      chol_solve_packed<3>(G, lam);
-    else
-      chol_solve_packed<6>(G, lam);
+    chol_solve_packed<nc>(G, lam);
+#pragma unroll
     for (int r = 0; r < nc; ++r)
 #pragma unroll
       for (int i = 0; i < NV; ++i) a[i] += MiJt[r][i] * lam[r];
@@ -914,17 +906,11 @@ EMPC_HD void node_nominal(const EMPC_K DevProblem& P, const SetT& set, double sm
   for (int ci = 0; ci < set.ncosts; ++ci) {
     const auto& c = set.costs[ci];
     if (!c.active || c.type != EMPC_COST_CONTACT_FRICTION_CONE) continue;
-    double AR[5][3];
-    double nsf[3] = {c.ref[0], c.ref[1], c.ref[2]};
-    cone_rows(nsf, c.ref[3], AR);
-    double cval = 0;
-    for (int i = 0; i < 5; ++i) {
-      double r = use_contact ? (AR[i][0] * lam[0] + AR[i][1] * lam[1] + AR[i][2] * lam[2]) : 0.0;
-      double av, Ar, Arr;
-      activation1(c.activation, r, c.act_w[i], c.lb[i], c.ub[i], av, Ar, Arr);
-      cval += av;
-    }
-    ell += c.weight * cval;
+    double r[6] = {0, 0, 0, 0, 0, 0};  // rows of A R_n^T precomputed by prepare_problem in ref[4..18]
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+      r[i] = use_contact ? (c.ref[4 + 3 * i] * lam[0] + c.ref[5 + 3 * i] * lam[1] + c.ref[6 + 3 * i] * lam[2]) : 0.0;
+    ell += c.weight * activation_value<6>(c, r, 5);
   }
   ell += ell_frames;
   const double cscale = (terminal && !P.prm.terminal_dt_scaling) ? 1.0 : dt;

@@ -1121,8 +1121,9 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
       ex.sync();
       ex.each([&](int lane, int sl) {
         if (lane != 0) return;
-        double AR[5][3], nsf[3] = {c.ref[0], c.ref[1], c.ref[2]};
-        cone_rows(nsf, c.ref[3], AR);
+        double AR[5][3];  // A R_n^T, precomputed by prepare_problem in ref[4..18]
+        for (int i = 0; i < 5; ++i)
+          for (int j = 0; j < 3; ++j) AR[i][j] = c.ref[4 + 3 * i + j];
         double cv = 0;
         for (int i = 0; i < 5; ++i) {
           const double r = AR[i][0] * N[SM::OFF_LAM] + AR[i][1] * N[SM::OFF_LAM + 1] + AR[i][2] * N[SM::OFF_LAM + 2];

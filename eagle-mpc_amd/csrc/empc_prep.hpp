@@ -100,6 +100,18 @@ inline void prepare_problem(const EmpcProblemDesc& d, const EmpcSolverParams& pr
           break;
         }
     }
+  // friction-cone costs: the 5 x 3 matrix A R_n^T depends only on the cost's normal and mu; computed here once and kept
+  // in the cost's reference payload (ref[4..18]) so that the kernels do not rebuild it (sqrt / atan2 / sin / cos) per node
+  for (auto& s : H.sets)
+    for (int i = 0; i < s.ncosts; ++i) {
+      EmpcCost& c = s.costs[i];
+      if (c.type != EMPC_COST_CONTACT_FRICTION_CONE) continue;
+      double AR[5][3];
+      const double nsf[3] = {c.ref[0], c.ref[1], c.ref[2]};
+      cone_rows(nsf, c.ref[3], AR);
+      for (int r = 0; r < 5; ++r)
+        for (int j = 0; j < 3; ++j) c.ref[4 + 3 * r + j] = AR[r][j];
+    }
   // frame-capture capacity per cost set
   for (auto& s : H.sets) {
     int frames[EMPC_MAX_COSTS], nf = 0;
