@@ -39,6 +39,8 @@ struct DevBuffers {
   const DevProblem* P;
   const EmpcCostSet* sets;
   const int* knot_set;
+  const int* lin_knots;  // [T+1] knots sorted: first the n_lean knots whose cost set captures no operational frames, then the rest
+  int n_lean;            // linearize runs its lean body over the first group and the full body over the second
   TrajState* st;
   double* x0;       // [B][NX]
   double* xs;       // [B][T+1][NX]
@@ -59,7 +61,6 @@ struct DevBuffers {
   int* n_active;    // [1]
   unsigned long long* dbg;  // [64] cycle stamps of diagnostic builds (EMPC_STAMPS); unused otherwise
   int B, T, NA;
-  int any_frames;   // some cost set of the problem captures operational frames (linearize launches its full body too)
   double gaptol;    // feasibility tolerance actually used: max(th_gaptol, 1e-13)
 };
 

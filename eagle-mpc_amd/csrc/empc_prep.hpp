@@ -144,11 +144,21 @@ inline void prepare_problem(const EmpcProblemDesc& d, const EmpcSolverParams& pr
 namespace empc {
 // State of one trajectory at the start of SolverSbFDDP::solve (src/sbfddp.cpp:198-210).  `prev` carries the members
 // that the reference keeps across solve() calls (cost_, cost_prev_, stop_).
-// does any cost set capture operational frames?  (flag written by prepare_problem)
-inline int problem_uses_frames(const HostProblem& H) {
-  for (const auto& s : H.sets)
-    if (s.ncosts > 0 && (s.costs[0].reserved & 1)) return 1;
-  return 0;
+// knots grouped for linearize: the lean ones (cost set without operational frames, flag written by prepare_problem)
+// first, the others after; returns the size of the first group
+inline int group_linearize_knots(const HostProblem& H, std::vector<int>& order) {
+  order.clear();
+  const int n = (int)H.knot_set.size();
+  auto uses = [&](int t) {
+    const EmpcCostSet& s = H.sets[H.knot_set[t]];
+    return s.ncosts > 0 && (s.costs[0].reserved & 1);
+  };
+  for (int t = 0; t < n; ++t)
+    if (!uses(t)) order.push_back(t);
+  const int n_lean = (int)order.size();
+  for (int t = 0; t < n; ++t)
+    if (uses(t)) order.push_back(t);
+  return n_lean;
 }
 
 inline void init_traj_state(TrajState& s, const EmpcSolverParams& prm, int maxiter, bool is_feasible_arg,

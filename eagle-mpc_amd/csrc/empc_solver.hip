@@ -75,9 +75,10 @@ k_linearize(DevBuffers D) {
   constexpr int USZ = CT ? Lin2Smem<DM>::SIZE : Lin2Smem<DM>::SIZE_NC;
   const int unit = blockIdx.x * UPB + threadIdx.x / LPU;
   const int lane = threadIdx.x % LPU;
-  const int n_units = D.B * (D.T + 1);
-  if (unit >= n_units) return;
-  const int t = unit / D.B, b = unit % D.B;
+  // this body's knots: the lean group or the rest of the sorted knot list
+  const int k0 = FR ? D.n_lean : 0, nk = FR ? (D.T + 1 - D.n_lean) : D.n_lean;
+  if (unit >= D.B * nk) return;
+  const int t = EMPC_KPTR(int, D.lin_knots)[k0 + unit / D.B], b = unit % D.B;
   const TrajState& st = D.st[b];
   if (st.phase == PHASE_DONE || !st.need_lin) return;
   LaneExec ex{lane};
@@ -229,9 +230,10 @@ static void launch_linearize_blk(DevBuffers D, hipStream_t s) {
     return true;
   }();
   (void)once;
-  // lean body for the units without operational frames, full body for the rest; each unit runs in exactly one of them
-  hipLaunchKernelGGL((k_linearize<DM, CT, LPU, BLK, false>), dim3((n + UPB - 1) / UPB), dim3(BLK), smem, s, D);
-  if (D.any_frames) hipLaunchKernelGGL((k_linearize<DM, CT, LPU, BLK, true>), dim3((n + UPB - 1) / UPB), dim3(BLK), smem, s, D);
+  // lean body over the knots without operational frames, full body over the rest; every unit runs in exactly one of them
+  const int n_lean = D.B * D.n_lean, n_full = D.B * (D.T + 1 - D.n_lean);
+  if (n_lean > 0) hipLaunchKernelGGL((k_linearize<DM, CT, LPU, BLK, false>), dim3((n_lean + UPB - 1) / UPB), dim3(BLK), smem, s, D);
+  if (n_full > 0) hipLaunchKernelGGL((k_linearize<DM, CT, LPU, BLK, true>), dim3((n_full + UPB - 1) / UPB), dim3(BLK), smem, s, D);
 }
 template <class DM, bool CT>
 static void launch_linearize(DevBuffers D, hipStream_t s) {
@@ -328,6 +330,7 @@ struct EmpcSolver {
   DevProblem* dP = nullptr;
   EmpcCostSet* dsets = nullptr;
   int* dknot = nullptr;
+  int* dlin_knots = nullptr;
   double* dscratch = nullptr;  // output staging (squashed controls)
   double* dplant_x = nullptr;  // [B][NX] plant states of closed-loop runs (empc_plant_*)
   double* dplant_u = nullptr;  // [B][NU] staging of caller-supplied plant controls
@@ -364,6 +367,12 @@ static void upload_problem(EmpcSolver* s) {
   HIP_CHECK(hipMemcpyAsync(s->dP, &s->H.P, sizeof(DevProblem), hipMemcpyHostToDevice, s->stream));
   HIP_CHECK(hipMemcpyAsync(s->dsets, s->H.sets.data(), sizeof(EmpcCostSet) * s->H.sets.size(), hipMemcpyHostToDevice, s->stream));
   HIP_CHECK(hipMemcpyAsync(s->dknot, s->H.knot_set.data(), sizeof(int) * s->H.knot_set.size(), hipMemcpyHostToDevice, s->stream));
+  {
+    std::vector<int> order;
+    s->D.n_lean = group_linearize_knots(s->H, order);
+    HIP_CHECK(hipMemcpyAsync(s->dlin_knots, order.data(), sizeof(int) * order.size(), hipMemcpyHostToDevice, s->stream));
+    HIP_CHECK(hipStreamSynchronize(s->stream));  // `order` is a local
+  }
   HIP_CHECK(hipStreamSynchronize(s->stream));
 }
 
@@ -456,6 +465,9 @@ EmpcSolver* empc_solver_create(const EmpcProblemDesc* problem, const EmpcSolverP
   D.P = s->dP;
   D.sets = s->dsets;
   D.knot_set = s->dknot;
+  s->dlin_knots = s->dalloc<int>(T + 1);
+  D.lin_knots = s->dlin_knots;
+  D.n_lean = T + 1;
   D.st = s->dalloc<TrajState>(B);
   D.x0 = s->dalloc<double>(B * k.nx);
   D.xs = s->dalloc<double>(B * (T + 1) * k.nx);
@@ -480,7 +492,6 @@ EmpcSolver* empc_solver_create(const EmpcProblemDesc* problem, const EmpcSolverP
   D.T = s->T;
   D.NA = s->NA;
   D.gaptol = std::max(prm.th_gaptol, 1e-13);
-  D.any_frames = problem_uses_frames(s->H);
   s->dscratch = s->dalloc<double>(B * T * k.nu);
   s->dplant_x = s->dalloc<double>(B * k.nx);
   s->dplant_u = s->dalloc<double>(B * k.nu);
@@ -542,7 +553,6 @@ int empc_solver_update_problem(EmpcSolver* s, const EmpcProblemDesc* problem) {
   s->use();
   const EmpcSolverParams prm = s->H.P.prm;
   prepare_problem(*problem, prm, s->H);
-  s->D.any_frames = problem_uses_frames(s->H);
   upload_problem(s);
   return EMPC_OK;
   EMPC_CATCH(RET_INT)

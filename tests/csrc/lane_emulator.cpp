@@ -49,7 +49,8 @@ struct Emu {
   int B, T, NA, nb, nrot;
   std::vector<TrajState> st;
   std::vector<double> x0, xs, us, acc, tape, K, kff, Vx, Vf, xs_try, us_try, acc_try, try_cost, try_dv, us_last;
-  std::vector<int> try_ok;
+  std::vector<int> try_ok, lin_knots;
+  int n_lean;
   int n_active;
   int rec, nx, ndx, nu, nv;
   DevBuffers D;
@@ -108,7 +109,9 @@ static void emu_alloc(Emu& e) {
   D.T = T;
   D.NA = NA;
   D.gaptol = e.H.P.prm.th_gaptol > 1e-13 ? e.H.P.prm.th_gaptol : 1e-13;
-  D.any_frames = problem_uses_frames(e.H);
+  e.n_lean = group_linearize_knots(e.H, e.lin_knots);
+  D.lin_knots = e.lin_knots.data();
+  D.n_lean = e.n_lean;
   for (int b = 0; b < B; ++b) std::memcpy(&e.x0[(size_t)b * DM::NX], e.H.x0.data(), sizeof(double) * DM::NX);
 }
 
