@@ -325,7 +325,7 @@ struct EmpcSolver {
   static constexpr int MAX_STREAMS = 16;
   int n_streams = 1;
   hipStream_t streams[MAX_STREAMS] = {};
-  hipEvent_t cev[MAX_STREAMS][6] = {};
+  hipEvent_t cev[MAX_STREAMS][2][7] = {};  // per chunk, per in-flight sweep slot: kernel boundaries + 'results on the host'
   DevBuffers D;
   DevProblem* dP = nullptr;
   EmpcCostSet* dsets = nullptr;
@@ -355,8 +355,9 @@ struct EmpcSolver {
     for (auto& e : ev)
       if (e) (void)hipEventDestroy(e);
     for (int c = 0; c < MAX_STREAMS; ++c) {
-      for (auto& e : cev[c])
-        if (e) (void)hipEventDestroy(e);
+      for (auto& slot : cev[c])
+        for (auto& e : slot)
+          if (e) (void)hipEventDestroy(e);
       if (streams[c]) (void)hipStreamDestroy(streams[c]);
     }
     if (stream) (void)hipStreamDestroy(stream);
@@ -443,7 +444,7 @@ EmpcSolver* empc_solver_create(const EmpcProblemDesc* problem, const EmpcSolverP
   s->NA = prm.n_alphas;
   HIP_CHECK(hipStreamCreate(&s->stream));
   for (auto& e : s->ev) HIP_CHECK(hipEventCreate(&e));
-  HIP_CHECK(hipHostMalloc((void**)&s->h_active, sizeof(int) * EmpcSolver::MAX_STREAMS));
+  HIP_CHECK(hipHostMalloc((void**)&s->h_active, sizeof(int) * 2 * EmpcSolver::MAX_STREAMS));
   {
     // independent chunks of the batch run on separate streams (EMPC_STREAMS overrides; 1 = single stream)
     int ns = 1;  // measured on MI355X (profiles/r01_streams.txt): lock-stepped chunks do not overlap usefully
@@ -453,7 +454,8 @@ EmpcSolver* empc_solver_create(const EmpcProblemDesc* problem, const EmpcSolverP
     s->n_streams = ns;
     for (int c = 0; c < ns; ++c) {
       HIP_CHECK(hipStreamCreate(&s->streams[c]));
-      for (auto& e : s->cev[c]) HIP_CHECK(hipEventCreate(&e));
+      for (auto& slot : s->cev[c])
+        for (auto& e : slot) HIP_CHECK(hipEventCreate(&e));
     }
   }
   const size_t B = batch, T = s->T, NA = s->NA;
@@ -485,7 +487,7 @@ EmpcSolver* empc_solver_create(const EmpcProblemDesc* problem, const EmpcSolverP
   D.try_dv = s->dalloc<double>(B * NA);
   D.try_ok = s->dalloc<int>(B * NA);
   D.us_last = s->dalloc<double>(B * T * k.nu);
-  D.n_active = s->dalloc<int>(EmpcSolver::MAX_STREAMS);
+  D.n_active = s->dalloc<int>(2 * EmpcSolver::MAX_STREAMS);
   D.dbg = s->dalloc<unsigned long long>(64);
   HIP_CHECK(hipMemsetAsync(D.dbg, 0, 64 * sizeof(unsigned long long), s->stream));
   D.B = batch;
@@ -665,7 +667,7 @@ static void timed(EmpcSolver* s, int slot, double& acc_ms) {
 struct Chunk {
   DevBuffers D;
   hipStream_t stream;
-  hipEvent_t ev[6];
+  hipEvent_t ev[2][7];
   int b0, nb, active, idx;
 };
 
@@ -690,7 +692,7 @@ static DevBuffers chunk_view(const EmpcSolver* s, int b0, int nb, int idx) {
   D.try_dv += (size_t)b0 * NA;
   D.try_ok += (size_t)b0 * NA;
   D.us_last += (size_t)b0 * T * k.nu;
-  D.n_active = s->D.n_active + idx;
+  D.n_active = s->D.n_active + 2 * idx;
   D.B = nb;
   return D;
 }
@@ -722,39 +724,45 @@ int empc_solver_solve(EmpcSolver* s, int maxiter, int is_feasible) {
     chunks[c].active = hi - lo;
     chunks[c].D = chunk_view(s, lo, hi - lo, c);
     chunks[c].stream = s->streams[c];
-    for (int e = 0; e < 6; ++e) chunks[c].ev[e] = s->cev[c][e];
+    for (int q = 0; q < 2; ++q)
+      for (int e = 0; e < 7; ++e) chunks[c].ev[q][e] = s->cev[c][q][e];
   }
   hipEvent_t t_begin, t_end;
   HIP_CHECK(hipEventCreate(&t_begin));
   HIP_CHECK(hipEventCreate(&t_end));
   HIP_CHECK(hipEventRecord(t_begin, s->stream));
   const int hard_cap = 4 * (3 * (maxiter + 1) + 8);  // (passes + clean-up) x maxiter can never be exceeded
-  // Every chunk runs its own sweep loop on its own stream; the host only retires a chunk's sweep (reads its active count)
-  // and queues the next one.  Chunks start staggered -- chunk c waits for chunk c-1's first backward pass -- so that the
-  // throughput-bound linearize of one chunk overlaps the latency-bound backward / rollout of the others instead of
-  // meeting the same kernel of its neighbours.
-  std::vector<int> pending(nchunks, 0), sweeps(nchunks, 0);
+  // Every chunk runs its own sweep loop on its own stream, two sweeps deep: sweep k + 1 is queued before the host has
+  // seen the active count of sweep k (its kernels return at once for finished trajectories), so the device never waits
+  // for the host round trip between sweeps; the one surplus sweep at the end is empty and is not counted.
+  // Chunks start staggered -- chunk c waits for chunk c-1's first backward pass.
+  std::vector<int> queued(nchunks, 0), retired(nchunks, 0);
   auto enqueue = [&](Chunk& c) {
-    HIP_CHECK(hipMemsetAsync(c.D.n_active, 0, sizeof(int), c.stream));
-    HIP_CHECK(hipEventRecord(c.ev[0], c.stream));
-    k.calc(c.D, c.stream);
-    HIP_CHECK(hipEventRecord(c.ev[1], c.stream));
-    k.linearize(c.D, c.stream);
-    HIP_CHECK(hipEventRecord(c.ev[2], c.stream));
-    k.backward(c.D, c.stream);
-    HIP_CHECK(hipEventRecord(c.ev[3], c.stream));
-    k.rollout(c.D, c.stream);
-    HIP_CHECK(hipEventRecord(c.ev[4], c.stream));
-    k.select(c.D, c.stream);
-    HIP_CHECK(hipEventRecord(c.ev[5], c.stream));
-    HIP_CHECK(hipMemcpyAsync(s->h_active + c.idx, c.D.n_active, sizeof(int), hipMemcpyDeviceToHost, c.stream));
-    pending[c.idx] = 1;
+    const int q = queued[c.idx] & 1;
+    DevBuffers Dq = c.D;
+    Dq.n_active = c.D.n_active + q;
+    HIP_CHECK(hipMemsetAsync(Dq.n_active, 0, sizeof(int), c.stream));
+    HIP_CHECK(hipEventRecord(c.ev[q][0], c.stream));
+    k.calc(Dq, c.stream);
+    HIP_CHECK(hipEventRecord(c.ev[q][1], c.stream));
+    k.linearize(Dq, c.stream);
+    HIP_CHECK(hipEventRecord(c.ev[q][2], c.stream));
+    k.backward(Dq, c.stream);
+    HIP_CHECK(hipEventRecord(c.ev[q][3], c.stream));
+    k.rollout(Dq, c.stream);
+    HIP_CHECK(hipEventRecord(c.ev[q][4], c.stream));
+    k.select(Dq, c.stream);
+    HIP_CHECK(hipEventRecord(c.ev[q][5], c.stream));
+    HIP_CHECK(hipMemcpyAsync(s->h_active + 2 * c.idx + q, Dq.n_active, sizeof(int), hipMemcpyDeviceToHost, c.stream));
+    HIP_CHECK(hipEventRecord(c.ev[q][6], c.stream));
+    queued[c.idx]++;
   };
-  auto retire = [&](Chunk& c) {
-    HIP_CHECK(hipStreamSynchronize(c.stream));
+  auto retire = [&](Chunk& c) {  // oldest in-flight sweep of the chunk
+    const int q = retired[c.idx] & 1;
+    HIP_CHECK(hipEventSynchronize(c.ev[q][6]));
     auto el = [&](int a) {
       float ms = 0;
-      return hipEventElapsedTime(&ms, c.ev[a], c.ev[a + 1]) == hipSuccess ? (double)ms : 0.0;
+      return hipEventElapsedTime(&ms, c.ev[q][a], c.ev[q][a + 1]) == hipSuccess ? (double)ms : 0.0;
     };
     S.ms_calc += el(0);
     S.ms_linearize += el(1);
@@ -769,32 +777,31 @@ int empc_solver_solve(EmpcSolver* s, int maxiter, int is_feasible) {
     S.backward_units += (long long)c.active * s->T;
     S.rollout_units += (long long)c.active * s->NA * (s->T + 1);
     S.linearize_units += (long long)c.active * (s->T + 1);  // upper bound: trajectories that re-linearize this sweep
-    c.active = s->h_active[c.idx];
-    pending[c.idx] = 0;
-    sweeps[c.idx]++;
+    c.active = s->h_active[2 * c.idx + q];
+    retired[c.idx]++;
   };
   for (auto& c : chunks) {
-    if (c.idx > 0) HIP_CHECK(hipStreamWaitEvent(c.stream, chunks[c.idx - 1].ev[3], 0));  // stagger the first sweep
+    if (c.idx > 0) HIP_CHECK(hipStreamWaitEvent(c.stream, chunks[c.idx - 1].ev[0][3], 0));  // stagger the first sweep
     enqueue(c);
+    if (hard_cap > 1) enqueue(c);
   }
   int total_active = s->B;
-  bool any_pending = true;
-  while (any_pending) {
-    any_pending = false;
+  bool any_live = true;
+  while (any_live) {
+    any_live = false;
     for (auto& c : chunks) {
-      if (!pending[c.idx]) continue;
+      if (retired[c.idx] == queued[c.idx] || c.active <= 0) continue;
       retire(c);
-      if (c.active > 0 && sweeps[c.idx] < hard_cap) {
-        enqueue(c);
-        any_pending = true;
-      }
+      if (c.active > 0 && queued[c.idx] < hard_cap) enqueue(c);
+      if (c.active > 0 && retired[c.idx] < queued[c.idx]) any_live = true;
     }
     HIP_CHECK(hipGetLastError());
   }
   total_active = 0;
   for (auto& c : chunks) {
     total_active += c.active;
-    S.sweeps = std::max(S.sweeps, sweeps[c.idx]);
+    S.sweeps = std::max(S.sweeps, retired[c.idx]);
+    HIP_CHECK(hipStreamSynchronize(c.stream));  // drains the surplus (empty) sweep
   }
   for (int c = 1; c < nchunks; ++c) HIP_CHECK(hipStreamSynchronize(chunks[c].stream));
   HIP_CHECK(hipEventRecord(t_end, s->stream));
