@@ -189,3 +189,22 @@ def test_error_paths(empc, problems):
     finally:
         for k, t in patched:
             d.sets[k].contacts[0].type = t
+
+
+@pytest.mark.parametrize("squash,n_alphas", [(True, 4), (True, 16), (False, 10)])
+def test_solver_parameter_variants(empc, squash, n_alphas):
+    """Fewer / more step lengths than the default ten, and a problem without the squashing layer, against the oracle."""
+    t = empc.Trajectory()
+    t.autoSetup(empc.yaml_path("hexacopter370_flying_arm_3/trajectories/displacement.yaml"))
+    p = t.createProblem(80, squash, "IntegratedActionModelEuler")
+    d = p.desc
+    x0s = empc.perturbed_x0s(p.x0, 3, nq=d.model.nq)
+    prm = empc.default_params()
+    prm.n_alphas = n_alphas
+    oprm = ob.default_params()
+    oprm.n_alphas = n_alphas
+    s = empc.SolverSbFDDP(p, batch=3, params=prm)
+    s.solve([], [], 100, x0s=x0s)
+    r = ob.solve_batch(d, x0s, 100, nthreads=3, params=oprm)
+    assert np.array_equal(s.iter_batch, r["iter"])
+    assert np.abs(s.xs_batch - r["xs"]).max() < 1e-4 and np.abs(s.us_batch - r["us"]).max() < 1e-4
