@@ -214,7 +214,7 @@ def main():
         if args.config == "carrot_mpc":
             out["mpc_cycles_per_s"] = args.steps * MPC_CYCLES_PER_STEP / elapsed
             out["plant_controller_cycles_per_s"] = args.steps * MPC_CYCLES_PER_STEP * B * world / elapsed
-        if not args.no_cpu_baseline and args.config != "carrot_mpc":
+        if not args.no_cpu_baseline and args.config != "carrot_mpc" and world == 1:  # rank 0 at N = 1 only
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_binding as ob  # the oracle timed as the CPU baseline ("port"), never part of the product path
             cores = os.cpu_count() or 1
