@@ -57,6 +57,8 @@ def main():
     ap.add_argument("--config", default="displacement", choices=sorted(CONFIGS))
     ap.add_argument("--maxiter", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of the result gather (nccl = RCCL; gloo only for dry runs of the N > 1 path)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -72,12 +74,15 @@ def main():
     empc = empc_loader.load()
     if empc.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: the solver has no CPU path")
-    torch.cuda.set_device(local_rank)
+    n_dev = max(torch.cuda.device_count(), 1)
+    local_dev = local_rank % n_dev  # one rank per GPU; the modulo only matters for gloo dry runs on fewer GPUs
+    torch.cuda.set_device(local_dev)
+    coll_dev = "cuda" if args.backend == "nccl" else "cpu"
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
 
     if args.batch is None:
         args.batch = 256 if args.config == "carrot_mpc" else 1024
@@ -92,14 +97,14 @@ def main():
     sharding = importlib.import_module("eagle_mpc_amd.sharding")
     x0_all = empc.perturbed_x0s(problem.x0, B * world, nq=d.model.nq)
     x0s = sharding.shard(x0_all, world, rank)
-    solver = empc.SolverSbFDDP(problem, batch=B, device=local_rank) if args.config != "carrot_mpc" else None
+    solver = empc.SolverSbFDDP(problem, batch=B, device=local_dev) if args.config != "carrot_mpc" else None
     mpc_state = {"t": 0}
     if args.config == "carrot_mpc":
         # plan once (one rollout), then B controllers-in-one track it from perturbed plant states
-        planner = empc.SolverSbFDDP(problem, batch=1, device=local_rank)
+        planner = empc.SolverSbFDDP(problem, batch=1, device=local_dev)
         planner.solve([], [], args.maxiter)
         xs_plan, us_plan = np.array(planner.xs), np.array(planner.us)
-        mpc = empc.CarrotMpc(traj, xs_plan, dt, MPC_YAML, batch=B, device=local_rank)
+        mpc = empc.CarrotMpc(traj, xs_plan, dt, MPC_YAML, batch=B, device=local_dev)
         mpc.updateProblem(0)
         solver = mpc.solver
         d = mpc.problem.desc
@@ -119,7 +124,7 @@ def main():
             mpc_state["t"] += MPC_DT_SIM
         if dist is not None:
             rows = sharding.pack_results(solver.xs_batch, solver.us_squash_batch, solver.cost_batch, solver.iter_batch)
-            sharding.gather_results(dist, rows, world, rank, device="cuda", global_batch=B * world)
+            sharding.gather_results(dist, rows, world, rank, device=coll_dev, global_batch=B * world)
         return agg_s
 
     def one_step():
@@ -129,7 +134,7 @@ def main():
         if dist is not None:
             # the only exchange of the algorithm: results to rank 0 (RCCL gather over xGMI)
             rows = sharding.pack_results(solver.xs_batch, solver.us_squash_batch, solver.cost_batch, solver.iter_batch)
-            sharding.gather_results(dist, rows, world, rank, device="cuda", global_batch=B * world)
+            sharding.gather_results(dist, rows, world, rank, device=coll_dev, global_batch=B * world)
         return solver.stats()
 
     for _ in range(args.warmup):
@@ -149,10 +154,10 @@ def main():
     elapsed = time.perf_counter() - t0
     iters_rank = float(agg["total_iters"])
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        tsum = torch.tensor([iters_rank], dtype=torch.float64, device="cuda")
+        tsum = torch.tensor([iters_rank], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         iters_total = float(tsum.item())
     else:
