@@ -44,3 +44,12 @@ def test_cpp_examples_on_gpu(built):
     assert m
     z = float(m.group(3))
     assert 0.0 < z < 0.2   # the plant climbs along the planned trajectory (reference z at 200 ms ~ 0.05 m)
+
+
+@pytest.mark.gpu
+def test_python_examples_on_gpu():
+    import sys
+    for name, pattern in (("trajectory.py", r"iterations 17 cost 124\.5710"), ("mpc.py", r"tracking error \(position, max over plants\): 0\.\d+ m")):
+        r = subprocess.run([sys.executable, os.path.join(EX, "python", name)], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr
+        assert re.search(pattern, r.stdout), r.stdout
