@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Address/UB sanitizer pass over the HIP kernel bodies, executed by the CPU lane emulator (GPU ASan is not available on
+the pool).  Builds tests/csrc/lane_emulator.cpp with -fsanitize=address,undefined and runs short solves of all four model
+shapes through both forms of the backward and rollout bodies and the lean / full linearize bodies.
+
+    LD_PRELOAD="$(g++ -print-file-name=libasan.so) $(g++ -print-file-name=libstdc++.so.6)" ASAN_OPTIONS=detect_leaks=0 \
+        python tools/asan_emulator.py
+"""
+import subprocess
+import sys, os, ctypes as C
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+LIB = '/tmp/liblane_emulator_asan.so'
+subprocess.check_call(['g++', '-O1', '-g', '-std=c++17', '-fPIC', '-shared', '-fsanitize=address,undefined', '-fno-omit-frame-pointer',
+                       '-I' + os.path.join(ROOT, 'include'), os.path.join(ROOT, 'tests', 'csrc', 'lane_emulator.cpp'), '-o', LIB])
+import empc_loader, oracle_binding as ob
+empc = empc_loader.load()
+L = C.CDLL(LIB)
+L.emu_create.restype = C.c_void_p
+L.emu_create.argtypes = [C.POINTER(empc.T.ProblemDesc), C.POINTER(empc.T.SolverParams), C.c_int]
+L.emu_destroy.argtypes=[C.c_void_p]; L.emu_set_x0.argtypes=[C.c_void_p, C.POINTER(C.c_double)]
+L.emu_set_warmstart.argtypes=[C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+L.emu_solve_c.argtypes=[C.c_void_p, C.c_int, C.c_int]
+for rel, dt, it in (("hexacopter370/trajectories/hover.yaml",40,100),("hexacopter370_flying_arm_3/trajectories/displacement.yaml",80,3),("hexacopter370_flying_arm_3/trajectories/eagle_catch.yaml",32,3),("hextilt_flying_arm_5/trajectories/push_slide.yaml",13,2)):
+    t = empc.Trajectory(); t.autoSetup(empc.yaml_path(rel)); p = t.createProblem(dt, True, "IntegratedActionModelEuler")
+    prm = ob.default_params()
+    for bwd in (3, 2):
+        L.emu_set_backward_version(bwd); L.emu_set_rollout_version(5 if bwd==3 else 1); L.emu_set_linearize_version(2)
+        e = C.c_void_p(L.emu_create(C.byref(p.desc), C.byref(prm), 2))
+        L.emu_set_warmstart(e, None, None)
+        L.emu_solve_c(e, it, 0)
+        L.emu_destroy(e)
+    print("ok", rel, flush=True)
