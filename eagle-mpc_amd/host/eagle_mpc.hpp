@@ -152,7 +152,9 @@ class Stage : public std::enable_shared_from_this<Stage> {
                  const std::shared_ptr<ParamsServer>& server, std::size_t t_ini);
   void set_t_ini(std::size_t t_ini) { t_ini_ = t_ini; }
   void set_duration(std::size_t duration) { duration_ = duration; }
-  const std::shared_ptr<Trajectory>& get_trajectory() const { return trajectory_; }
+  // the owning trajectory (empty once it is gone).  The back-reference is weak: the reference keeps a strong
+  // boost::shared_ptr here (include/eagle_mpc/stage.hpp), a Trajectory <-> Stage cycle that never frees either.
+  std::shared_ptr<Trajectory> get_trajectory() const { return trajectory_.lock(); }
   const std::shared_ptr<CostModelSum>& get_costs() const { return costs_; }
   const std::shared_ptr<ContactModelMultiple>& get_contacts() const { return contacts_; }
   const std::map<std::string, CostModelTypes>& get_cost_types() const { return cost_types_; }
@@ -165,7 +167,7 @@ class Stage : public std::enable_shared_from_this<Stage> {
 
  private:
   explicit Stage(const std::shared_ptr<Trajectory>& trajectory);
-  std::shared_ptr<Trajectory> trajectory_;
+  std::weak_ptr<Trajectory> trajectory_;
   std::shared_ptr<CostModelSum> costs_;
   std::shared_ptr<ContactModelMultiple> contacts_;
   std::map<std::string, CostModelTypes> cost_types_;

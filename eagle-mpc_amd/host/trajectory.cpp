@@ -404,13 +404,15 @@ void Stage::autoSetup(const std::string& path_to_stages, const std::map<std::str
   is_transition_ = converter<bool>::convert(stage.at("transition"));
   ContactModelFactory contact_factory;
   CostModelFactory cost_factory;
-  const std::size_t nu = trajectory_->get_nu();
+  const std::shared_ptr<Trajectory> trajectory = trajectory_.lock();
+  if (!trajectory) throw std::runtime_error("Stage: the owning trajectory no longer exists");
+  const std::size_t nu = trajectory->get_nu();
   try {
     std::vector<std::string> contact_names = converter<std::vector<std::string>>::convert(stage.at("contacts"));
     for (const auto& contact_name : contact_names) {
       ContactModelTypes contact_type;
       EmpcContact contact = contact_factory.create(path_to_stage + "contacts/" + contact_name + "/", server,
-                                                   trajectory_->get_robot_model(), trajectory_->frame_table(), nu, contact_type);
+                                                   trajectory->get_robot_model(), trajectory->frame_table(), nu, contact_type);
       contacts_->addContact(contact_name, contact);
       contact_types_.insert({contact_name, contact_type});
     }
@@ -428,8 +430,8 @@ void Stage::autoSetup(const std::string& path_to_stages, const std::map<std::str
       active = true;
     }
     CostModelTypes cost_type;
-    EmpcCost cost = cost_factory.create(path_to_stage + "costs/" + cost_name + "/", server, trajectory_->get_robot_model(),
-                                        trajectory_->frame_table(), nu, cost_type);
+    EmpcCost cost = cost_factory.create(path_to_stage + "costs/" + cost_name + "/", server, trajectory->get_robot_model(),
+                                        trajectory->frame_table(), nu, cost_type);
     costs_->addCost(cost_name, cost, weight, active);
     cost_types_.insert({cost_name, cost_type});
   }
