@@ -112,6 +112,20 @@ def main():
         solver.solve(xs_plan[:d.T + 1], us_plan[:d.T], args.maxiter, x0s="plant")
         solver.convergence_init = 1e-3
 
+    rows_dev = {}
+
+    def gather_step():
+        # the only exchange of the algorithm: every rank's results to rank 0.  RCCL: rows are packed on the device and
+        # gathered GPU to GPU over xGMI; gloo (dry runs): through host memory.
+        if args.backend == "nccl":
+            if "t" not in rows_dev:
+                rows_dev["t"] = torch.empty((B, solver.pack_results_device()), dtype=torch.float64, device="cuda")
+            solver.pack_results_device(rows_dev["t"].data_ptr())
+            sharding.gather_rows_device(dist, rows_dev["t"], world, rank)
+        else:
+            rows = sharding.pack_results(solver.xs_batch, solver.us_squash_batch, solver.cost_batch, solver.iter_batch)
+            sharding.gather_results(dist, rows, world, rank, device=coll_dev, global_batch=B * world)
+
     def mpc_step():
         agg_s = {}
         for _ in range(MPC_CYCLES_PER_STEP):
@@ -123,8 +137,7 @@ def main():
             solver.plant_step(MPC_DT_SIM)
             mpc_state["t"] += MPC_DT_SIM
         if dist is not None:
-            rows = sharding.pack_results(solver.xs_batch, solver.us_squash_batch, solver.cost_batch, solver.iter_batch)
-            sharding.gather_results(dist, rows, world, rank, device=coll_dev, global_batch=B * world)
+            gather_step()
         return agg_s
 
     def one_step():
@@ -132,9 +145,7 @@ def main():
             return mpc_step()
         solver.solve([], [], args.maxiter, x0s=x0s)
         if dist is not None:
-            # the only exchange of the algorithm: results to rank 0 (RCCL gather over xGMI)
-            rows = sharding.pack_results(solver.xs_batch, solver.us_squash_batch, solver.cost_batch, solver.iter_batch)
-            sharding.gather_results(dist, rows, world, rank, device=coll_dev, global_batch=B * world)
+            gather_step()
         return solver.stats()
 
     for _ in range(args.warmup):

@@ -76,6 +76,7 @@ def lib():
         getattr(L, "empc_solver_get_" + name).argtypes = [C.c_void_p, _dp]
     L.empc_solver_get_iters.argtypes = [C.c_void_p, _ip]
     L.empc_solver_get_status.argtypes = [C.c_void_p, _ip]
+    L.empc_solver_pack_results_device.argtypes = [C.c_void_p, C.c_void_p, _ip]
     L.empc_solver_get_stats.argtypes = [C.c_void_p, C.POINTER(T.SolveStats)]
     L.empc_solver_dims.argtypes = [C.c_void_p] + [_ip] * 6
     L.empc_tape_layout.argtypes = [C.c_void_p, C.POINTER(T.TapeLayout)]
@@ -355,6 +356,13 @@ class SolverSbFDDP:
     iter = property(lambda self: int(self.iter_batch[0]))
     cost = property(lambda self: float(self.cost_batch[0]))
     stop = property(lambda self: float(self.stop_batch[0]))
+
+    def pack_results_device(self, device_ptr=None):
+        """Rows xs | us_squash | cost | iters of every rollout written to device memory at `device_ptr` (e.g. a torch CUDA
+        tensor's data_ptr()); returns the row length in doubles.  device_ptr=None only queries the length."""
+        n = C.c_int()
+        _check(lib().empc_solver_pack_results_device(self._h, C.c_void_p(device_ptr) if device_ptr else None, C.byref(n)))
+        return n.value
 
     def stats_na(self):
         """step lengths tried per line search (SolverParams.n_alphas of this solver)"""

@@ -848,6 +848,32 @@ int empc_solver_get_us_squash(EmpcSolver* s, double* out) {
   return EMPC_OK;
   EMPC_CATCH(RET_INT)
 }
+// One row per rollout: xs | us_squash | cost | iters (as double), written to a DEVICE buffer of batch x row doubles --
+// the payload of the multi-GPU result gather, packed without a host round trip.
+int empc_solver_pack_results_device(EmpcSolver* s, double* dst_device, int* row_doubles) {
+  EMPC_TRY
+  if (!s) throw std::invalid_argument("solver is NULL");
+  s->use();
+  const size_t nx = s->kt.nx, nu = s->kt.nu, T = s->T, B = s->B;
+  const size_t nxs = (T + 1) * nx, nus = T * nu, row = nxs + nus + 2;
+  if (row_doubles) *row_doubles = (int)row;
+  if (!dst_device) return EMPC_OK;  // size query
+  s->kt.squash_out(s->D, s->dscratch, s->stream);
+  HIP_CHECK(hipMemcpy2DAsync(dst_device, row * sizeof(double), s->D.xs, nxs * sizeof(double), nxs * sizeof(double), B,
+                             hipMemcpyDeviceToDevice, s->stream));
+  HIP_CHECK(hipMemcpy2DAsync(dst_device + nxs, row * sizeof(double), s->dscratch, nus * sizeof(double), nus * sizeof(double), B,
+                             hipMemcpyDeviceToDevice, s->stream));
+  std::vector<double> tail(2 * B);
+  for (size_t b = 0; b < B; ++b) {
+    tail[2 * b] = s->h_st[b].cost;
+    tail[2 * b + 1] = (double)s->h_st[b].iter;
+  }
+  HIP_CHECK(hipMemcpy2DAsync(dst_device + nxs + nus, row * sizeof(double), tail.data(), 2 * sizeof(double), 2 * sizeof(double), B,
+                             hipMemcpyHostToDevice, s->stream));
+  HIP_CHECK(hipStreamSynchronize(s->stream));
+  return EMPC_OK;
+  EMPC_CATCH(RET_INT)
+}
 int empc_solver_get_cost(EmpcSolver* s, double* cost) {
   if (!s || !cost) return EMPC_ERR_INVALID;
   for (int b = 0; b < s->B; ++b) cost[b] = s->h_st[b].cost;

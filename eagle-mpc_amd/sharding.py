@@ -32,6 +32,15 @@ def unpack_results(rows, T, nx, nu):
     return (rows[:, :a].reshape(B, T + 1, nx), rows[:, a:b].reshape(B, T, nu), rows[:, b], rows[:, b + 1].astype(np.int64))
 
 
+def gather_rows_device(dist, rows_dev, world_size, rank):
+    """Gather equally sized device-resident result rows (a torch CUDA tensor per rank) on rank 0 over RCCL; the gathered
+    rows stay on rank 0's GPU (list of per-rank tensors) -- nothing passes through host memory."""
+    import torch
+    out = [torch.empty_like(rows_dev) for _ in range(world_size)] if rank == 0 else None
+    dist.gather(rows_dev, out, dst=0)
+    return out
+
+
 def gather_results(dist, rows, world_size, rank, device=None, global_batch=None):
     """Gather per-rank result rows on rank 0 (torch.distributed gather; RCCL on GPUs, gloo in the CPU tests).
     Shards may differ in size by one row, so rows are padded to the largest shard."""

@@ -95,6 +95,9 @@ int empc_solver_get_cost(EmpcSolver* s, double* cost /* batch */);
 int empc_solver_get_stop(EmpcSolver* s, double* stop /* batch */);
 int empc_solver_get_iters(EmpcSolver* s, int* iters /* batch: iter_ = total iterations - 1 */);
 int empc_solver_get_status(EmpcSolver* s, int* status /* batch: EMPC_STATUS_* bits */);
+/* results packed on the device, one row per rollout: xs | us_squash | cost | iters (as double) -- the payload of the
+ * multi-GPU gather; dst_device == NULL only returns the row length in doubles */
+int empc_solver_pack_results_device(EmpcSolver* s, double* dst_device /* batch x row, device memory */, int* row_doubles);
 
 /* timing / accounting of the last solve (device time measured with HIP events on the solver's stream) */
 typedef struct EmpcSolveStats {

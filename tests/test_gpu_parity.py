@@ -7,6 +7,8 @@ Tolerances (FP64 everywhere):
 The oracle itself is checked by finite differences / identities in test_oracle_math.py (parity vs the reference is
 UNPINNED: the reference's arithmetic lives in the un-vendored Crocoddyl fork).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -208,3 +210,44 @@ def test_solver_parameter_variants(empc, squash, n_alphas):
     r = ob.solve_batch(d, x0s, 100, nthreads=3, params=oprm)
     assert np.array_equal(s.iter_batch, r["iter"])
     assert np.abs(s.xs_batch - r["xs"]).max() < 1e-4 and np.abs(s.us_batch - r["us"]).max() < 1e-4
+
+
+_PACK_SCRIPT = r"""
+import importlib, os, sys
+import numpy as np
+import torch                      # before the solver library: one HIP runtime per process (torch's)
+import torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+import empc_loader
+empc = empc_loader.load()
+sharding = importlib.import_module("eagle_mpc_amd.sharding")
+t = empc.Trajectory(); t.autoSetup(empc.yaml_path("hexacopter370_flying_arm_3/trajectories/displacement.yaml"))
+problem = t.createProblem(80, True, "IntegratedActionModelEuler")
+B = 4
+x0s = empc.perturbed_x0s(problem.x0, B, nq=problem.desc.model.nq)
+s = empc.SolverSbFDDP(problem, batch=B)
+s.solve([], [], 100, x0s=x0s)
+rows_host = sharding.pack_results(s.xs_batch, s.us_squash_batch, s.cost_batch, s.iter_batch)
+n = s.pack_results_device()
+assert n == rows_host.shape[1]
+rows = torch.empty((B, n), dtype=torch.float64, device="cuda")
+s.pack_results_device(rows.data_ptr())
+assert np.array_equal(rows.cpu().numpy(), rows_host), "device packing differs from host packing"
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+dist.init_process_group(backend="nccl", rank=0, world_size=1)
+out = sharding.gather_rows_device(dist, rows, 1, 0)
+assert len(out) == 1 and np.array_equal(out[0].cpu().numpy(), rows_host), "RCCL gather changed the rows"
+dist.destroy_process_group()
+print("PACK_OK")
+"""
+
+
+def test_pack_results_device_and_rccl_gather():
+    """The multi-GPU payload: rows packed on the device equal the host-side packing and travel through an RCCL gather
+    (world size 1 here; the N > 1 path is covered with gloo on the CPU).  Own process: torch must load its HIP runtime
+    before the solver library does."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _PACK_SCRIPT, root], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "PACK_OK" in r.stdout, r.stderr[-2000:]
