@@ -801,7 +801,13 @@ int empc_solver_solve(EmpcSolver* s, int maxiter, int is_feasible) {
   for (auto& c : chunks) {
     total_active += c.active;
     S.sweeps = std::max(S.sweeps, retired[c.idx]);
-    HIP_CHECK(hipStreamSynchronize(c.stream));  // drains the surplus (empty) sweep
+    HIP_CHECK(hipStreamSynchronize(c.stream));  // drains the surplus (empty) sweep ...
+    while (retired[c.idx] < queued[c.idx]) {    // ... whose launches still count as launches (they are in any profile)
+      const int act = c.active;
+      c.active = 0;  // no units processed
+      retire(c);
+      c.active = act;
+    }
   }
   for (int c = 1; c < nchunks; ++c) HIP_CHECK(hipStreamSynchronize(chunks[c].stream));
   HIP_CHECK(hipEventRecord(t_end, s->stream));
