@@ -53,6 +53,9 @@ def lib():
     L.empc_trajectory_destroy.argtypes = [C.c_void_p]
     L.empc_trajectory_dims.argtypes = [C.c_void_p] + [_ip] * 6
     L.empc_trajectory_stage_info.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int, _ip, _ip, _ip, _ip]
+    L.empc_trajectory_stage_t_ini.restype = C.c_longlong
+    L.empc_trajectory_stage_t_ini.argtypes = [C.c_void_p, C.c_int]
+    L.empc_trajectory_stage_cost.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_int, _dp, _ip]
     L.empc_trajectory_get_initial_state.argtypes = [C.c_void_p, _dp]
     L.empc_trajectory_set_initial_state.argtypes = [C.c_void_p, _dp]
     L.empc_trajectory_get_platform.argtypes = [C.c_void_p, _dp, _dp, _dp, _ip]
@@ -97,6 +100,18 @@ def lib():
     L.empc_carrot_mpc_set_x0.argtypes = [C.c_void_p, _dp]
     L.empc_carrot_mpc_problem_desc.restype = C.POINTER(T.ProblemDesc)
     L.empc_carrot_mpc_problem_desc.argtypes = [C.c_void_p]
+    L.empc_rail_mpc_create.restype = C.c_void_p
+    L.empc_rail_mpc_create.argtypes = [_dp, C.c_int, C.c_int, C.c_int, C.c_char_p]
+    L.empc_weighted_mpc_create.restype = C.c_void_p
+    L.empc_weighted_mpc_create.argtypes = [C.c_void_p, C.c_int, C.c_char_p]
+    L.empc_mpc_destroy.argtypes = [C.c_void_p]
+    L.empc_mpc_params.argtypes = [C.c_void_p] + [_ip] * 6
+    L.empc_mpc_update_problem.argtypes = [C.c_void_p, C.c_longlong]
+    L.empc_mpc_set_x0.argtypes = [C.c_void_p, _dp]
+    L.empc_mpc_problem_desc.restype = C.POINTER(T.ProblemDesc)
+    L.empc_mpc_problem_desc.argtypes = [C.c_void_p]
+    L.empc_rail_mpc_state_reference.argtypes = [C.c_void_p, C.c_longlong, _dp]
+    L.empc_weighted_mpc_t_stages.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.c_int]
     L.empc_set_data_dirs(YAML_DIR.encode(), ROBOT_DIR.encode())
     _lib = L
     return L
@@ -163,8 +178,15 @@ class Trajectory:
         self._h = C.c_void_p(h)
         v = [C.c_int() for _ in range(6)]
         _check(lib().empc_trajectory_dims(self._h, *[C.byref(x) for x in v]))
-        self.nx, self.ndx, self.nu, self.n_stages, hc, self.duration = [x.value for x in v]
+        self.nx, self.ndx, self.nu, _, hc, self.duration = [x.value for x in v]
         self.has_contact = bool(hc)
+
+    @property
+    def n_stages(self):
+        """len(get_stages()); live, because WeightedMpc removes the transition stages of the trajectory it is given"""
+        n = C.c_int()
+        _check(lib().empc_trajectory_dims(self._h, None, None, None, C.byref(n), None, None))
+        return n.value
 
     def createProblem(self, dt=0, squash=True, integration_method="IntegratedActionModelEuler"):
         h = lib().empc_trajectory_create_problem(self._h, int(dt), int(bool(squash)), integration_method.encode())
@@ -197,8 +219,13 @@ class Trajectory:
         name = C.create_string_buffer(64)
         v = [C.c_int() for _ in range(4)]
         _check(lib().empc_trajectory_stage_info(self._h, i, name, 64, *[C.byref(x) for x in v]))
+        costs = []
+        for k in range(v[2].value):
+            cname, w, a = C.create_string_buffer(64), C.c_double(), C.c_int()
+            _check(lib().empc_trajectory_stage_cost(self._h, i, k, cname, 64, C.byref(w), C.byref(a)))
+            costs.append(dict(name=cname.value.decode(), weight=w.value, active=bool(a.value)))
         return dict(name=name.value.decode(), duration=v[0].value, is_transition=bool(v[1].value), n_costs=v[2].value,
-                    n_contacts=v[3].value)
+                    n_contacts=v[3].value, t_ini=int(lib().empc_trajectory_stage_t_ini(self._h, i)), costs=costs)
 
     def get_param(self, key):
         buf = C.create_string_buffer(4096)
@@ -433,12 +460,14 @@ class SolverSbFDDP:
 class MpcProblem:
     """The controller's ShootingProblem (get_problem()); owned by the controller."""
 
-    def __init__(self, mpc):
+    def __init__(self, mpc, prefix="empc_carrot_mpc"):
         self._mpc = mpc
+        self._desc_fn = getattr(lib(), prefix + "_problem_desc")
+        self._set_x0_fn = getattr(lib(), prefix + "_set_x0")
 
     @property
     def desc(self):
-        p = lib().empc_carrot_mpc_problem_desc(self._mpc._h)
+        p = self._desc_fn(self._mpc._h)
         if not p:
             raise EmpcError(lib().empc_last_error().decode())
         return p.contents
@@ -456,7 +485,7 @@ class MpcProblem:
     def x0(self, value):
         v = np.ascontiguousarray(value, dtype=np.float64)
         assert v.shape == (self._mpc.nx,)
-        _check(lib().empc_carrot_mpc_set_x0(self._mpc._h, _ptr(v)))
+        _check(self._set_x0_fn(self._mpc._h, _ptr(v)))
 
 
 class CarrotMpc:
@@ -505,6 +534,69 @@ class CarrotMpc:
             lib().empc_carrot_mpc_destroy(self._h)
         except Exception:
             pass
+
+
+class _Mpc:
+    """Common part of RailMpc / WeightedMpc (MpcAbstract, include/eagle_mpc/mpc-base.hpp:59-119)."""
+
+    def _init_common(self, h, batch, device, params):
+        if not h:
+            raise EmpcError(lib().empc_last_error().decode())
+        self._h = C.c_void_p(h)
+        v = [C.c_int() for _ in range(6)]
+        _check(lib().empc_mpc_params(self._h, *[C.byref(x) for x in v]))
+        self.knots, self.iters, self.dt, self.nx, self.ndx, self.nu = [x.value for x in v]
+        self.problem = MpcProblem(self, prefix="empc_mpc")
+        self._batch, self._device, self._params = int(batch), int(device), params
+        self._solver = None
+
+    @property
+    def solver(self):
+        if self._solver is None:
+            self._solver = SolverSbFDDP(self.problem, batch=self._batch, device=self._device, params=self._params)
+        return self._solver
+
+    def updateProblem(self, current_time):
+        _check(lib().empc_mpc_update_problem(self._h, int(current_time)))
+        if self._solver is not None:
+            self._solver.update_problem()
+
+    def __del__(self):
+        try:
+            lib().empc_mpc_destroy(self._h)
+        except Exception:
+            pass
+
+
+class RailMpc(_Mpc):
+    """Mirror of eagle_mpc.RailMpc(state_ref, dt_ref, yaml_path) (src/mpc-controllers/rail-mpc.cpp): every knot
+    tracks the planned state at its own time."""
+
+    def __init__(self, state_ref, dt_ref, yaml_path, batch=1, device=0, params=None):
+        ref = np.ascontiguousarray(np.asarray(state_ref, dtype=np.float64))
+        if ref.ndim != 2:
+            raise ValueError("state_ref must be (n_ref, nx)")
+        self._init_common(lib().empc_rail_mpc_create(_ptr(ref), ref.shape[0], ref.shape[1], int(dt_ref),
+                                                     os.fspath(yaml_path).encode()), batch, device, params)
+
+    def computeStateReference(self, time):
+        x = np.zeros(self.nx)
+        _check(lib().empc_rail_mpc_state_reference(self._h, int(time), _ptr(x)))
+        return x
+
+
+class WeightedMpc(_Mpc):
+    """Mirror of eagle_mpc.WeightedMpc(trajectory, dt_ref, yaml_path) (src/mpc-controllers/weighted-mpc.cpp).
+    Like the reference, construction merges every transition stage of ``trajectory`` into the stage after it."""
+
+    def __init__(self, trajectory, dt_ref, yaml_path, batch=1, device=0, params=None):
+        self.trajectory = trajectory
+        self._init_common(lib().empc_weighted_mpc_create(trajectory._h, int(dt_ref), os.fspath(yaml_path).encode()),
+                          batch, device, params)
+        n = lib().empc_weighted_mpc_t_stages(self._h, None, 0)
+        ts = (C.c_longlong * max(n, 1))()
+        _check(min(lib().empc_weighted_mpc_t_stages(self._h, ts, n), 0))
+        self.t_stages = [int(ts[i]) for i in range(n)]
 
 
 def perturbed_x0s(x0, batch, nq, seed=0, amplitude=0.05, joint_lb=None, joint_ub=None):

@@ -87,6 +87,30 @@ int empc_trajectory_stage_info(const EmpcTrajectory* t, int stage, char* name, i
   EMPC_CATCH(EMPC_ERR_INVALID)
 }
 
+long long empc_trajectory_stage_t_ini(const EmpcTrajectory* t, int stage) {
+  EMPC_TRY
+  if (!t) throw std::invalid_argument("trajectory is NULL");
+  return (long long)t->t->get_stages().at((size_t)stage)->get_t_ini();
+  EMPC_CATCH(-1)
+}
+int empc_trajectory_stage_cost(const EmpcTrajectory* t, int stage, int cost, char* name, int name_len, double* weight,
+                               int* active) {
+  EMPC_TRY
+  if (!t) throw std::invalid_argument("trajectory is NULL");
+  const auto& costs = t->t->get_stages().at((size_t)stage)->get_costs()->get_costs();
+  if (cost < 0 || (size_t)cost >= costs.size()) throw std::out_of_range("cost index out of range");
+  auto it = costs.begin();
+  std::advance(it, cost);
+  if (name && name_len > 0) {
+    std::strncpy(name, it->first.c_str(), (size_t)name_len - 1);
+    name[name_len - 1] = 0;
+  }
+  if (weight) *weight = it->second.weight;
+  if (active) *active = it->second.active;
+  return EMPC_OK;
+  EMPC_CATCH(EMPC_ERR_INVALID)
+}
+
 int empc_trajectory_get_initial_state(const EmpcTrajectory* t, double* x0) {
   EMPC_TRY
   if (!t || !x0) throw std::invalid_argument("NULL argument");
@@ -220,6 +244,87 @@ const EmpcProblemDesc* empc_carrot_mpc_problem_desc(EmpcCarrotMpc* m) {
   if (!m) throw std::invalid_argument("controller is NULL");
   return &m->m->get_problem()->desc();
   EMPC_CATCH(nullptr)
+}
+
+// ---- Rail / Weighted MPC -----------------------------------------------------------------------------------------
+struct EmpcMpc {
+  std::shared_ptr<MpcAbstract> m;
+  std::shared_ptr<RailMpc> rail;
+  std::shared_ptr<WeightedMpc> weighted;
+};
+
+EmpcMpc* empc_rail_mpc_create(const double* state_ref, int n_ref, int nx, int dt_ref_ms, const char* mpc_yaml_path) {
+  EMPC_TRY
+  if (!mpc_yaml_path) throw std::invalid_argument("NULL argument");
+  if (n_ref < 0 || nx <= 0 || dt_ref_ms < 0 || (n_ref > 0 && !state_ref)) throw std::invalid_argument("bad state reference");
+  std::vector<VectorXd> ref((std::size_t)n_ref);
+  for (int i = 0; i < n_ref; ++i)
+    ref[(std::size_t)i].assign(state_ref + (std::size_t)i * (std::size_t)nx, state_ref + (std::size_t)(i + 1) * (std::size_t)nx);
+  auto r = std::make_shared<RailMpc>(ref, (std::size_t)dt_ref_ms, mpc_yaml_path);
+  return new EmpcMpc{r, r, nullptr};
+  EMPC_CATCH(nullptr)
+}
+EmpcMpc* empc_weighted_mpc_create(EmpcTrajectory* t, int dt_ref_ms, const char* mpc_yaml_path) {
+  EMPC_TRY
+  if (!t || !mpc_yaml_path) throw std::invalid_argument("NULL argument");
+  if (dt_ref_ms < 0) throw std::invalid_argument("dt_ref must be >= 0");
+  auto w = std::make_shared<WeightedMpc>(t->t, (std::size_t)dt_ref_ms, mpc_yaml_path);
+  return new EmpcMpc{w, nullptr, w};
+  EMPC_CATCH(nullptr)
+}
+void empc_mpc_destroy(EmpcMpc* m) { delete m; }
+int empc_mpc_params(const EmpcMpc* m, int* knots, int* iters, int* dt_ms, int* nx, int* ndx, int* nu) {
+  EMPC_TRY
+  if (!m) throw std::invalid_argument("controller is NULL");
+  if (knots) *knots = (int)m->m->get_knots();
+  if (iters) *iters = (int)m->m->get_iters();
+  if (dt_ms) *dt_ms = (int)m->m->get_dt();
+  if (nx) *nx = (int)m->m->get_nx();
+  if (ndx) *ndx = (int)m->m->get_ndx();
+  if (nu) *nu = (int)m->m->get_nu();
+  return EMPC_OK;
+  EMPC_CATCH(EMPC_ERR_INVALID)
+}
+int empc_mpc_update_problem(EmpcMpc* m, long long current_time_ms) {
+  EMPC_TRY
+  if (!m) throw std::invalid_argument("controller is NULL");
+  if (current_time_ms < 0) throw std::invalid_argument("current_time must be >= 0");
+  m->m->updateProblem((std::size_t)current_time_ms);
+  return EMPC_OK;
+  EMPC_CATCH(EMPC_ERR_INVALID)
+}
+int empc_mpc_set_x0(EmpcMpc* m, const double* x0) {
+  EMPC_TRY
+  if (!m || !x0) throw std::invalid_argument("NULL argument");
+  m->m->get_problem()->set_x0(VectorXd(x0, x0 + m->m->get_nx()));
+  return EMPC_OK;
+  EMPC_CATCH(EMPC_ERR_INVALID)
+}
+const EmpcProblemDesc* empc_mpc_problem_desc(EmpcMpc* m) {
+  EMPC_TRY
+  if (!m) throw std::invalid_argument("controller is NULL");
+  return &m->m->get_problem()->desc();
+  EMPC_CATCH(nullptr)
+}
+int empc_rail_mpc_state_reference(EmpcMpc* m, long long time_ms, double* xref) {
+  EMPC_TRY
+  if (!m || !xref) throw std::invalid_argument("NULL argument");
+  if (!m->rail) throw std::invalid_argument("not a RailMpc handle");
+  if (time_ms < 0) throw std::invalid_argument("time must be >= 0");
+  const VectorXd& r = m->rail->computeStateReference((std::size_t)time_ms);
+  std::memcpy(xref, r.data(), sizeof(double) * r.size());
+  return EMPC_OK;
+  EMPC_CATCH(EMPC_ERR_INVALID)
+}
+int empc_weighted_mpc_t_stages(const EmpcMpc* m, long long* t_stages, int capacity) {
+  EMPC_TRY
+  if (!m) throw std::invalid_argument("controller is NULL");
+  if (!m->weighted) throw std::invalid_argument("not a WeightedMpc handle");
+  const auto& ts = m->weighted->get_t_stages();
+  if (t_stages)
+    for (std::size_t i = 0; i < ts.size() && (int)i < capacity; ++i) t_stages[i] = (long long)ts[i];
+  return (int)ts.size();
+  EMPC_CATCH(EMPC_ERR_INVALID)
 }
 
 void empc_solver_params_default(EmpcSolverParams* p) {

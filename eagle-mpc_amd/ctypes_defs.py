@@ -10,7 +10,7 @@ MAX_ROTORS = 8
 MAX_NU = 16
 MAX_NR = 28
 MAX_FRAMES = 8
-MAX_COSTS = 12
+MAX_COSTS = 20
 MAX_CONTACTS = 2
 NAME_LEN = 40
 

@@ -303,7 +303,7 @@ class SolverSbFDDP {
 };
 
 // ------------------------------------------------------------------------------------------------------------
-// MPC controllers (include/eagle_mpc/mpc-base.hpp:34-119, include/eagle_mpc/mpc-controllers/carrot-mpc.hpp:23-88)
+// MPC controllers (include/eagle_mpc/mpc-base.hpp:34-119, include/eagle_mpc/mpc-controllers/{carrot,rail,weighted}-mpc.hpp)
 // ------------------------------------------------------------------------------------------------------------
 enum class SolverTypes { SolverSbFDDP, SolverBoxFDDP, SolverBoxDDP, NbSolverTypes };  // mpc-base.hpp:34-39
 
@@ -384,6 +384,70 @@ class CarrotMpc : public MpcAbstract {
     std::size_t idx_stage = 0, idx_last_stage = 0, node_time = 0, idx_state = 0;
     double alpha = 0;
     VectorXd state_ref;
+  } update_vars_;
+};
+
+// RailMpc (include/eagle_mpc/mpc-controllers/rail-mpc.hpp:24-60): every knot tracks the planned state at its own
+// time ("rail_state", weighted quadratic) plus a plain control regularisation ("control").
+class RailMpc : public MpcAbstract {
+ public:
+  // reference ctor: src/mpc-controllers/rail-mpc.cpp:14-60
+  RailMpc(const std::vector<VectorXd>& state_ref, std::size_t dt_ref, const std::string& yaml_path);
+  void createProblem() override;                                 // :64-126
+  void updateProblem(const std::size_t& current_time) override;  // :151-161
+
+  const std::vector<VectorXd>& get_state_ref() const { return state_ref_; }
+  const std::vector<std::size_t>& get_t_ref() const { return t_ref_; }
+  const VectorXd& computeStateReference(const std::size_t& time);  // :176-200
+
+ private:
+  EmpcCostSet createCosts() const;                // :128-149
+  void updateContactCosts(const std::size_t&) {}  // :163 (empty in the reference)
+  void updateFreeCosts(const std::size_t& idx);   // :165-174
+
+  std::vector<VectorXd> state_ref_;
+  std::vector<std::size_t> t_ref_;
+  VectorXd state_activation_weights_;
+  double state_weight_ = 10, control_weight_ = 1e-1;
+  struct UpdateVars {
+    std::size_t node_time = 0, idx_state = 0;
+    double alpha = 0;
+    VectorXd state_ref;
+  } update_vars_;
+};
+
+// WeightedMpc (include/eagle_mpc/mpc-controllers/weighted-mpc.hpp:24-70): every knot carries the task costs of all
+// (non-transition) stages of the trajectory; the costs of the stage active at the knot's time are switched on, the
+// task ones weighted by beta * exp(alpha * (time - end of the stage)).
+class WeightedMpc : public MpcAbstract {
+ public:
+  // reference ctor: src/mpc-controllers/weighted-mpc.cpp:16-72.  NOTE: like the reference, the ctor edits the trajectory
+  // it is given: every transition stage is merged into the stage that follows it.
+  WeightedMpc(const std::shared_ptr<Trajectory>& trajectory, std::size_t dt_ref, const std::string& yaml_path);
+  void createProblem() override;                                 // :76-143
+  void updateProblem(const std::size_t& current_time) override;  // :170-185
+
+  const std::shared_ptr<Trajectory>& get_trajectory() const { return trajectory_; }
+  const std::vector<std::size_t>& get_t_stages() const { return t_stages_; }
+  double get_alpha() const { return alpha_; }
+  double get_beta() const { return beta_; }
+
+ private:
+  CostModelSum createCosts() const;                                                          // :145-168
+  void computeActiveStage(const std::size_t& current_time);                                  // :187-191
+  void computeActiveStage(const std::size_t& current_time, const std::size_t& last_stage);   // :193-199
+  void computeWeight(const std::size_t& time);                                               // :230-243
+  void updateContactCosts(const std::size_t&) {}                                             // :201 (empty)
+  void updateFreeCosts(const std::size_t& idx);                                              // :203-228
+
+  std::shared_ptr<Trajectory> trajectory_;
+  std::vector<std::size_t> t_stages_;
+  std::vector<std::string> cost_names_;  // full names "<stage>/<cost>" in the order of every knot's cost set
+  double alpha_ = 20, beta_ = 1, state_reg_ = 1e-1, control_reg_ = 1e-1;
+  struct UpdateVars {
+    std::size_t idx_stage = 0, idx_last_stage = 0, node_time = 0;
+    std::string name_stage;
+    double weight = 1, weight_time = 0;
   } update_vars_;
 };
 

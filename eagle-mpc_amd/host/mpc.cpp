@@ -1,8 +1,10 @@
-// MpcAbstract / CarrotMpc: host-side mirror of src/mpc-base.cpp and src/mpc-controllers/carrot-mpc.cpp.
+// MpcAbstract / CarrotMpc / RailMpc / WeightedMpc: host-side mirror of src/mpc-base.cpp and
+// src/mpc-controllers/{carrot,rail,weighted}-mpc.cpp.
 // The controller only edits cost tables (references, active flags); the arithmetic of every solve runs in the HIP
 // kernels behind the C ABI.  Where the reference mutates shared Crocoddyl cost models in place, this class edits the
 // private EmpcCostSet of each knot and SolverSbFDDP::syncProblem() uploads the tables.
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <limits>
 #include <stdexcept>
@@ -285,6 +287,227 @@ const VectorXd& CarrotMpc::computeStateReference(const std::size_t& time) {  // 
     for (std::size_t i = 0; i < nv; ++i) update_vars_.state_ref[nq + i] = state_ref_[i0][nq + i];
   }
   return update_vars_.state_ref;
+}
+
+// -----------------------------------------------------------------------------------------------------
+// RailMpc (src/mpc-controllers/rail-mpc.cpp)
+// -----------------------------------------------------------------------------------------------------
+RailMpc::RailMpc(const std::vector<VectorXd>& state_ref, std::size_t dt_ref, const std::string& yaml_path)
+    : MpcAbstract(yaml_path) {  // :14-60
+  state_ref_ = state_ref;
+  for (const auto& x : state_ref_)
+    if (x.size() != get_nx()) throw std::invalid_argument("RailMpc: state_ref[i] has wrong dimension");
+  for (std::size_t i = 0; i < state_ref_.size(); ++i) t_ref_.push_back(dt_ref * i);
+
+  const std::string p = "mpc_controller/";
+  try {
+    state_weight_ = params_server_->getParam<double>(p + "rail_weight");
+  } catch (const std::exception&) {
+    state_weight_ = 10;
+  }
+  try {
+    state_activation_weights_ = converter<VectorXd>::convert(params_server_->getParam<std::string>(p + "rail_activation_weights"));
+  } catch (const std::exception&) {
+    state_activation_weights_ = VectorXd(get_ndx(), 1.0);
+  }
+  try {
+    control_weight_ = params_server_->getParam<double>(p + "rail_control_weight");
+  } catch (const std::exception&) {
+    control_weight_ = 1e-1;
+  }
+  createProblem();
+  update_vars_.state_ref = zero_state();
+}
+
+EmpcCostSet RailMpc::createCosts() const {  // :128-149
+  const std::size_t nx = get_nx(), ndx = get_ndx(), nu = get_nu();
+  const VectorXd zero = zero_state();
+  CostModelSum costs;
+  EmpcCost rail = blank_cost("rail_state", EMPC_COST_STATE, EMPC_ACT_WEIGHTED_QUAD, (int)ndx, state_weight_, true);
+  // the reference builds this error without throwing it (:42-46); the mismatch then fails inside CostModelResidual
+  if (state_activation_weights_.size() != ndx)
+    throw std::invalid_argument("RailMPC: the dimension for the state activation weights vector is " +
+                                std::to_string(state_activation_weights_.size()) + ", should be " + std::to_string(ndx));
+  for (std::size_t i = 0; i < ndx; ++i) rail.act_w[i] = state_activation_weights_[i];
+  for (std::size_t i = 0; i < nx; ++i) rail.ref[i] = zero[i];
+  costs.addCost("rail_state", rail, state_weight_, true);
+  EmpcCost control = blank_cost("control", EMPC_COST_CONTROL, EMPC_ACT_QUAD, (int)nu, control_weight_, true);
+  costs.addCost("control", control, control_weight_, true);
+  return makeCostSet(costs, ContactModelMultiple());
+}
+
+// the receding-horizon problem shared by the controllers: knots private action models, x0 = state->zero()
+static std::shared_ptr<ShootingProblem> horizon_problem(const MpcAbstract& mpc, const MpcParams& params,
+                                                        const std::vector<EmpcCostSet>& sets, const std::vector<int>& frames) {
+  if (params.knots < 2) throw std::invalid_argument("MPC: knots must be >= 2");
+  std::vector<int> knot_set;
+  for (std::size_t i = 0; i < params.knots; ++i) knot_set.push_back((int)i);
+  const int integrator = params.integrator_type == IntegratedActionModelTypes::IntegratedActionModelEuler ? EMPC_INTEGRATOR_EULER
+                                                                                                           : EMPC_INTEGRATOR_RK4;
+  const bool squash = params.solver_type == SolverTypes::SolverSbFDDP;  // actuation_squash_ vs actuation_
+  const auto& platform = mpc.get_platform_params();
+  return std::make_shared<ShootingProblem>(mpc.zero_state(), mpc.get_robot_model()->descWithFrames(frames), sets, knot_set,
+                                           platform->tau_f_, platform->u_lb, platform->u_ub, double(params.dt) / 1000.0, false,
+                                           squash, integrator);
+}
+
+void RailMpc::createProblem() {  // :64-126 (always the free-flight dynamics, :66-67)
+  std::vector<EmpcCostSet> sets;
+  for (std::size_t i = 0; i < params_.knots; ++i) sets.push_back(createCosts());
+  problem_ = horizon_problem(*this, params_, sets, std::vector<int>());
+}
+
+void RailMpc::updateProblem(const std::size_t& current_time) {  // :151-161
+  for (std::size_t i = 0; i < params_.knots; ++i) {
+    update_vars_.node_time = current_time + i * params_.dt;
+    updateFreeCosts(i);
+  }
+}
+
+void RailMpc::updateFreeCosts(const std::size_t& idx) {  // :165-174
+  EmpcCost& rail = find_cost(problem_->get_sets().at(idx), "rail_state");
+  computeStateReference(update_vars_.node_time);
+  for (std::size_t i = 0; i < get_nx(); ++i) rail.ref[i] = update_vars_.state_ref[i];
+}
+
+const VectorXd& RailMpc::computeStateReference(const std::size_t& time) {  // :176-200
+  const std::size_t nq = (std::size_t)robot_model_->nq(), nv = (std::size_t)robot_model_->nv();
+  if (state_ref_.empty()) throw std::runtime_error("RailMpc: empty state reference");
+  update_vars_.idx_state = std::size_t(std::upper_bound(t_ref_.begin(), t_ref_.end(), time) - t_ref_.begin());
+  if (update_vars_.idx_state >= state_ref_.size()) {
+    // hover at the last planned configuration, yaw kept: q = last q with (qz, qw) replaced by the normalised
+    // (0, 0, qz, qw) quaternion; qx, qy stay as copied (the reference overwrites entries 5 and 6 only, :181-185)
+    update_vars_.state_ref = zero_state();
+    const VectorXd& last = state_ref_.back();
+    for (std::size_t i = 0; i < nq; ++i) update_vars_.state_ref[i] = last[i];
+    double w = last[6], z = last[5];
+    const double n2 = w * w + z * z;
+    if (n2 > 0) {  // Eigen's normalize() leaves a zero quaternion untouched
+      const double n = std::sqrt(n2);
+      w /= n;
+      z /= n;
+    }
+    update_vars_.state_ref[5] = z;
+    update_vars_.state_ref[6] = w;
+  } else {
+    // same std::size_t quotient as CarrotMpc (:187-188): always 0, so the reference is the sample at or before `time`
+    const std::size_t i1 = update_vars_.idx_state, i0 = i1 - 1;
+    const std::size_t quotient = (time - t_ref_[i0]) / (t_ref_[i1] - t_ref_[i0]);
+    update_vars_.alpha = (double)quotient;
+    if (quotient != 0) throw std::logic_error("RailMpc: non-zero integer interpolation factor");
+    for (std::size_t i = 0; i < nq + nv; ++i) update_vars_.state_ref[i] = state_ref_[i0][i];
+  }
+  return update_vars_.state_ref;
+}
+
+// -----------------------------------------------------------------------------------------------------
+// WeightedMpc (src/mpc-controllers/weighted-mpc.cpp)
+// -----------------------------------------------------------------------------------------------------
+WeightedMpc::WeightedMpc(const std::shared_ptr<Trajectory>& trajectory, std::size_t, const std::string& yaml_path)
+    : MpcAbstract(yaml_path), trajectory_(trajectory) {  // :16-72 (dt_ref is unused by the reference too)
+  if (!trajectory) throw std::invalid_argument("WeightedMpc: trajectory is null");
+  auto scalar = [&](const char* key, double fallback) {
+    try {
+      return params_server_->getParam<double>(std::string("mpc_controller/") + key);
+    } catch (const std::exception&) {
+      return fallback;
+    }
+  };
+  alpha_ = scalar("weighted_alpha", 20.0);
+  beta_ = scalar("weighted_beta", 1.0);
+  state_reg_ = scalar("weighted_state_reg", 1e-1);      // loaded and never used, as in the reference
+  control_reg_ = scalar("weighted_control_reg", 1e-1);  // idem
+
+  // every transition stage is folded into its successor, which then starts where the transition started (:57-69)
+  for (std::size_t i = 0; i < trajectory_->get_stages().size(); ++i) {
+    const auto& stages = trajectory_->get_stages();
+    if (stages[i]->get_is_transition()) {
+      if (i + 1 >= stages.size())  // the reference indexes past the end here
+        throw std::runtime_error("WeightedMpc: the last stage of the trajectory is a transition");
+      stages[i + 1]->set_duration(stages[i]->get_duration() + stages[i + 1]->get_duration());
+      stages[i + 1]->set_t_ini(stages[i]->get_t_ini());
+      trajectory_->removeStage(i);
+    }
+    t_stages_.push_back(trajectory_->get_stages()[i]->get_t_ini());
+  }
+  createProblem();
+}
+
+CostModelSum WeightedMpc::createCosts() const {  // :145-168
+  CostModelSum costs;
+  for (const auto& stage : trajectory_->get_stages()) {
+    if (stage->get_is_transition()) continue;
+    // The reference re-creates each cost from the trajectory's parameter server with the same path and type
+    // (:156-158); the stage already holds exactly that object, so it is copied.  Added inactive, with the stage's weight.
+    for (const auto& ctype : stage->get_cost_types()) {
+      const EmpcCost& cost = stage->get_costs()->get_costs().at(ctype.first);
+      const std::string name = stage->get_name() + "/" + ctype.first;
+      if (name.size() >= EMPC_NAME_LEN) throw std::runtime_error("WeightedMpc: cost name too long: " + name);
+      costs.addCost(name, cost, cost.weight, false);
+    }
+  }
+  return costs;
+}
+
+void WeightedMpc::createProblem() {  // :76-143
+  if (trajectory_->get_has_contact()) throw std::runtime_error("Weighted with contact has not been implemented");  // :100
+  const CostModelSum costs = createCosts();
+  cost_names_.clear();
+  for (const auto& kv : costs.get_costs()) cost_names_.push_back(kv.first);
+  const EmpcCostSet set = makeCostSet(costs, ContactModelMultiple());
+  std::vector<EmpcCostSet> sets(params_.knots, set);
+  problem_ = horizon_problem(*this, params_, sets, trajectory_->frame_table().ids());
+}
+
+void WeightedMpc::updateProblem(const std::size_t& current_time) {  // :170-185
+  computeActiveStage(current_time);
+  update_vars_.idx_last_stage = update_vars_.idx_stage;
+  for (std::size_t i = 0; i < params_.knots; ++i) {
+    update_vars_.node_time = current_time + i * params_.dt;
+    computeActiveStage(update_vars_.node_time, update_vars_.idx_last_stage);
+    update_vars_.name_stage = trajectory_->get_stages().at(update_vars_.idx_stage)->get_name();
+    updateFreeCosts(i);
+    update_vars_.idx_last_stage = update_vars_.idx_stage;
+  }
+}
+
+void WeightedMpc::computeActiveStage(const std::size_t& current_time) {  // :187-191
+  update_vars_.idx_stage = std::size_t(std::upper_bound(t_stages_.begin(), t_stages_.end(), current_time) - t_stages_.begin()) - 1;
+}
+
+void WeightedMpc::computeActiveStage(const std::size_t& current_time, const std::size_t& last_stage) {  // :193-199
+  computeActiveStage(current_time);
+  if (update_vars_.idx_stage == last_stage + 2) update_vars_.idx_stage -= 1;  // never skip a stage between two knots
+}
+
+void WeightedMpc::updateFreeCosts(const std::size_t& idx) {  // :203-228
+  EmpcCostSet& set = problem_->get_sets().at(idx);
+  const std::string& stage_name = update_vars_.name_stage;
+  const auto& stage = trajectory_->get_stages().at(update_vars_.idx_stage);
+  for (std::size_t c = 0; c < cost_names_.size(); ++c) {
+    const std::string& name = cost_names_[c];
+    EmpcCost& cost = set.costs[c];
+    if (name.compare(0, stage_name.size(), stage_name) == 0) {  // prefix match, as in the reference
+      cost.active = 1;
+      if (name.compare(stage_name.size(), 4, "/reg") != 0 && name.compare(stage_name.size(), 7, "/limits") != 0) {
+        computeWeight(update_vars_.node_time);
+        // .at() throws std::out_of_range when the prefix matched a longer stage name, like the reference's map::at
+        cost.weight = stage->get_costs()->get_costs().at(name.substr(stage_name.size() + 1)).weight * update_vars_.weight * beta_;
+      }
+    } else {
+      cost.active = 0;  // ("barrier" is exempt in the reference, :223; here the barrier lives inside the solver)
+    }
+  }
+}
+
+void WeightedMpc::computeWeight(const std::size_t& time) {  // :230-243
+  if (time > trajectory_->get_duration()) {  // saturate once the knot is beyond the end of the trajectory
+    update_vars_.weight_time = 0.0;
+  } else {
+    const auto& stage = trajectory_->get_stages().at(update_vars_.idx_stage);
+    update_vars_.weight_time = ((int)time - ((int)stage->get_t_ini() + (int)stage->get_duration())) / 1000.0;
+  }
+  update_vars_.weight = std::exp(alpha_ * update_vars_.weight_time);
 }
 
 }  // namespace eagle_mpc

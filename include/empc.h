@@ -23,6 +23,8 @@
  *                             (src/mpc-controllers/carrot-mpc.cpp:298-359)
  *   empc_carrot_mpc_*         CarrotMpc ctor/createProblem/updateProblem/computeStateReference
  *                             (src/mpc-controllers/carrot-mpc.cpp:15-50,178-248,298-403, src/mpc-base.cpp:5-60)
+ *   empc_rail_mpc_* / empc_weighted_mpc_* / empc_mpc_*
+ *                             RailMpc, WeightedMpc (src/mpc-controllers/rail-mpc.cpp, weighted-mpc.cpp)
  *   empc_plant_*              AerialSimulator.simulateStep (bindings/python/eagle_mpc/utils/simulator.py:24-29)
  *   empc_linearize_batch / empc_backward_batch / empc_rollout_batch
  *                             crocoddyl SolverDDP::calcDiff / backwardPass / SolverFDDP::forwardPass as called at
@@ -62,6 +64,11 @@ int empc_trajectory_dims(const EmpcTrajectory* t, int* nx, int* ndx, int* nu, in
                          int* duration_ms);
 int empc_trajectory_stage_info(const EmpcTrajectory* t, int stage, char* name, int name_len, int* duration_ms,
                                int* is_transition, int* n_costs, int* n_contacts);
+/* Stage::get_t_ini() (include/eagle_mpc/stage.hpp); -1 on error */
+long long empc_trajectory_stage_t_ini(const EmpcTrajectory* t, int stage);
+/* Stage::get_costs()->get_costs(): the cost-th entry in name order, with its weight and active flag */
+int empc_trajectory_stage_cost(const EmpcTrajectory* t, int stage, int cost, char* name, int name_len, double* weight,
+                               int* active);
 int empc_trajectory_get_initial_state(const EmpcTrajectory* t, double* x0 /* nx */);
 int empc_trajectory_set_initial_state(EmpcTrajectory* t, const double* x0 /* nx */);
 int empc_trajectory_get_platform(const EmpcTrajectory* t, double* tau_f /* 6 x n_rotors */, double* u_lb, double* u_ub,
@@ -167,6 +174,31 @@ int empc_carrot_mpc_state_reference(EmpcCarrotMpc* m, long long time_ms, double*
 /* problem.x0 = x0 */
 int empc_carrot_mpc_set_x0(EmpcCarrotMpc* m, const double* x0 /* nx */);
 const EmpcProblemDesc* empc_carrot_mpc_problem_desc(EmpcCarrotMpc* m);
+
+/* ---- Rail / Weighted MPC controllers ----------------------------------------------------------------------------
+ * (include/eagle_mpc/mpc-controllers/rail-mpc.hpp:24-60, weighted-mpc.hpp:24-70; both derive MpcAbstract,
+ * include/eagle_mpc/mpc-base.hpp:59-119).  Host-side logic only, same use as EmpcCarrotMpc: update the cost tables for a
+ * time, hand empc_mpc_problem_desc() to empc_solver_create / empc_solver_update_problem. */
+typedef struct EmpcMpc EmpcMpc;
+/* RailMpc(state_ref, dt_ref, yaml_path)   src/mpc-controllers/rail-mpc.cpp:14-60 */
+EmpcMpc* empc_rail_mpc_create(const double* state_ref /* n_ref x nx */, int n_ref, int nx, int dt_ref_ms,
+                              const char* mpc_yaml_path);
+/* WeightedMpc(trajectory, dt_ref, yaml_path)   src/mpc-controllers/weighted-mpc.cpp:16-72.  Like the reference this
+ * EDITS the trajectory: each transition stage is merged into the stage after it. */
+EmpcMpc* empc_weighted_mpc_create(EmpcTrajectory* t, int dt_ref_ms, const char* mpc_yaml_path);
+void empc_mpc_destroy(EmpcMpc* m);
+/* get_knots / get_iters / get_dt (src/mpc-base.cpp:81-85) and the problem's dimensions */
+int empc_mpc_params(const EmpcMpc* m, int* knots, int* iters, int* dt_ms, int* nx, int* ndx, int* nu);
+/* updateProblem(current_time)   rail-mpc.cpp:151-161, weighted-mpc.cpp:170-185 */
+int empc_mpc_update_problem(EmpcMpc* m, long long current_time_ms);
+/* problem.x0 = x0 */
+int empc_mpc_set_x0(EmpcMpc* m, const double* x0 /* nx */);
+const EmpcProblemDesc* empc_mpc_problem_desc(EmpcMpc* m);
+/* RailMpc::computeStateReference(time)   rail-mpc.cpp:176-200 (error for a WeightedMpc handle) */
+int empc_rail_mpc_state_reference(EmpcMpc* m, long long time_ms, double* xref /* nx */);
+/* WeightedMpc::get_t_stages()   weighted-mpc.cpp:246; returns the count, fills t_stages when not NULL
+ * (error for a RailMpc handle) */
+int empc_weighted_mpc_t_stages(const EmpcMpc* m, long long* t_stages, int capacity);
 
 #ifdef __cplusplus
 }

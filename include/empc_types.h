@@ -35,7 +35,7 @@ extern "C" {
 #define EMPC_MAX_NU 16      /* rotors + arm joints                                */
 #define EMPC_MAX_NR 28      /* longest residual (state residual = ndx)            */
 #define EMPC_MAX_FRAMES 8
-#define EMPC_MAX_COSTS 12   /* per cost set, including the solver's "barrier"     */
+#define EMPC_MAX_COSTS 20   /* per cost set, including the solver's "barrier"     */
 #define EMPC_MAX_CONTACTS 2
 #define EMPC_NAME_LEN 40
 

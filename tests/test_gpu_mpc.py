@@ -49,20 +49,18 @@ def test_plant_rk4_parity(empc, problems, name):
         s2.plant_step(2)
 
 
-def test_closed_loop_matches_oracle(empc):
+def planned_trajectory(empc, dt_traj=80):
     traj = empc.Trajectory()
     traj.autoSetup(empc.yaml_path(ARM3_TRAJ))
-    dt_traj = 80
     prob = traj.createProblem(dt_traj, True, "IntegratedActionModelEuler")
     tsolver = empc.SolverSbFDDP(prob, batch=1)
     tsolver.solve([], [], 100)
-    xs_ref = np.array(tsolver.xs)
-    us_ref = np.array(tsolver.us)
+    return traj, np.array(tsolver.xs), np.array(tsolver.us)
 
-    B, n_steps, dt_sim = 4, 6, 2
-    mpc = empc.CarrotMpc(traj, xs_ref, dt_traj, empc.yaml_path(ARM3_MPC), batch=B)
+
+def closed_loop(empc, mpc, xs_ref, us_ref, nq, B=4, n_steps=6, dt_sim=2, tol=1e-6):
+    """examples/python/mpc.py:30-62 on the GPU (B plants at once) and on the oracle (one plant at a time)."""
     T_ = mpc.problem.T
-    nq = traj.nx - traj.ndx // 2
     x_plants = empc.perturbed_x0s(xs_ref[0], B, nq=nq, amplitude=0.02)
     d = mpc.problem.desc
 
@@ -80,8 +78,8 @@ def test_closed_loop_matches_oracle(empc):
         r = s.result()
         o_xs.append(r["xs"])
         o_us.append(r["us"])
-    assert np.abs(solver.xs_batch - np.array(o_xs)).max() < 1e-6
-    assert np.abs(solver.us_batch - np.array(o_us)).max() < 1e-6
+    assert np.abs(solver.xs_batch - np.array(o_xs)).max() < tol
+    assert np.abs(solver.us_batch - np.array(o_us)).max() < tol
 
     t = 0
     worst = 0.0
@@ -98,10 +96,32 @@ def test_closed_loop_matches_oracle(empc):
             s.solve(o_xs[b], o_us[b], mpc.iters)
             r = s.result()
             o_xs[b], o_us[b] = r["xs"], r["us"]
-            assert np.abs(usq[b] - r["us_squash"][0]).max() < 1e-6, (step, b)
+            assert np.abs(usq[b] - r["us_squash"][0]).max() < tol, (step, b)
             o_x[b] = ob.plant_rk4(d, o_x[b], r["us_squash"][0], dt_sim / 1000.0)[0]
         worst = max(worst, np.abs(gx - o_x).max())
         t += dt_sim
-    assert worst < 1e-6
+    assert worst < tol
     # the plants moved and stayed bounded
     assert np.isfinite(gx).all() and np.abs(gx - x_plants).max() > 1e-5
+    return worst
+
+
+def test_closed_loop_matches_oracle(empc):
+    traj, xs_ref, us_ref = planned_trajectory(empc)
+    mpc = empc.CarrotMpc(traj, xs_ref, 80, empc.yaml_path(ARM3_MPC), batch=4)
+    closed_loop(empc, mpc, xs_ref, us_ref, nq=traj.nx - traj.ndx // 2)
+
+
+def test_rail_closed_loop_matches_oracle(empc):
+    """RailMpc (src/mpc-controllers/rail-mpc.cpp): every knot tracks the planned state at its own time."""
+    traj, xs_ref, us_ref = planned_trajectory(empc)
+    mpc = empc.RailMpc(xs_ref, 80, empc.yaml_path(ARM3_MPC), batch=4)
+    closed_loop(empc, mpc, xs_ref, us_ref, nq=traj.nx - traj.ndx // 2)
+
+
+def test_weighted_closed_loop_matches_oracle(empc):
+    """WeightedMpc (src/mpc-controllers/weighted-mpc.cpp): task costs of the active stage, exponentially weighted; the
+    cost sets carry an operational frame, so this also runs the full linearize body inside the MPC loop."""
+    traj, xs_ref, us_ref = planned_trajectory(empc)
+    mpc = empc.WeightedMpc(traj, 80, empc.yaml_path(ARM3_MPC), batch=4)
+    closed_loop(empc, mpc, xs_ref, us_ref, nq=traj.nx - traj.ndx // 2)
