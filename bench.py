@@ -29,9 +29,11 @@ CONFIGS = {
     "push_slide": ("hextilt_flying_arm_5/trajectories/push_slide.yaml", 13),
     # BASELINE.json configs[4]: closed-loop Carrot MPC on the displacement trajectory, 50-knot horizon, RK4 plants
     "carrot_mpc": ("hexacopter370_flying_arm_3/trajectories/displacement.yaml", 80),
+    "rail_mpc": ("hexacopter370_flying_arm_3/trajectories/displacement.yaml", 80),
+    "weighted_mpc": ("hexacopter370_flying_arm_3/trajectories/displacement.yaml", 80),
 }
 MPC_YAML = os.path.join(ROOT, "eagle-mpc_amd", "data", "mpc", "carrot_50knots.yaml")
-MPC_CYCLES_PER_STEP = 20   # one bench step of the carrot_mpc config = 20 controller cycles (updateProblem, solve, plant)
+MPC_CYCLES_PER_STEP = 20   # one bench step of the *_mpc configs = 20 controller cycles (updateProblem, solve, plant)
 MPC_DT_SIM = 2             # ms, examples/python/mpc.py:41
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
@@ -53,7 +55,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=None, help="rollouts per GPU (default 1024; 256 for carrot_mpc)")
+    ap.add_argument("--batch", type=int, default=None, help="rollouts per GPU (default 1024; 256 for the *_mpc configs)")
     ap.add_argument("--config", default="displacement", choices=sorted(CONFIGS))
     ap.add_argument("--maxiter", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -84,8 +86,9 @@ def main():
         dist = dist_mod
         dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
 
+    is_mpc = args.config.endswith("_mpc")
     if args.batch is None:
-        args.batch = 256 if args.config == "carrot_mpc" else 1024
+        args.batch = 256 if is_mpc else 1024
     rel, dt = CONFIGS[args.config]
     traj = empc.Trajectory()
     traj.autoSetup(empc.yaml_path(rel))
@@ -97,14 +100,19 @@ def main():
     sharding = importlib.import_module("eagle_mpc_amd.sharding")
     x0_all = empc.perturbed_x0s(problem.x0, B * world, nq=d.model.nq)
     x0s = sharding.shard(x0_all, world, rank)
-    solver = empc.SolverSbFDDP(problem, batch=B, device=local_dev) if args.config != "carrot_mpc" else None
+    solver = empc.SolverSbFDDP(problem, batch=B, device=local_dev) if not is_mpc else None
     mpc_state = {"t": 0}
-    if args.config == "carrot_mpc":
+    if is_mpc:
         # plan once (one rollout), then B controllers-in-one track it from perturbed plant states
         planner = empc.SolverSbFDDP(problem, batch=1, device=local_dev)
         planner.solve([], [], args.maxiter)
         xs_plan, us_plan = np.array(planner.xs), np.array(planner.us)
-        mpc = empc.CarrotMpc(traj, xs_plan, dt, MPC_YAML, batch=B, device=local_dev)
+        if args.config == "carrot_mpc":
+            mpc = empc.CarrotMpc(traj, xs_plan, dt, MPC_YAML, batch=B, device=local_dev)
+        elif args.config == "rail_mpc":
+            mpc = empc.RailMpc(xs_plan, dt, MPC_YAML, batch=B, device=local_dev)
+        else:
+            mpc = empc.WeightedMpc(traj, dt, MPC_YAML, batch=B, device=local_dev)
         mpc.updateProblem(0)
         solver = mpc.solver
         d = mpc.problem.desc
@@ -141,7 +149,7 @@ def main():
         return agg_s
 
     def one_step():
-        if args.config == "carrot_mpc":
+        if is_mpc:
             return mpc_step()
         solver.solve([], [], args.maxiter, x0s=x0s)
         if dist is not None:
@@ -208,10 +216,10 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": ("%s dt=%dms T=%d batch=%d/GPU SolverSbFDDP.solve(maxiter=%d), perturbed x0" %
-                                    (rel, dt, d.T, B, args.maxiter)) if args.config != "carrot_mpc" else
-                                   ("CarrotMpc closed loop on %s: %d-knot horizon dt=%dms, %d plants/GPU (RK4, %d ms), %d cycles/step, "
+                                    (rel, dt, d.T, B, args.maxiter)) if not is_mpc else
+                                   ("%s closed loop on %s: %d-knot horizon dt=%dms, %d plants/GPU (RK4, %d ms), %d cycles/step, "
                                     "%d iterations/cycle, warm start and plant states device-resident" %
-                                    (rel, d.T + 1, mpc.dt, B, MPC_DT_SIM, MPC_CYCLES_PER_STEP, mpc.iters)),
+                                    (type(mpc).__name__, rel, d.T + 1, mpc.dt, B, MPC_DT_SIM, MPC_CYCLES_PER_STEP, mpc.iters)),
                        "nx": d.nx, "ndx": d.ndx, "nu": d.nu, "parallelism": "batch-sharded x%d" % world},
             "trajectory_iters_per_s": iters_total / elapsed,
             "mean_iters_per_trajectory": iters_total / (B * world * args.steps),
@@ -227,10 +235,10 @@ def main():
                                    "achieved_GBs": iters_total * d.T * words["iteration"] * 8 / elapsed / 1e9 / world,
                                    "frac_of_8TBs": iters_total * d.T * words["iteration"] * 8 / elapsed / 1e9 / world / HBM_PEAK_GBS},
         }
-        if args.config == "carrot_mpc":
+        if is_mpc:
             out["mpc_cycles_per_s"] = args.steps * MPC_CYCLES_PER_STEP / elapsed
             out["plant_controller_cycles_per_s"] = args.steps * MPC_CYCLES_PER_STEP * B * world / elapsed
-        if not args.no_cpu_baseline and args.config != "carrot_mpc" and world == 1:  # rank 0 at N = 1 only
+        if not args.no_cpu_baseline and not is_mpc and world == 1:  # rank 0 at N = 1 only
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_binding as ob  # the oracle timed as the CPU baseline ("port"), never part of the product path
             cores = os.cpu_count() or 1
