@@ -1,4 +1,4 @@
-// Host-side C++ (YAML / URDF readers, problem factory, Carrot MPC) under AddressSanitizer + UBSan + LeakSanitizer:
+// Host-side C++ (YAML / URDF readers, problem factory, Carrot / Rail / Weighted MPC) under AddressSanitizer + UBSan + LeakSanitizer:
 // built and run by tests/test_host_sanitize.py.  The solver entry points are stubbed: nothing here touches a GPU.
 #include <string>
 #include <cstdio>
@@ -41,6 +41,13 @@ int main(int argc, char** argv) {
       CarrotMpc mpc(t, ref, 80, yaml_dir() + "/hexacopter370_flying_arm_3/mpc/mpc.yaml");
       for (std::size_t tm : {0, 1700, 2010, 8000, 9000}) mpc.updateProblem(tm);
       std::printf("mpc knots %zu T %zu\n", mpc.get_knots(), mpc.get_problem()->get_T());
+      RailMpc rail(ref, 80, yaml_dir() + "/hexacopter370_flying_arm_3/mpc/mpc.yaml");
+      for (std::size_t tm : {0, 79, 7990, 8000, 20000}) rail.updateProblem(tm);
+      std::printf("rail knots %zu\n", rail.get_knots());
+      // last: WeightedMpc edits the trajectory (merges its transition stages)
+      WeightedMpc weighted(t, 80, yaml_dir() + "/hexacopter370_flying_arm_3/mpc/mpc.yaml");
+      for (std::size_t tm : {0, 1990, 2000, 7990, 8000, 9000}) weighted.updateProblem(tm);
+      std::printf("weighted stages %zu t_stages %zu\n", t->get_stages().size(), weighted.get_t_stages().size());
     }
   }
   // malformed inputs must throw, not crash
