@@ -579,7 +579,11 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
 #pragma unroll
         for (int i = 0; i < 6; ++i) F[12 + i] = fv[i];
       }
-    } else if (lane == 1) {
+    }
+  });
+  LIN_STAMP(12);
+  ex.each([&](int lane, int sl) {
+    if (lane == 1) {
       double x[NX], dxe[NDX], xnext[NX], pe[3], J2[36];
 #pragma unroll
       for (int i = 0; i < NX; ++i) x[i] = N[SM::OFF_X + i];
@@ -876,78 +880,85 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
       for (int i = 0; i < NDX; ++i) hxu_l[sl][i] = 0.0;
     }
   });
-  // round 1: State costs, nominal parts by one lane per cost (same code), up to NSLOT at a time.  The parameters of the
-  // NSLOT costs (reference, weights, bounds) are first copied into LDS by the whole unit -- coalesced, one memory latency
-  // -- into the body / inertia / Lie-Jacobian / xnext / gap area, which is dead from here on; a per-lane load / wait / branch per
-  // component cost a third of the kernel (profiles/r01_rollout_ablation.txt).
-  constexpr int CPAR = NX + 3 * NDX;  // ref | act_w | lb | ub
-  static_assert(SM::NSLOT * CPAR <= SM::OFF_FR - SM::OFF_BODY, "cost parameter staging does not fit the dead LDS area");
+  // round 1: State costs, up to NSLOT at a time.  Phase A: one lane per cost that owns its reference (ref_share, set by
+  // prepare_problem) takes the state difference and its log Jacobian -- the only serial part.  Phase B: the activation of
+  // all components at once, lane i = component i, costs in a uniform loop: the cost set is the same for the whole unit,
+  // so type and weight are scalar loads and the branch on the activation type is uniform; the component parameters
+  // (act_w / lb / ub) are one coalesced vector load each.  (Before: one lane per cost ran the 18 activations in a
+  // row, after a copy of all parameters into LDS; 19k of a unit's 87k cycles.)
+  static_assert(EMPC_MAX_COSTS % SM::NSLOT == 0, "group loads assume whole groups inside costs[]");
   for (int base = 0; base < set.ncosts; base += SM::NSLOT) {
+    // uniform facts of the group, loaded once (costs[] has EMPC_MAX_COSTS entries: base + q is always in range)
+    bool on[SM::NSLOT];
+    int own[SM::NSLOT], act[SM::NSLOT];
+    double wg[SM::NSLOT];
+#pragma unroll
+    for (int q = 0; q < SM::NSLOT; ++q) {
+      const EMPC_K EmpcCost& c = set.costs[base + q];
+      on[q] = base + q < set.ncosts && c.active && c.type == EMPC_COST_STATE;
+      own[q] = (c.ref_share >= base) ? c.ref_share - base : q;  // slot holding this cost's residual and log Jacobian
+      act[q] = c.activation;
+      wg[q] = c.weight;
+    }
     ex.sync();
-    ex.each([&](int lane, int sl) {
-      for (int q = 0; q < SM::NSLOT && base + q < set.ncosts; ++q) {
-        const EMPC_K EmpcCost& cq = set.costs[base + q];
-        if (!cq.active || cq.type != EMPC_COST_STATE) continue;
-        double* Pq = N + SM::OFF_BODY + q * CPAR;
-        for (int i = lane; i < CPAR; i += lpu) {
-          double v;
-          if (i < NX)
-            v = cq.ref[i];
-          else if (i < NX + NDX)
-            v = cq.act_w[i - NX];
-          else if (i < NX + 2 * NDX)
-            v = cq.lb[i - NX - NDX];
-          else
-            v = cq.ub[i - NX - 2 * NDX];
-          Pq[i] = v;
-        }
-      }
-    });
-    ex.sync();
+    LIN_STAMP(10);
     ex.each([&](int lane, int sl) {
       if (lane >= SM::NSLOT || base + lane >= set.ncosts) return;
       const EMPC_K EmpcCost& c = set.costs[base + lane];
+      if (!c.active || c.type != EMPC_COST_STATE || c.ref_share >= base) return;
       double* S = N + SM::OFF_CST + lane * SM::SLOT;
-      if (!c.active || c.type != EMPC_COST_STATE) {
-        S[3 * NDX + 36] = 0.0;
-        return;
-      }
-      const int act = c.activation;
-      const double wgt = c.weight;
-      const double* xref = N + SM::OFF_BODY + lane * CPAR;
-      const double* pw = xref + NX;
-      const double* plb = pw + NDX;
-      const double* pub = plb + NDX;
-      // residual and log Jacobian go straight to their LDS slot (r | Ar | Arr | J6 | value): no 54-double register
-      // arrays next to the column accumulators
-      double* r = S;
-      double dpl[3];
-      state_diff<DM>(xref, N + SM::OFF_X, r, dpl);
-      Jlog6(r, dpl, S + 3 * NDX);
-      double cv = 0;
+      double xref[NX], dpl[3];
 #pragma unroll
-      for (int i = 0; i < NDX; ++i) {
-        double av, Ar, Arr;
-        activation_sel(act, r[i], pw[i], plb[i], pub[i], av, Ar, Arr);
-        cv += av;
-        S[NDX + i] = wgt * Ar;
-        S[2 * NDX + i] = wgt * Arr;
-      }
-      S[3 * NDX + 36] = wgt * cv;
+      for (int i = 0; i < NX; ++i) xref[i] = c.ref[i];
+      // residual and log Jacobian go straight to their LDS slot (r | Ar | Arr | J6 | value)
+      state_diff<DM>(xref, N + SM::OFF_X, S, dpl);
+      Jlog6(S, dpl, S + 3 * NDX);
     });
     ex.sync();
+    LIN_STAMP(11);
+    ex.each([&](int lane, int sl) {
+      if (lane >= NDX) return;
+      // all parameter loads of the group first, then the arithmetic: one memory latency for the group, not one per cost
+      double pw[SM::NSLOT], plb[SM::NSLOT], pub[SM::NSLOT];
+#pragma unroll
+      for (int q = 0; q < SM::NSLOT; ++q) {
+        const EMPC_K EmpcCost& c = set.costs[base + q];
+        pw[q] = c.act_w[lane];
+        plb[q] = c.lb[lane];
+        pub[q] = c.ub[lane];
+      }
+#pragma unroll
+      for (int q = 0; q < SM::NSLOT; ++q) {
+        if (!on[q]) continue;
+        double* S = N + SM::OFF_CST + q * SM::SLOT;
+        double av, Ar, Arr;
+        activation1(act[q], N[SM::OFF_CST + own[q] * SM::SLOT + lane], pw[q], plb[q], pub[q], av, Ar, Arr);
+        S[NDX + lane] = wg[q] * Ar;
+        S[2 * NDX + lane] = wg[q] * Arr;
+        N[SM::OFF_RSH + q * NDX + lane] = av;  // the exchange area of the frame-cost round is free here
+      }
+    });
+    ex.sync();
+    LIN_STAMP(13);
     ex.each([&](int lane, int sl) {
       if (lane == 0) {
         double a_ = 0;
-        for (int q = 0; q < SM::NSLOT && base + q < set.ncosts; ++q) a_ += N[SM::OFF_CST + q * SM::SLOT + 3 * NDX + 36];
+#pragma unroll
+        for (int q = 0; q < SM::NSLOT; ++q) {
+          if (!on[q]) continue;
+          double cv = 0;
+#pragma unroll
+          for (int i = 0; i < NDX; ++i) cv += N[SM::OFF_RSH + q * NDX + i];
+          a_ += wg[q] * cv;
+        }
         N[SM::OFF_RED] += a_;
       }
       if (lane >= NDX) return;
-      for (int q = 0; q < SM::NSLOT && base + q < set.ncosts; ++q) {
-        const EMPC_K EmpcCost& c = set.costs[base + q];
-        if (!c.active || c.type != EMPC_COST_STATE) continue;
+#pragma unroll
+      for (int q = 0; q < SM::NSLOT; ++q) {
+        if (!on[q]) continue;
         const double* S = N + SM::OFF_CST + q * SM::SLOT;
-        const double* J6 = S + 3 * NDX;
+        const double* J6 = N + SM::OFF_CST + own[q] * SM::SLOT + 3 * NDX;
         if (lane < 6) {
           double g = 0;
 #pragma unroll
@@ -1213,7 +1224,7 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
   if (b == 0 && t == 10)
     ex.each([&](int lane, int sl) {
       if (lane == 0)
-        for (int i = 0; i < 10; ++i) D.dbg[32 + i] = lst[i];
+        for (int i = 0; i < 14; ++i) D.dbg[32 + i] = lst[i];
     });
 #endif
 }

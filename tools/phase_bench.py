@@ -44,5 +44,5 @@ empc.lib().empc_solver_debug_counters(s._h, cnt, 48)
 print('stage cycles (EMPC_STAMPS builds; rollout v1, trajectory 0, alpha 1/2): feedback|prep|rnea|crba|chol|kkt|euler|costs|-|tail', list(cnt)[:10])
 
 
-print('linearize stage cycles (unit b=0,t=10): S0 load|S1 squash/trig|S2 nominal+Euler|S3 tangent|S4 chol|S5 solves+Fx,Fu|S6 state costs|ctrl costs|frame costs|S7 store', list(cnt)[32:42])
+print('linearize stage cycles (unit b=0,t=10): S0 load|S1 squash/trig|S2 nominal+Euler|S3 tangent|S4 chol|S5 solves+Fx,Fu|S6 state costs (column sums)|ctrl costs|frame costs|S7 store|S6 staging|S6 nominal parts|S2 nominal chain only|S6 activations', list(cnt)[32:46])
 print('backward stage cycles (trajectory 0, EMPC_STAMPS builds): load|W|Q|gains|Vxx|sym|gap|looptop', list(cnt)[16:24])
