@@ -82,6 +82,12 @@ struct LaneExec {
     f(lane, 0);
   }
   EMPC_HD void sync() { wave_sync(); }
+  // workgroup barrier (role split of linearize)
+  EMPC_HD void block_sync() {
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+    __syncthreads();
+#endif
+  }
 };
 
 // =====================================================================================================================

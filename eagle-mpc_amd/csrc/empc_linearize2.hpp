@@ -425,8 +425,21 @@ EMPC_HD void lin2_frame_jcol(const EMPC_K EmpcModelDesc& m, const double* N, int
 // FR = false is the lean body for all other units -- the frame Jacobian / velocity-derivative columns (72 registers per
 // lane) do not exist in it.  The kernel is launched once per flavour; a unit returns at once from the wrong one
 // (flag bit 0 of costs[0].reserved, set by prepare_problem).
-template <class DM, bool CT, bool FR, class Exec>
-EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lpu, double* N) {
+// Role split (RW > 0, GPU only): the three single-lane sections of a unit -- nominal chain, Euler step with its Lie
+// Jacobians, state differences of the State costs -- run the same code for every unit of a workgroup (all units of a
+// block are trajectories of one knot: same cost set).  Instead of every wavefront running them one after the other on
+// one lane per unit, wavefront 0 runs the chain for ALL units of the block (lane = unit), wavefront 1 the Euler step,
+// wavefront 2 (or 1 when the block has two) the state differences, between two workgroup barriers.
+struct LinRole {
+  int tid;       // thread in the block
+  int upb;       // units per block
+  int usz;       // doubles of LDS per unit
+  int b0;        // trajectory of the block's unit 0
+  double* base;  // LDS of unit 0
+  bool active;   // this thread's unit has work (the threads of idle units still serve as role lanes)
+};
+template <class DM, bool CT, bool FR, class Exec, int RW = 0>
+EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lpu, double* N, const LinRole* RL = nullptr) {
   typedef Lin2Smem<DM> SM;
   constexpr int NB = DM::NB, NV = DM::NV, NQ = DM::NQ, NX = DM::NX, NDX = DM::NDX, NU = DM::NU, NROT = DM::NROT;
   constexpr int REC = DM::REC;
@@ -487,8 +500,137 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
   for (int i = 0; i < 16; ++i) lst[i] = 0;
   lst[15] = __builtin_readcyclecounter();
 #endif
+  // the three single-lane sections of a unit, as functions of the unit's LDS block (see LinRole)
+  auto chain_section = [&](double* Nu) {
+    lin2_nominal_chain<DM>(m, Nu, use_contact ? cbody : -1);
+    // nominal frame data
+#pragma unroll
+    for (int c = 0; c < NCAP; ++c) {
+      if (c >= ncap) continue;
+      const int f = capf[c];
+      const int bf = m.frame_body[f];
+      double Rb[9], pb[3], vb[6];
+#pragma unroll
+      for (int bb = 0; bb < NB; ++bb)
+        if (bb == bf) {
+          const double* Bb = Nu + SM::OFF_BODY + bb * SM::BODY;
+#pragma unroll
+          for (int i = 0; i < 9; ++i) Rb[i] = Bb[SM::B_RW + i];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) pb[i] = Bb[SM::B_PW + i];
+#pragma unroll
+          for (int i = 0; i < 6; ++i) vb[i] = Bb[SM::B_VB + i];
+        }
+      double* F = Nu + SM::OFF_FR + c * 18;
+      double Rf[9], Rp[3], wxr[3], tmp[3], fv[6];
+      matmul3<double>(Rb, m.frame_R[f], Rf);
+      matvec3<double>(Rb, m.frame_p[f], Rp);
+      cross3<double>(vb + 3, m.frame_p[f], wxr);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) tmp[i] = vb[i] + wxr[i];
+      matTvec3<double>(m.frame_R[f], tmp, fv);
+      matTvec3<double>(m.frame_R[f], vb + 3, fv + 3);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) F[i] = Rf[i];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) F[9 + i] = pb[i] + Rp[i];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) F[12 + i] = fv[i];
+    }
+  };
+  auto euler_section = [&](double* Nu, int bu, bool feasu) {
+    double x[NX], dxe[NDX], xnext[NX], pe[3], J2[36];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x[i] = Nu[SM::OFF_X + i];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const double ai = Nu[SM::OFF_A + i];
+      dxe[i] = x[NQ + i] * dt + ai * dt * dt;
+      dxe[NV + i] = ai * dt;
+    }
+    state_integrate<DM>(x, dxe, xnext, pe);
+    Jexp6(dxe, pe, J2);
+    double qe[4], pe2[3], Re[9], Px[9], RtP[9];
+    exp6_quat(dxe, qe, pe2);
+    quat_to_R(qe, Re);
+    skew3(pe2, Px);
+    matTmul3<double>(Re, Px, RtP);
+    // J1 = Ad(exp6(xi)^-1) = [[R^T, -R^T [p]x],[0, R^T]]
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        Nu[SM::OFF_J1 + r * 6 + c] = Re[3 * c + r];
+        Nu[SM::OFF_J1 + r * 6 + 3 + c] = -RtP[3 * r + c];
+        Nu[SM::OFF_J1 + (3 + r) * 6 + c] = 0.0;
+        Nu[SM::OFF_J1 + (3 + r) * 6 + 3 + c] = Re[3 * c + r];
+      }
+#pragma unroll
+    for (int i = 0; i < 36; ++i) Nu[SM::OFF_J2 + i] = J2[i];
+#pragma unroll
+    for (int i = 0; i < NDX; ++i) Nu[SM::OFF_DXE + i] = dxe[i];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) Nu[SM::OFF_XN + i] = xnext[i];
+    // gaps: fs[t+1] = xnext (-) xs[t+1];  fs[0] = x0 (-) xs[0]
+    if (!terminal) {
+      double gap[NDX];
+      if (!feasu) {
+        double xn[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xn[i] = Nu[SM::OFF_GAP + i];  // staged at S0
+        state_diff<DM>(xn, xnext, gap, nullptr);
+      }
+#pragma unroll
+      for (int i = 0; i < NDX; ++i) Nu[SM::OFF_GAP + i] = feasu ? 0.0 : gap[i];
+    }
+    if (t == 0) {
+      double gap[NDX];
+      if (!feasu) state_diff<DM>(x, D.x0 + (size_t)bu * NX, gap, nullptr);
+#pragma unroll
+      for (int i = 0; i < NDX; ++i) Nu[SM::OFF_GAP + NDX + i] = feasu ? 0.0 : gap[i];
+    }
+  };
+  // State cost q of group `base`: state difference and its log Jacobian, if the cost owns its reference (ref_share)
+  auto owner_section = [&](double* Nu, int base, int q) {
+    if (base + q >= set.ncosts) return;
+    const EMPC_K EmpcCost& c = set.costs[base + q];
+    if (!c.active || c.type != EMPC_COST_STATE || c.ref_share >= base) return;
+    double* S = Nu + SM::OFF_CST + q * SM::SLOT;
+    double xref[NX], dpl[3];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xref[i] = c.ref[i];
+    // residual and log Jacobian go straight to their LDS slot (r | Ar | Arr | J6 | value)
+    state_diff<DM>(xref, Nu + SM::OFF_X, S, dpl);
+    Jlog6(S, dpl, S + 3 * NDX);
+  };
+  // this thread's share of the role phase (RW > 0)
+  auto role_phase = [&]() {
+    if constexpr (RW > 0) {
+      const int wv = RL->tid / 64, wl = RL->tid % 64;
+      auto live = [&](int u) {
+        const int bu = RL->b0 + u;
+        if (u >= RL->upb || bu >= D.B) return false;
+        const TrajState& su = D.st[bu];
+        return su.phase != PHASE_DONE && su.need_lin != 0;
+      };
+      if (wv == 0) {
+        if (live(wl)) chain_section(RL->base + (size_t)wl * RL->usz);
+      } else if (wv == 1) {
+        if (live(wl)) euler_section(RL->base + (size_t)wl * RL->usz, RL->b0 + wl, D.st[RL->b0 + wl].is_feasible != 0);
+      }
+      if (wv == RW - 1) {
+        const int u = wl / SM::NSLOT, q = wl % SM::NSLOT;
+        if (live(u)) owner_section(RL->base + (size_t)u * RL->usz, 0, q);
+      }
+    }
+  };
+  // A unit without work (finished trajectory, b >= B) still lends its threads as role lanes.  The workgroup barriers
+  // must sit in wave-uniform control flow -- a wavefront holds two units, one of which may be idle -- so the idle unit
+  // skips the stages, not the barriers.
+  bool unit_on = true;
+  if constexpr (RW > 0) unit_on = RL->active;
   // ---- S0: load x, s, a ------------------------------------------------------------------------------------
-  ex.each([&](int lane, int sl) {
+  if (unit_on) ex.each([&](int lane, int sl) {
     const double* xg = D.xs + ((size_t)b * (T + 1) + t) * NX;
     const double* ag = D.acc + ((size_t)b * (T + 1) + t) * DM::NACC;
     const double* ug = D.us + ((size_t)b * T + (terminal ? 0 : t)) * NU;
@@ -506,7 +648,7 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
   ex.sync();
   LIN_STAMP(0);
   // ---- S1: squash (lanes < NU), joint sin/cos (next NJ lanes), base rotation (last lane) -------------------------
-  ex.each([&](int lane, int sl) {
+  if (unit_on) ex.each([&](int lane, int sl) {
     if (lane < NU) {
       double u = N[SM::OFF_S + lane], du = 1.0;
       if (P.use_squash) squash1(N[SM::OFF_S + lane], P.u_lb[lane], P.u_ub[lane], smooth, P.prm.smoothsat_power, u, du);
@@ -541,102 +683,22 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
   });
   ex.sync();
   LIN_STAMP(1);
-  // ---- S2: nominal chain (lane 0) || Euler step and its Lie Jacobians (lane 1) ----------------------------------
-  ex.each([&](int lane, int sl) {
-    if (lane == 0) {
-      lin2_nominal_chain<DM>(m, N, use_contact ? cbody : -1);
-      // nominal frame data
-#pragma unroll
-      for (int c = 0; c < NCAP; ++c) {
-        if (c >= ncap) continue;
-        const int f = capf[c];
-        const int bf = m.frame_body[f];
-        double Rb[9], pb[3], vb[6];
-#pragma unroll
-        for (int bb = 0; bb < NB; ++bb)
-          if (bb == bf) {
-            const double* Bb = N + SM::OFF_BODY + bb * SM::BODY;
-#pragma unroll
-            for (int i = 0; i < 9; ++i) Rb[i] = Bb[SM::B_RW + i];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) pb[i] = Bb[SM::B_PW + i];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) vb[i] = Bb[SM::B_VB + i];
-          }
-        double* F = N + SM::OFF_FR + c * 18;
-        double Rf[9], Rp[3], wxr[3], tmp[3], fv[6];
-        matmul3<double>(Rb, m.frame_R[f], Rf);
-        matvec3<double>(Rb, m.frame_p[f], Rp);
-        cross3<double>(vb + 3, m.frame_p[f], wxr);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) tmp[i] = vb[i] + wxr[i];
-        matTvec3<double>(m.frame_R[f], tmp, fv);
-        matTvec3<double>(m.frame_R[f], vb + 3, fv + 3);
-#pragma unroll
-        for (int i = 0; i < 9; ++i) F[i] = Rf[i];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) F[9 + i] = pb[i] + Rp[i];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) F[12 + i] = fv[i];
-      }
-    }
-  });
-  LIN_STAMP(12);
-  ex.each([&](int lane, int sl) {
-    if (lane == 1) {
-      double x[NX], dxe[NDX], xnext[NX], pe[3], J2[36];
-#pragma unroll
-      for (int i = 0; i < NX; ++i) x[i] = N[SM::OFF_X + i];
-#pragma unroll
-      for (int i = 0; i < NV; ++i) {
-        const double ai = N[SM::OFF_A + i];
-        dxe[i] = x[NQ + i] * dt + ai * dt * dt;
-        dxe[NV + i] = ai * dt;
-      }
-      state_integrate<DM>(x, dxe, xnext, pe);
-      Jexp6(dxe, pe, J2);
-      double qe[4], pe2[3], Re[9], Px[9], RtP[9];
-      exp6_quat(dxe, qe, pe2);
-      quat_to_R(qe, Re);
-      skew3(pe2, Px);
-      matTmul3<double>(Re, Px, RtP);
-      // J1 = Ad(exp6(xi)^-1) = [[R^T, -R^T [p]x],[0, R^T]]
-#pragma unroll
-      for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          N[SM::OFF_J1 + r * 6 + c] = Re[3 * c + r];
-          N[SM::OFF_J1 + r * 6 + 3 + c] = -RtP[3 * r + c];
-          N[SM::OFF_J1 + (3 + r) * 6 + c] = 0.0;
-          N[SM::OFF_J1 + (3 + r) * 6 + 3 + c] = Re[3 * c + r];
-        }
-#pragma unroll
-      for (int i = 0; i < 36; ++i) N[SM::OFF_J2 + i] = J2[i];
-#pragma unroll
-      for (int i = 0; i < NDX; ++i) N[SM::OFF_DXE + i] = dxe[i];
-#pragma unroll
-      for (int i = 0; i < NX; ++i) N[SM::OFF_XN + i] = xnext[i];
-      // gaps: fs[t+1] = xnext (-) xs[t+1];  fs[0] = x0 (-) xs[0]
-      if (!terminal) {
-        double gap[NDX];
-        if (!feas) {
-          double xn[NX];
-#pragma unroll
-          for (int i = 0; i < NX; ++i) xn[i] = N[SM::OFF_GAP + i];  // staged at S0
-          state_diff<DM>(xn, xnext, gap, nullptr);
-        }
-#pragma unroll
-        for (int i = 0; i < NDX; ++i) N[SM::OFF_GAP + i] = feas ? 0.0 : gap[i];
-      }
-      if (t == 0) {
-        double gap[NDX];
-        if (!feas) state_diff<DM>(x, D.x0 + (size_t)b * NX, gap, nullptr);
-#pragma unroll
-        for (int i = 0; i < NDX; ++i) N[SM::OFF_GAP + NDX + i] = feas ? 0.0 : gap[i];
-      }
-    }
-  });
-  ex.sync();
+  // ---- S2: nominal chain || Euler step and its Lie Jacobians (|| state differences of the first State-cost group) ----
+  if constexpr (RW > 0) {
+    ex.block_sync();
+    role_phase();
+    ex.block_sync();
+    if (!unit_on) return;
+  } else {
+    ex.each([&](int lane, int sl) {
+      if (lane == 0) chain_section(N);
+    });
+    LIN_STAMP(12);
+    ex.each([&](int lane, int sl) {
+      if (lane == 1) euler_section(N, b, feas);
+    });
+    ex.sync();
+  }
   LIN_STAMP(2);
   // ---- S3: tangent recursion; inertia columns to LDS ---------------------------------------------------------
   double dtau_l[Exec::SLOTS][NV];
@@ -902,18 +964,11 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
     }
     ex.sync();
     LIN_STAMP(10);
-    ex.each([&](int lane, int sl) {
-      if (lane >= SM::NSLOT || base + lane >= set.ncosts) return;
-      const EMPC_K EmpcCost& c = set.costs[base + lane];
-      if (!c.active || c.type != EMPC_COST_STATE || c.ref_share >= base) return;
-      double* S = N + SM::OFF_CST + lane * SM::SLOT;
-      double xref[NX], dpl[3];
-#pragma unroll
-      for (int i = 0; i < NX; ++i) xref[i] = c.ref[i];
-      // residual and log Jacobian go straight to their LDS slot (r | Ar | Arr | J6 | value)
-      state_diff<DM>(xref, N + SM::OFF_X, S, dpl);
-      Jlog6(S, dpl, S + 3 * NDX);
-    });
+    if (RW == 0 || base > 0) {  // the first group was done in the role phase
+      ex.each([&](int lane, int sl) {
+        if (lane < SM::NSLOT) owner_section(N, base, lane);
+      });
+    }
     ex.sync();
     LIN_STAMP(11);
     ex.each([&](int lane, int sl) {

@@ -73,16 +73,34 @@ k_linearize(DevBuffers D) {
   extern __shared__ double smem_lin[];
   constexpr int UPB = BLK / LPU;  // units per block
   constexpr int USZ = CT ? Lin2Smem<DM>::SIZE : Lin2Smem<DM>::SIZE_NC;
-  const int unit = blockIdx.x * UPB + threadIdx.x / LPU;
-  const int lane = threadIdx.x % LPU;
-  // this body's knots: the lean group or the rest of the sorted knot list
+#ifdef EMPC_LIN_NO_ROLES
+  constexpr int RW = 0;
+#else
+  constexpr int RW = (BLK / 64 >= 3) ? 3 : (BLK / 64 == 2 ? 2 : 0);  // wavefronts that share the single-lane sections
+#endif
+  // this body's knots: the lean group or the rest of the sorted knot list; a block holds UPB trajectories of ONE knot
   const int k0 = FR ? D.n_lean : 0, nk = FR ? (D.T + 1 - D.n_lean) : D.n_lean;
-  if (unit >= D.B * nk) return;
-  const int t = EMPC_KPTR(int, D.lin_knots)[k0 + unit / D.B], b = unit % D.B;
-  const TrajState& st = D.st[b];
-  if (st.phase == PHASE_DONE || !st.need_lin) return;
+  const int bpk = (D.B + UPB - 1) / UPB;
+  const int kn = blockIdx.x / bpk;
+  if (kn >= nk) return;
+  const int t = EMPC_KPTR(int, D.lin_knots)[k0 + kn];
+  const int b0 = (blockIdx.x % bpk) * UPB;
+  const int u = threadIdx.x / LPU, lane = threadIdx.x % LPU;
+  const int b = b0 + u;
+  bool active = b < D.B;
+  if (active) {
+    const TrajState& st = D.st[b];
+    active = !(st.phase == PHASE_DONE || !st.need_lin);
+  }
   LaneExec ex{lane};
-  linearize_unit2<DM, CT, FR>(ex, D, b, t, LPU, smem_lin + (size_t)(threadIdx.x / LPU) * USZ);
+  if constexpr (RW > 0) {
+    if (!__syncthreads_or(active ? 1 : 0)) return;  // nothing to do in the whole block
+    const LinRole R{(int)threadIdx.x, UPB, USZ, b0, smem_lin, active};
+    linearize_unit2<DM, CT, FR, LaneExec, RW>(ex, D, active ? b : b0, t, LPU, smem_lin + (size_t)u * USZ, &R);
+  } else {
+    if (!active) return;
+    linearize_unit2<DM, CT, FR>(ex, D, b, t, LPU, smem_lin + (size_t)u * USZ);
+  }
 }
 
 // workgroup-wide executor: barriers are real workgroup barriers
@@ -231,22 +249,23 @@ static void launch_linearize_blk(DevBuffers D, hipStream_t s) {
   }();
   (void)once;
   // lean body over the knots without operational frames, full body over the rest; every unit runs in exactly one of them
-  const int n_lean = D.B * D.n_lean, n_full = D.B * (D.T + 1 - D.n_lean);
-  if (n_lean > 0) hipLaunchKernelGGL((k_linearize<DM, CT, LPU, BLK, false>), dim3((n_lean + UPB - 1) / UPB), dim3(BLK), smem, s, D);
-  if (n_full > 0) hipLaunchKernelGGL((k_linearize<DM, CT, LPU, BLK, true>), dim3((n_full + UPB - 1) / UPB), dim3(BLK), smem, s, D);
+  const int bpk = (D.B + UPB - 1) / UPB;  // blocks per knot: a block never straddles two knots
+  const int n_lean = bpk * D.n_lean, n_full = bpk * (D.T + 1 - D.n_lean);
+  if (n_lean > 0) hipLaunchKernelGGL((k_linearize<DM, CT, LPU, BLK, false>), dim3(n_lean), dim3(BLK), smem, s, D);
+  if (n_full > 0) hipLaunchKernelGGL((k_linearize<DM, CT, LPU, BLK, true>), dim3(n_full), dim3(BLK), smem, s, D);
 }
 template <class DM, bool CT>
 static void launch_linearize(DevBuffers D, hipStream_t s) {
   static const int blk = [] {
     const char* e = getenv("EMPC_LIN_BLOCK");
-    return e ? atoi(e) : 128;
+    return e ? atoi(e) : 256;  // 4 wavefronts: chain | Euler step | state differences on their own wavefronts (LinRole)
   }();
   if (blk == 64)
     launch_linearize_blk<DM, CT, 64>(D, s);
-  else if (blk == 256)
-    launch_linearize_blk<DM, CT, 256>(D, s);
-  else
+  else if (blk == 128)
     launch_linearize_blk<DM, CT, 128>(D, s);
+  else
+    launch_linearize_blk<DM, CT, 256>(D, s);
 }
 template <class DM>
 static void launch_backward(DevBuffers D, hipStream_t s) {
