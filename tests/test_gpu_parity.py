@@ -251,3 +251,48 @@ def test_pack_results_device_and_rccl_gather():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", _PACK_SCRIPT, root], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "PACK_OK" in r.stdout, r.stderr[-2000:]
+
+
+_LIN_BLOCK_SCRIPT = r"""
+import hashlib, importlib, os, sys
+import numpy as np
+root = sys.argv[1]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+empc = importlib.import_module("eagle-mpc_amd")
+out = []
+for rel, dt in [("hexacopter370_flying_arm_3/trajectories/displacement.yaml", 80),
+                ("hexacopter370_flying_arm_3/trajectories/eagle_catch.yaml", 32)]:
+    traj = empc.Trajectory(); traj.autoSetup(empc.yaml_path(rel))
+    prob = traj.createProblem(dt, True, "IntegratedActionModelEuler")
+    d = prob.desc
+    B = 11                                     # not a multiple of the 8 units of a workgroup: idle units, idle wavefronts
+    rng = np.random.default_rng(3)
+    xs = np.zeros((B, d.T + 1, d.nx)); xs[..., :3] = rng.normal(size=(B, d.T + 1, 3)) * 0.3
+    q = np.array([0, 0, 0, 1.0]) + rng.normal(size=(B, d.T + 1, 4)) * 0.2
+    xs[..., 3:7] = q / np.linalg.norm(q, axis=-1, keepdims=True)
+    xs[..., 7:] = rng.normal(size=(B, d.T + 1, d.nx - 7)) * 0.3
+    us = rng.uniform(2, 6, size=(B, d.T, d.nu)); us[..., d.n_rotors:] = rng.normal(size=(B, d.T, d.nu - d.n_rotors)) * 0.2
+    s = empc.SolverSbFDDP(prob, batch=B)
+    tape = np.ascontiguousarray(s.linearize(xs, us, smooth=0.1, is_feasible=False, x0s=empc.perturbed_x0s(prob.x0, B, nq=d.model.nq)))
+    blocks = [np.ascontiguousarray(np.asarray(v)).tobytes() for b in range(B) for t in range(d.T + 1)
+              for k, v in sorted(s.tape_blocks(tape[b, t]).items())]
+    out.append(hashlib.sha256(b"".join(blocks)).hexdigest())
+print("TAPE", *out)
+"""
+
+
+def test_linearize_identical_across_workgroup_sizes():
+    """The role split of linearize (single-lane sections of all units of a workgroup on separate wavefronts,
+    empc_linearize2.hpp LinRole) moves work between wavefronts, never changes an operation: the tape of workgroups of
+    8 units (3 role wavefronts, default), 4 units (2) and 2 units (no split) must agree bit for bit, also with idle
+    units in the last workgroup.  EMPC_LIN_BLOCK is read once per process, hence the subprocesses."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for blk in ("256", "128", "64"):
+        env = dict(os.environ, EMPC_LIN_BLOCK=blk)
+        r = subprocess.run([sys.executable, "-c", _LIN_BLOCK_SCRIPT, root], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0 and "TAPE" in r.stdout, r.stderr[-2000:]
+        got[blk] = r.stdout.strip().splitlines()[-1]
+    assert got["256"] == got["128"] == got["64"], got
