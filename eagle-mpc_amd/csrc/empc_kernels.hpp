@@ -59,6 +59,13 @@ struct DevBuffers {
   int* try_ok;      // [B][NA]
   double* us_last;  // [B][T][NU]  control of the last IAM.calc at every node (fillSquashedOutputs semantics)
   int* n_active;    // [1]
+  // trajectories that linearize in this sweep, written by the previous sweep's select (compact, any order); nullptr =
+  // every trajectory.  linearize is the one throughput-bound kernel: with the list its time follows the number of
+  // trajectories still iterating instead of the number of workgroups that hold at least one of them.
+  const int* lin_list = nullptr;
+  const int* lin_count = nullptr;
+  int* lin_list_out = nullptr;   // the list select builds for the next sweep (nullptr = none)
+  int* lin_count_out = nullptr;
   unsigned long long* dbg;  // [64] cycle stamps of diagnostic builds (EMPC_STAMPS); unused otherwise
   int B, T, NA;
   double gaptol;    // feasibility tolerance actually used: max(th_gaptol, 1e-13)

@@ -434,7 +434,9 @@ struct LinRole {
   int tid;       // thread in the block
   int upb;       // units per block
   int usz;       // doubles of LDS per unit
-  int b0;        // trajectory of the block's unit 0
+  int b0;        // index of the block's unit 0 in the list of trajectories (DevBuffers::lin_list) or trajectory itself
+  int n;         // entries of that list (D.B without a list)
+  const int* list;
   double* base;  // LDS of unit 0
   bool active;   // this thread's unit has work (the threads of idle units still serve as role lanes)
 };
@@ -607,16 +609,16 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
   auto role_phase = [&]() {
     if constexpr (RW > 0) {
       const int wv = RL->tid / 64, wl = RL->tid % 64;
+      auto traj = [&](int u) { return RL->list ? RL->list[RL->b0 + u] : RL->b0 + u; };
       auto live = [&](int u) {
-        const int bu = RL->b0 + u;
-        if (u >= RL->upb || bu >= D.B) return false;
-        const TrajState& su = D.st[bu];
+        if (u >= RL->upb || RL->b0 + u >= RL->n) return false;
+        const TrajState& su = D.st[traj(u)];
         return su.phase != PHASE_DONE && su.need_lin != 0;
       };
       if (wv == 0) {
         if (live(wl)) chain_section(RL->base + (size_t)wl * RL->usz);
       } else if (wv == 1) {
-        if (live(wl)) euler_section(RL->base + (size_t)wl * RL->usz, RL->b0 + wl, D.st[RL->b0 + wl].is_feasible != 0);
+        if (live(wl)) euler_section(RL->base + (size_t)wl * RL->usz, traj(wl), D.st[traj(wl)].is_feasible != 0);
       }
       if (wv == RW - 1) {
         const int u = wl / SM::NSLOT, q = wl % SM::NSLOT;

@@ -84,10 +84,12 @@ k_linearize(DevBuffers D) {
   const int kn = blockIdx.x / bpk;
   if (kn >= nk) return;
   const int t = EMPC_KPTR(int, D.lin_knots)[k0 + kn];
-  const int b0 = (blockIdx.x % bpk) * UPB;
+  const int i0 = (blockIdx.x % bpk) * UPB;  // position in the list of trajectories that linearize in this sweep
+  const int nlist = D.lin_list ? *D.lin_count : D.B;
+  if (i0 >= nlist) return;
   const int u = threadIdx.x / LPU, lane = threadIdx.x % LPU;
-  const int b = b0 + u;
-  bool active = b < D.B;
+  bool active = i0 + u < nlist;
+  const int b = active ? (D.lin_list ? D.lin_list[i0 + u] : i0 + u) : (D.lin_list ? D.lin_list[i0] : i0);
   if (active) {
     const TrajState& st = D.st[b];
     active = !(st.phase == PHASE_DONE || !st.need_lin);
@@ -95,8 +97,8 @@ k_linearize(DevBuffers D) {
   LaneExec ex{lane};
   if constexpr (RW > 0) {
     if (!__syncthreads_or(active ? 1 : 0)) return;  // nothing to do in the whole block
-    const LinRole R{(int)threadIdx.x, UPB, USZ, b0, smem_lin, active};
-    linearize_unit2<DM, CT, FR, LaneExec, RW>(ex, D, active ? b : b0, t, LPU, smem_lin + (size_t)u * USZ, &R);
+    const LinRole R{(int)threadIdx.x, UPB, USZ, i0, nlist, D.lin_list, smem_lin, active};
+    linearize_unit2<DM, CT, FR, LaneExec, RW>(ex, D, b, t, LPU, smem_lin + (size_t)u * USZ, &R);
   } else {
     if (!active) return;
     linearize_unit2<DM, CT, FR>(ex, D, b, t, LPU, smem_lin + (size_t)u * USZ);
@@ -160,7 +162,10 @@ __global__ void __launch_bounds__(64) k_select(DevBuffers D) {
     select_decide<DM>(D, b, acc_ai, last_ai);
     sh[0] = acc_ai;
     sh[1] = last_ai;
-    if (D.st[b].phase != PHASE_DONE) atomicAdd(D.n_active, 1);
+    if (D.st[b].phase != PHASE_DONE) {
+      atomicAdd(D.n_active, 1);
+      if (D.lin_count_out && D.st[b].need_lin) D.lin_list_out[atomicAdd(D.lin_count_out, 1)] = b;
+    }
   }
   __syncthreads();
   select_copy<DM>(D, b, sh[0], sh[1], threadIdx.x, blockDim.x);
@@ -350,6 +355,7 @@ struct EmpcSolver {
   EmpcCostSet* dsets = nullptr;
   int* dknot = nullptr;
   int* dlin_knots = nullptr;
+  int* dlin_list = nullptr;  // [2][B] linearize lists of the two sweep slots
   double* dscratch = nullptr;  // output staging (squashed controls)
   double* dplant_x = nullptr;  // [B][NX] plant states of closed-loop runs (empc_plant_*)
   double* dplant_u = nullptr;  // [B][NU] staging of caller-supplied plant controls
@@ -506,7 +512,8 @@ EmpcSolver* empc_solver_create(const EmpcProblemDesc* problem, const EmpcSolverP
   D.try_dv = s->dalloc<double>(B * NA);
   D.try_ok = s->dalloc<int>(B * NA);
   D.us_last = s->dalloc<double>(B * T * k.nu);
-  D.n_active = s->dalloc<int>(2 * EmpcSolver::MAX_STREAMS);
+  D.n_active = s->dalloc<int>(4 * EmpcSolver::MAX_STREAMS);  // per chunk and sweep slot: {active trajectories, entries of the linearize list}
+  s->dlin_list = s->dalloc<int>(2 * (size_t)batch);          // per sweep slot: the linearize list of every chunk, chunk after chunk
   D.dbg = s->dalloc<unsigned long long>(64);
   HIP_CHECK(hipMemsetAsync(D.dbg, 0, 64 * sizeof(unsigned long long), s->stream));
   D.B = batch;
@@ -711,7 +718,7 @@ static DevBuffers chunk_view(const EmpcSolver* s, int b0, int nb, int idx) {
   D.try_dv += (size_t)b0 * NA;
   D.try_ok += (size_t)b0 * NA;
   D.us_last += (size_t)b0 * T * k.nu;
-  D.n_active = s->D.n_active + 2 * idx;
+  D.n_active = s->D.n_active + 4 * idx;
   D.B = nb;
   return D;
 }
@@ -759,8 +766,14 @@ int empc_solver_solve(EmpcSolver* s, int maxiter, int is_feasible) {
   auto enqueue = [&](Chunk& c) {
     const int q = queued[c.idx] & 1;
     DevBuffers Dq = c.D;
-    Dq.n_active = c.D.n_active + q;
-    HIP_CHECK(hipMemsetAsync(Dq.n_active, 0, sizeof(int), c.stream));
+    Dq.n_active = c.D.n_active + 2 * q;
+    Dq.lin_count_out = Dq.n_active + 1;
+    Dq.lin_list_out = s->dlin_list + (size_t)q * s->B + c.b0;
+    if (queued[c.idx] > 0) {  // the list written by the previous sweep's select; the first sweep takes every trajectory
+      Dq.lin_count = c.D.n_active + 2 * (1 - q) + 1;
+      Dq.lin_list = s->dlin_list + (size_t)(1 - q) * s->B + c.b0;
+    }
+    HIP_CHECK(hipMemsetAsync(Dq.n_active, 0, 2 * sizeof(int), c.stream));
     HIP_CHECK(hipEventRecord(c.ev[q][0], c.stream));
     k.calc(Dq, c.stream);
     HIP_CHECK(hipEventRecord(c.ev[q][1], c.stream));
