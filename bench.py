@@ -250,7 +250,13 @@ def main():
             n_par = int(min(8, n_sample))
             rp = ob.solve_batch(d, x0s[:n_par], args.maxiter, nthreads=min(cores, n_par), want_traj=True)
             gx, gu, gc, gi = solver.xs_batch[:n_par], solver.us_batch[:n_par], solver.cost_batch[:n_par], solver.iter_batch[:n_par]
-            out["parity"] = {"rollouts": n_par, "xs_max_abs_err": float(np.abs(gx - rp["xs"]).max()),
+            per_roll = np.maximum(np.abs(gx - rp["xs"]).reshape(n_par, -1).max(axis=1),
+                                  np.abs(gu - rp["us"]).reshape(n_par, -1).max(axis=1))
+            out["parity"] = {"rollouts": n_par, "rollouts_within_tolerance": int((per_roll < 1e-4).sum()),
+                             "unperturbed_rollout_max_abs_err": float(per_roll[0]),
+                             "note": "rollout 0 is the YAML initial state; the perturbed contact / hover problems are "
+                                     "ill-conditioned for the oracle too (DESIGN.md, parity at full batch size)",
+                             "xs_max_abs_err": float(np.abs(gx - rp["xs"]).max()),
                              "us_max_abs_err": float(np.abs(gu - rp["us"]).max()),
                              "cost_max_rel_err": float((np.abs(gc - rp["cost"]) / (1.0 + np.abs(rp["cost"]))).max()),
                              "iterations_equal": bool((gi == rp["iter"]).all()), "tolerance": 1e-4,
