@@ -68,7 +68,7 @@ template <class DM, bool CT, int LPU, int BLK, bool FR>
 #ifndef EMPC_LIN_WAVES
 #define EMPC_LIN_WAVES 2
 #endif
-__global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(EMPC_LIN_WAVES, EMPC_LIN_WAVES)))
+__global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(DM::NV > 9 ? 1 : EMPC_LIN_WAVES, DM::NV > 9 ? 1 : EMPC_LIN_WAVES)))
 k_linearize(DevBuffers D) {
   extern __shared__ double smem_lin[];
   constexpr int UPB = BLK / LPU;  // units per block
