@@ -231,9 +231,9 @@ def main():
                          "unit_definition": "(trajectory, step length, knot): one launch rolls out all %d step lengths of "
                                             "the line search" % solver.stats_na() if dom == "rollout" else "(trajectory, knot)",
                          "avg_launch_ms": avg_ms,
-                         "limiter": "not HBM: the kernel is bound by the FP64 vector issue of one wavefront per SIMD "
-                                    "(about 9.0k FP64 instructions per knot x 4 cycles = the measured cycles per knot; 10 of "
-                                    "64 lanes carry step lengths) -- DESIGN.md section 3.1, profiles/r01_rollout_ablation.txt"
+                         "limiter": "not HBM: the kernel is bound by the instruction stream of one wavefront per SIMD (4.6k vector "
+                                    "instructions per knot, vector unit busy 58 % of the wavefront's lifetime, 10 of 64 lanes carry "
+                                    "step lengths) -- DESIGN.md section 3.1, profiles/r01_pmc_sq_final.csv"
                          if dom == "rollout" else "latency / instruction bound, DESIGN.md section 3.1"},
             "iteration_roofline": {"algorithmic_bytes_per_traj_knot_iter": words["iteration"] * 8,
                                    "achieved_GBs": iters_total * d.T * words["iteration"] * 8 / elapsed / 1e9 / world,
