@@ -552,6 +552,7 @@ std::shared_ptr<ShootingProblem> Trajectory::createProblem(std::size_t dt, bool 
   if (dt == 0) throw std::runtime_error("dt must be positive");
   std::vector<EmpcCostSet> sets;
   std::vector<int> knot_set;
+  constexpr std::size_t kMaxKnots = 1u << 20;  // far above any horizon the device buffers are sized for
   bool last_duration0 = false;
   int terminal_set = -1;
   for (std::size_t si = 0; si < stages_.size(); ++si) {
@@ -563,10 +564,20 @@ std::shared_ptr<ShootingProblem> Trajectory::createProblem(std::size_t dt, bool 
       last_duration0 = true;
     } else {
       n_knots = stage->get_duration() / dt;
-      if (last_duration0) n_knots -= 1;  // size_t arithmetic, as in the reference
+      if (last_duration0) {
+        // The reference subtracts in size_t: with n_knots == 0 (a stage shorter than dt after a zero-knot stage) that
+        // wraps to SIZE_MAX and its std::vector(n_knots, iam) constructor throws length_error at once.  Fail the same
+        // way, before any allocation.
+        if (n_knots == 0)
+          throw std::length_error("createProblem: stage '" + stage->get_name() + "' is shorter than dt = " + std::to_string(dt) +
+                                  " ms and follows a zero-knot stage (cannot create std::vector larger than max_size())");
+        n_knots -= 1;
+      }
       last_duration0 = false;
     }
     terminal_set = (int)si;
+    if (knot_set.size() + n_knots > kMaxKnots)
+      throw std::length_error("createProblem: more than " + std::to_string(kMaxKnots) + " knots (duration / dt)");
     for (std::size_t k = 0; k < n_knots; ++k) knot_set.push_back((int)si);
   }
   knot_set.push_back(terminal_set);  // terminal model = the last stage's running model (:135)

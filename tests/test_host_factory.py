@@ -37,6 +37,17 @@ def test_knot_expansion(empc, problems):
     assert problems["hover"][0].createProblem(20, True, "IntegratedActionModelEuler").T == 100
 
 
+def test_dt_larger_than_a_stage_fails_at_once(empc, problems):
+    # a stage shorter than dt right after a zero-knot stage made `n_knots -= 1` wrap around in size_t and the
+    # knot table grow until the host ran out of memory.  The reference fails at once in its std::vector constructor
+    # (src/trajectory.cpp:120-131); so must this.
+    t = problems["eagle_catch"][0]
+    with pytest.raises(empc.EmpcError, match="shorter than dt"):
+        t.createProblem(5000, True, "IntegratedActionModelEuler")
+    # a dt that only collapses stages to single knots is still fine
+    assert t.createProblem(200, True, "IntegratedActionModelEuler").T > 0
+
+
 def test_dimensions_and_flags(problems):
     d = problems["displacement"][1].desc
     assert (d.nx, d.ndx, d.nu, d.n_rotors, d.has_contact) == (19, 18, 9, 6, 0)

@@ -1,0 +1,151 @@
+#!/usr/bin/env python3
+"""Oracle-vs-oracle' sensitivity study (CPU only; test infrastructure, never part of the product path).
+
+Question: when the GPU solver and the oracle disagree on a perturbed eagle_catch / hover rollout,
+is that a defect of the GPU path or the conditioning of the algorithm on that problem?  This tool answers it without a
+GPU: it solves the SAME batch of perturbed rollouts with variants of the oracle that differ only in rounding --
+
+  base   oracle/liboracle.so as shipped (g++ -O3 -ffp-contract=off)
+  fma    the same sources built with -ffp-contract=fast (x86 FMA contraction, i.e. "another correct compiler")
+  ulp    base library, every component of x0 moved to the adjacent double (random direction, quaternion renormalised)
+
+-- and reports, per pair, how many rollouts end with the same iteration count and within 1e-4 on xs/us (the north-star
+tolerance), next to the committed GPU-vs-oracle figures.  If base-vs-fma and base-vs-ulp disagree as often as
+GPU-vs-base, the disagreement is a property of the problem, not of the device code.
+
+Usage: python tools/oracle_sensitivity.py [--batch 256] [--configs eagle_catch,hover,displacement] [--out profiles/r02_oracle_sensitivity.json]
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import empc_loader  # noqa: E402
+import oracle_binding as ob  # noqa: E402
+
+empc = empc_loader.load()
+T = empc.T
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+CONFIGS = {"displacement": ("hexacopter370_flying_arm_3/trajectories/displacement.yaml", 80),
+           "eagle_catch": ("hexacopter370_flying_arm_3/trajectories/eagle_catch.yaml", 32),
+           "hover": ("hexacopter370/trajectories/hover.yaml", 40),
+           "push_slide": ("hextilt_flying_arm_5/trajectories/push_slide.yaml", 13)}
+VARIANT_DIR = os.path.join(ROOT, "oracle", "_variants")  # git-ignored build products
+BASE_FLAGS = "-O3 -march=x86-64-v3 -fPIC -std=c++17 -fopenmp -Wall -Wno-unused-variable -Wno-unused-but-set-variable".split()
+
+
+def build_variant(name, extra):
+    os.makedirs(VARIANT_DIR, exist_ok=True)
+    out = os.path.join(VARIANT_DIR, "liboracle_%s.so" % name)
+    src = os.path.join(ROOT, "oracle", "oracle_api.cpp")
+    deps = [os.path.join(ROOT, "oracle", f) for f in os.listdir(os.path.join(ROOT, "oracle")) if f.endswith((".hpp", ".cpp"))]
+    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+        subprocess.check_call(["g++"] + BASE_FLAGS + extra + ["-shared", "-o", out, src])
+    L = C.CDLL(out)
+    L.oracle_solve_batch.restype = C.c_double
+    L.oracle_solve_batch.argtypes = [C.POINTER(T.ProblemDesc), C.POINTER(T.SolverParams), C.c_int, _dp, C.c_int, C.c_int,
+                                     _dp, _dp, _dp, _dp, _ip, _ip]
+    return L
+
+
+def solve_with(L, desc, prm, x0s, maxiter, nthreads):
+    x0s = np.ascontiguousarray(x0s, dtype=np.float64)
+    B = x0s.shape[0]
+    xs = np.zeros((B, desc.T + 1, desc.nx))
+    us = np.zeros((B, desc.T, desc.nu))
+    usq = np.zeros((B, desc.T, desc.nu))
+    cost = np.zeros(B)
+    iters = np.zeros(B, dtype=np.int32)
+    status = np.zeros(B, dtype=np.int32)
+    p = lambda a: a.ctypes.data_as(_dp)
+    L.oracle_solve_batch(C.byref(desc), C.byref(prm), B, p(x0s), int(maxiter), int(nthreads), p(xs), p(us), p(usq), p(cost),
+                         iters.ctypes.data_as(_ip), status.ctypes.data_as(_ip))
+    return dict(xs=xs, us=us, cost=cost, iter=iters, status=status)
+
+
+def solved(r):
+    return ((r["status"] & 1) != 0) & ((r["status"] & (2 | 4)) == 0) & np.isfinite(r["cost"]) & (np.abs(r["cost"]) < 1e6)
+
+
+def compare(a, b, tol=1e-4):
+    B = a["iter"].shape[0]
+    same = a["iter"] == b["iter"]
+    ex = np.abs(a["xs"] - b["xs"]).reshape(B, -1).max(axis=1)
+    eu = np.abs(a["us"] - b["us"]).reshape(B, -1).max(axis=1)
+    ec = np.abs(a["cost"] - b["cost"]) / (1 + np.abs(a["cost"]))
+    ok = same & (ex < tol) & (eu < tol)
+    sa, sb = solved(a), solved(b)
+    both = sa & sb
+    q = lambda v, m: [float(x) for x in np.quantile(v[m], [0.5, 0.9, 1.0])] if m.any() else None
+    return {"rollouts": int(B), "iterations_equal": int(same.sum()), "within_1e-4_and_iterations_equal": int(ok.sum()),
+            "solved_by_a": int(sa.sum()), "solved_by_both": int(both.sum()),
+            "solved_by_a_and_within_tolerance": int((sa & ok).sum()),
+            "solved_by_both_other_iteration_count": int((both & ~same).sum()),
+            "xs_err_q50_q90_max_where_iterations_differ_both_solved": q(ex, both & ~same),
+            "cost_rel_err_q50_q90_max_where_iterations_differ_both_solved": q(ec, both & ~same),
+            "xs_err_q50_q90_max_where_iterations_equal": q(ex, same),
+            "cost_rel_err_q50_q90_max_solved_by_both": q(ec, both)}
+
+
+def nudge_ulp(x0s, seed=7):
+    rng = np.random.default_rng(seed)
+    out = x0s.copy()
+    up = rng.integers(0, 2, size=out.shape).astype(bool)
+    out = np.where(up, np.nextafter(out, np.inf), np.nextafter(out, -np.inf))
+    out[:, 3:7] /= np.linalg.norm(out[:, 3:7], axis=1, keepdims=True)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--configs", default="eagle_catch,hover,displacement")
+    ap.add_argument("--maxiter", type=int, default=100)
+    ap.add_argument("--threads", type=int, default=os.cpu_count() or 1)
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02_oracle_sensitivity.json"))
+    args = ap.parse_args()
+    ob.build_oracle()
+    base = build_variant("base", ["-ffp-contract=off"])
+    fma = build_variant("fma", ["-ffp-contract=fast"])
+    res = {"note": "CPU oracle against rounding-only variants of itself on identical perturbed rollouts "
+                   "(benchmark/utils/utils.hpp:15-27 recipe, seed as in bench.py); tolerance 1e-4 on xs/us",
+           "variants": {"base": "g++ -O3 -march=x86-64-v3 -ffp-contract=off (the shipped oracle)",
+                        "fma": "same sources, -ffp-contract=fast (FMA contraction)",
+                        "ulp": "base library, each component of x0 moved to the adjacent double",
+                        "gaptol13": "base library with th_gaptol = 1e-13 (the device's feasibility tolerance)"}}
+    for name in args.configs.split(","):
+        rel, dt = CONFIGS[name]
+        tr = empc.Trajectory()
+        tr.autoSetup(empc.yaml_path(rel))
+        pb = tr.createProblem(dt, True, "IntegratedActionModelEuler")
+        d = pb.desc
+        x0s = empc.perturbed_x0s(pb.x0, args.batch, nq=d.model.nq)
+        prm = ob.default_params()
+        prm13 = ob.default_params()
+        prm13.th_gaptol = 1e-13
+        t0 = time.time()
+        r_base = solve_with(base, d, prm, x0s, args.maxiter, args.threads)
+        r_g13 = solve_with(base, d, prm13, x0s, args.maxiter, args.threads)
+        r_fma = solve_with(fma, d, prm13, x0s, args.maxiter, args.threads)  # FMA breaks diff(x, x) == 0 exactly: needs the 1e-13 gap tolerance
+        r_ulp = solve_with(base, d, prm, nudge_ulp(x0s), args.maxiter, args.threads)
+        res[name] = {"knots": d.T, "iteration_range_base": [int(r_base["iter"].min()), int(r_base["iter"].max())],
+                     "mean_iterations_base": float(r_base["iter"].mean() + 1),
+                     "base_vs_gaptol13": compare(r_base, r_g13), "base_vs_fma": compare(r_base, r_fma),
+                     "base_vs_ulp": compare(r_base, r_ulp), "seconds": round(time.time() - t0, 1)}
+        print(name, json.dumps(res[name], indent=1), flush=True)
+    with open(args.out, "w") as f:
+        json.dump(res, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
