@@ -16,7 +16,7 @@ from . import ctypes_defs as T
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, "libempc.so")
-YAML_DIR = os.path.join(os.path.dirname(_PKG_DIR), "tests", "golden", "yaml")
+YAML_DIR = os.path.join(_PKG_DIR, "data", "yaml")  # the problem files the reference ships under yaml/ (unchanged: configuration data)
 ROBOT_DIR = os.path.join(_PKG_DIR, "data", "robots")
 
 _dp = C.POINTER(C.c_double)
@@ -81,6 +81,8 @@ def lib():
     L.empc_solver_get_status.argtypes = [C.c_void_p, _ip]
     L.empc_solver_pack_results_device.argtypes = [C.c_void_p, C.c_void_p, _ip]
     L.empc_solver_get_stats.argtypes = [C.c_void_p, C.POINTER(T.SolveStats)]
+    L.empc_solver_enable_trace.argtypes = [C.c_void_p, C.c_int]
+    L.empc_solver_get_trace.argtypes = [C.c_void_p, C.c_int, _dp, C.c_int, _ip]
     L.empc_solver_dims.argtypes = [C.c_void_p] + [_ip] * 6
     L.empc_tape_layout.argtypes = [C.c_void_p, C.POINTER(T.TapeLayout)]
     L.empc_linearize_batch.argtypes = [C.c_void_p, _dp, _dp, C.c_double, C.c_int, _dp, _dp, _dp]
@@ -390,6 +392,25 @@ class SolverSbFDDP:
         n = C.c_int()
         _check(lib().empc_solver_pack_results_device(self._h, C.c_void_p(device_ptr) if device_ptr else None, C.byref(n)))
         return n.value
+
+    # -- per-iteration trace (the reference's callback hook: setCallbacks, src/sbfddp.cpp:303-307) -----------------
+    TRACE_FIELDS = ("phase", "iter", "cost", "stop", "xreg", "steplength", "feasible", "dV", "dVexp", "gapnorm", "d0", "d1")
+
+    def enable_trace(self, capacity=512):
+        """Record {phase, iter, cost, stop, xreg, steplength, feasible, dV, dVexp, gapnorm, d0, d1} of every iteration of
+        every trajectory in a device ring of `capacity` records each (0 = off); read it with ``trace(b)``."""
+        _check(lib().empc_solver_enable_trace(self._h, int(capacity)))
+        self._trace_cap = int(capacity)
+
+    def trace(self, b=0):
+        """Iteration records of trajectory b from the last solve, oldest first: array (n, 12), columns TRACE_FIELDS."""
+        n = C.c_int()
+        _check(lib().empc_solver_get_trace(self._h, int(b), None, 0, C.byref(n)))
+        k = min(n.value, getattr(self, "_trace_cap", 0))
+        out = np.zeros((k, len(self.TRACE_FIELDS)))
+        if k:
+            _check(lib().empc_solver_get_trace(self._h, int(b), _ptr(out), k, C.byref(n)))
+        return out
 
     def stats_na(self):
         """step lengths tried per line search (SolverParams.n_alphas of this solver)"""

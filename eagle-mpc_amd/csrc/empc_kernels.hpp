@@ -27,7 +27,7 @@ struct TrajState {
   int iter, total_iters, status;
   int is_feasible, was_feasible;
   int need_calc, need_lin;
-  int maxiter, bwd_failed, reserved0, last_ok;
+  int maxiter, bwd_failed, trace_count, last_ok;  // trace_count: iteration records written in this solve
   double smooth, smooth_next, convergence, th_stop;
   double xreg, ureg, cost, cost_prev, stop, steplength, dV, dVexp, d0, d1;
   double dg_u, dq_u;      // sum Qu.k , -sum k.Quuk          (control part)
@@ -67,6 +67,10 @@ struct DevBuffers {
   int* lin_list_out = nullptr;   // the list select builds for the next sweep (nullptr = none)
   int* lin_count_out = nullptr;
   unsigned long long* dbg;  // [64] cycle stamps of diagnostic builds (EMPC_STAMPS); unused otherwise
+  // optional per-iteration record (the reference's callback hook, src/sbfddp.cpp:303-307,381-385): ring of trace_cap
+  // records of EMPC_TRACE_WORDS doubles per trajectory, written by select; nullptr = off
+  double* trace = nullptr;  // [B][trace_cap][EMPC_TRACE_WORDS]
+  int trace_cap = 0;
   int B, T, NA;
   double gaptol;    // feasibility tolerance actually used: max(th_gaptol, 1e-13)
 };
@@ -521,6 +525,23 @@ EMPC_HD void select_decide(const DevBuffers& D, int b, int& accepted_ai, int& la
         st.stop = fabs(st.d0 + 0.5 * st.d1);
       else
         st.stop = st.qu2;
+      if (D.trace) {
+        // what a crocoddyl callback sees at this point of solveFDDP / solveDDP (same fields as oracle::IterRecord)
+        double* r = D.trace + ((size_t)b * D.trace_cap + (st.trace_count % D.trace_cap)) * EMPC_TRACE_WORDS;
+        r[0] = (double)st.phase;
+        r[1] = (double)st.iter;
+        r[2] = st.cost;
+        r[3] = st.stop;
+        r[4] = st.xreg;
+        r[5] = st.steplength;
+        r[6] = st.is_feasible ? 1.0 : 0.0;
+        r[7] = st.dV;
+        r[8] = st.dVexp;
+        r[9] = st.gapnorm;
+        r[10] = st.d0;
+        r[11] = st.d1;
+        st.trace_count += 1;
+      }
       const bool stop_now = ddp ? (st.was_feasible && st.stop < st.th_stop)
                                 : (st.stop < st.th_stop && st.gapnorm < prm.th_stop_gaps);
       if (stop_now) {

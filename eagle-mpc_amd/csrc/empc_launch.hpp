@@ -1,0 +1,365 @@
+// empc_launch.hpp -- the HIP kernels (gfx950), their launchers and the per-robot kernel table.
+//
+// Every (bodies, rotors, contact) combination is instantiated in its own translation unit (empc_inst_*.hip) so that the
+// instantiations compile in parallel; empc_solver.hip (host driver + C ABI) only sees the table accessors declared
+// below.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../include/empc.h"
+#include "empc_internal.hpp"
+#include "empc_prep.hpp"
+#ifdef EMPC_INSTANTIATE  // kernel bodies are only needed where a table is instantiated
+#include "empc_linearize2.hpp"
+#include "empc_backward2.hpp"
+#include "empc_backward3.hpp"
+#endif
+
+using namespace empc;
+
+// launchers of one (bodies, rotors, contact) instantiation
+struct KernelTable {
+  void (*calc)(DevBuffers, hipStream_t);
+  void (*linearize)(DevBuffers, hipStream_t);
+  void (*backward)(DevBuffers, hipStream_t);
+  void (*rollout)(DevBuffers, hipStream_t);
+  void (*select)(DevBuffers, hipStream_t);
+  void (*squash_out)(DevBuffers, double*, hipStream_t);
+  void (*pack_rows)(DevBuffers, double*, hipStream_t);
+  void (*plant)(DevBuffers, double*, const double*, double, int, hipStream_t);
+  int nx, ndx, nu, nv, nacc, rec;
+  int off[9], ld[5];
+};
+
+
+// (bodies, rotors) = (1,4) iris | (1,6) hexacopter370 / hextilt | (3,6) hexacopter680_flying_arm_2 |
+// (4,6) hexacopter370_flying_arm_3, free and contact dynamics | (6,6) hextilt_flying_arm_5
+KernelTable empc_table_1_4();
+KernelTable empc_table_1_6();
+KernelTable empc_table_3_6();
+KernelTable empc_table_4_6();
+KernelTable empc_table_4_6_contact();
+KernelTable empc_table_6_6();
+
+#ifdef EMPC_INSTANTIATE
+// --------------------------------------------------------------------------------------------------------------------
+// kernels
+// --------------------------------------------------------------------------------------------------------------------
+template <class DM, bool CT>
+__global__ void __launch_bounds__(64) k_calc(DevBuffers D) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = D.B * (D.T + 1);
+  if (idx >= n) return;
+  // consecutive lanes = consecutive trajectories of the same node (same cost set -> no divergence)
+  const int t = idx / D.B, b = idx % D.B;
+  calc_thread<DM, CT>(D, b, t);
+}
+
+template <class DM, bool CT>
+__global__ void __launch_bounds__(64) k_rollout(DevBuffers D) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= D.B * D.NA) return;
+  const int b = idx / D.NA, ai = idx % D.NA;
+  rollout_thread<DM, CT>(D, b, ai);
+}
+
+// the shipped rollout: one wavefront per trajectory, lanes = step lengths, feedback product by the whole wave
+template <class DM, bool CT>
+__global__ void __launch_bounds__(64) k_rollout5(DevBuffers D) {
+  extern __shared__ double smem_roll5[];
+  static_assert(DM::NU <= 64, "feedback rows must fit one wavefront");
+  LaneExec ex{(int)threadIdx.x};
+  rollout_wave5<DM, CT>(ex, D, blockIdx.x, 64, smem_roll5);
+}
+
+template <class DM, bool CT, int LPU, int BLK, bool FR>
+// Two wavefronts per SIMD: at the compiler's own choice (326 registers, one wavefront per SIMD) the kernel sits at
+// ~1 resident wave per SIMD with 37 % of its time in waits; capping the budget at 256 registers costs ~250 spilled
+// values but doubles the resident waves: 2.02 -> 1.42 ms per launch (profiles/README.md).
+#ifndef EMPC_LIN_WAVES
+#define EMPC_LIN_WAVES 2
+#endif
+__global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(DM::NV > 9 ? 1 : EMPC_LIN_WAVES, DM::NV > 9 ? 1 : EMPC_LIN_WAVES)))
+k_linearize(DevBuffers D) {
+  extern __shared__ double smem_lin[];
+  constexpr int UPB = BLK / LPU;  // units per block
+  constexpr int USZ = CT ? Lin2Smem<DM>::SIZE : Lin2Smem<DM>::SIZE_NC;
+#ifdef EMPC_LIN_NO_ROLES
+  constexpr int RW = 0;
+#else
+  constexpr int RW = (BLK / 64 >= 3) ? 3 : (BLK / 64 == 2 ? 2 : 0);  // wavefronts that share the single-lane sections
+#endif
+  // this body's knots: the lean group or the rest of the sorted knot list; a block holds UPB trajectories of ONE knot
+  const int k0 = FR ? D.n_lean : 0, nk = FR ? (D.T + 1 - D.n_lean) : D.n_lean;
+  const int bpk = (D.B + UPB - 1) / UPB;
+  const int kn = blockIdx.x / bpk;
+  if (kn >= nk) return;
+  const int t = EMPC_KPTR(int, D.lin_knots)[k0 + kn];
+  const int i0 = (blockIdx.x % bpk) * UPB;  // position in the list of trajectories that linearize in this sweep
+  const int nlist = D.lin_list ? *D.lin_count : D.B;
+  if (i0 >= nlist) return;
+  const int u = threadIdx.x / LPU, lane = threadIdx.x % LPU;
+  bool active = i0 + u < nlist;
+  const int b = active ? (D.lin_list ? D.lin_list[i0 + u] : i0 + u) : (D.lin_list ? D.lin_list[i0] : i0);
+  if (active) {
+    const TrajState& st = D.st[b];
+    active = !(st.phase == PHASE_DONE || !st.need_lin);
+  }
+  LaneExec ex{lane};
+  if constexpr (RW > 0) {
+    if (!__syncthreads_or(active ? 1 : 0)) return;  // nothing to do in the whole block
+    const LinRole R{(int)threadIdx.x, UPB, USZ, i0, nlist, D.lin_list, smem_lin, active};
+    linearize_unit2<DM, CT, FR, LaneExec, RW>(ex, D, b, t, LPU, smem_lin + (size_t)u * USZ, &R);
+  } else {
+    if (!active) return;
+    linearize_unit2<DM, CT, FR>(ex, D, b, t, LPU, smem_lin + (size_t)u * USZ);
+  }
+}
+
+// workgroup-wide executor: barriers are real workgroup barriers
+struct BlockExec {
+  int lane;
+  static constexpr int SLOTS = 1;
+  template <class F>
+  __device__ __forceinline__ void each(F&& f) {
+    __builtin_amdgcn_sched_barrier(0);  // keep the scheduler from interleaving stages (register pressure)
+    f(lane, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __device__ __forceinline__ void sync() {
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  template <class F>
+  __device__ __forceinline__ bool any(F&& f) {
+    return __syncthreads_or(f(lane, 0) ? 1 : 0) != 0;
+  }
+  // one v_mfma_f64_16x16x4_f64 of the wavefront: acc[im][in] += A-operand a[ia] x B-operand b[ib] (per-lane values)
+  template <class A, class B, class C>
+  __device__ __forceinline__ void mfma(A& a, int ia, B& b, int ib, C& c, int im, int in) {
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    d4 v = {c[0][im][in][0], c[0][im][in][1], c[0][im][in][2], c[0][im][in][3]};
+    v = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][ia], b[0][ib], v, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c[0][im][in][r] = v[r];
+  }
+};
+
+#ifndef EMPC_BWD_NL
+#define EMPC_BWD_NL 64
+#endif
+template <class DM>
+__global__ void __launch_bounds__(EMPC_BWD_NL) k_backward(DevBuffers D) {
+  extern __shared__ double smem_bwd[];
+  const int b = blockIdx.x;
+  BlockExec ex{(int)threadIdx.x};
+  backward_traj2<DM, EMPC_BWD_NL>(ex, D, b, smem_bwd);
+}
+
+// matrix-core form of the backward pass (one wavefront per trajectory)
+template <class DM>
+__global__ void __launch_bounds__(64) k_backward3(DevBuffers D) {
+  extern __shared__ double smem_bwd3[];
+  BlockExec ex{(int)threadIdx.x};
+  backward_traj3<DM>(ex, D, blockIdx.x, smem_bwd3);
+}
+
+template <class DM>
+__global__ void __launch_bounds__(64) k_select(DevBuffers D) {
+  __shared__ int sh[2];
+  const int b = blockIdx.x;
+  if (threadIdx.x == 0) {
+    int acc_ai, last_ai;
+    select_decide<DM>(D, b, acc_ai, last_ai);
+    sh[0] = acc_ai;
+    sh[1] = last_ai;
+    if (D.st[b].phase != PHASE_DONE) {
+      atomicAdd(D.n_active, 1);
+      if (D.lin_count_out && D.st[b].need_lin) D.lin_list_out[atomicAdd(D.lin_count_out, 1)] = b;
+    }
+  }
+  __syncthreads();
+  select_copy<DM>(D, b, sh[0], sh[1], threadIdx.x, blockDim.x);
+}
+
+// us_squash[b][t] = sigma(us_last[b][t]) with the trajectory's final smooth (fillSquashedOutputs, src/sbfddp.cpp:479-486)
+template <class DM>
+__global__ void k_squash_out(DevBuffers D, double* out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = D.B * D.T * DM::NU;
+  if (idx >= n) return;
+  const int b = idx / (D.T * DM::NU), i = idx % DM::NU;
+  const EMPC_K DevProblem& P = EMPC_KREF(DevProblem, D.P);
+  double u = D.us_last[idx], du;
+  if (P.use_squash) squash1(D.us_last[idx], P.u_lb[i], P.u_ub[i], D.st[b].smooth, P.prm.smoothsat_power, u, du);
+  out[idx] = u;
+}
+
+// One row per rollout: xs | us_squash | cost | iters (as double) -- the payload of the multi-GPU result gather, packed
+// entirely on the device (costs and iteration counts come from the device-resident TrajState, not from the host copy).
+template <class DM>
+__global__ void k_pack_rows(DevBuffers D, double* out) {
+  const size_t nxs = (size_t)(D.T + 1) * DM::NX, nus = (size_t)D.T * DM::NU, row = nxs + nus + 2;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)D.B * row) return;
+  const int b = (int)(idx / row);
+  const size_t j = idx % row;
+  const EMPC_K DevProblem& P = EMPC_KREF(DevProblem, D.P);
+  double v;
+  if (j < nxs) {
+    v = D.xs[(size_t)b * nxs + j];
+  } else if (j < nxs + nus) {
+    const size_t k = j - nxs;
+    const int i = (int)(k % DM::NU);
+    double du;
+    v = D.us_last[(size_t)b * nus + k];
+    if (P.use_squash) squash1(D.us_last[(size_t)b * nus + k], P.u_lb[i], P.u_ub[i], D.st[b].smooth, P.prm.smoothsat_power, v, du);
+  } else {
+    v = (j == nxs + nus) ? D.st[b].cost : (double)D.st[b].iter;
+  }
+  out[idx] = v;
+}
+
+// Plant of the closed-loop MPC runs: x[b] <- RK4(x[b], u[b], dt) repeated nsub times, one lane per plant.
+// u == nullptr takes the squashed first control of the last solve (control = solver.us_squash[0], examples/python/mpc.py:60).
+template <class DM>
+__global__ void __launch_bounds__(64) k_plant_rk4(DevBuffers D, double* x, const double* u, double dt, int nsub) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= D.B) return;
+  const EMPC_K DevProblem& P = EMPC_KREF(DevProblem, D.P);
+  double uu[DM::NU], xa[DM::NX], xb[DM::NX];
+#pragma unroll
+  for (int i = 0; i < DM::NU; ++i) {
+    if (u) {
+      uu[i] = u[(size_t)b * DM::NU + i];
+    } else {
+      const double s = D.us_last[(size_t)b * D.T * DM::NU + i];
+      double du;
+      uu[i] = s;
+      if (P.use_squash) squash1(s, P.u_lb[i], P.u_ub[i], D.st[b].smooth, P.prm.smoothsat_power, uu[i], du);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < DM::NX; ++i) xa[i] = x[(size_t)b * DM::NX + i];
+  for (int k = 0; k < nsub; ++k) {
+    plant_rk4_step<DM>(P, xa, uu, dt, xb);
+#pragma unroll
+    for (int i = 0; i < DM::NX; ++i) xa[i] = xb[i];
+  }
+#pragma unroll
+  for (int i = 0; i < DM::NX; ++i) x[(size_t)b * DM::NX + i] = xa[i];
+}
+
+template <class DM, bool CT>
+static void launch_calc(DevBuffers D, hipStream_t s) {
+  const int n = D.B * (D.T + 1);
+  hipLaunchKernelGGL((k_calc<DM, CT>), dim3((n + 63) / 64), dim3(64), 0, s, D);
+}
+template <class DM, bool CT, int BLK>
+static void launch_linearize_blk(DevBuffers D, hipStream_t s) {
+  constexpr int LPU = (3 * DM::NV <= 32) ? 32 : 64;
+  constexpr int UPB = BLK / LPU;
+  constexpr int USZ = CT ? Lin2Smem<DM>::SIZE : Lin2Smem<DM>::SIZE_NC;
+  const int n = D.B * (D.T + 1);
+  const size_t smem = sizeof(double) * USZ * UPB;
+  static const bool once = [&] {
+    if (getenv("EMPC_DEBUG_OCC")) {
+      int nb = -1;
+      hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)k_linearize<DM, CT, LPU, BLK, false>, BLK, smem);
+      hipFuncAttributes fa;
+      hipError_t e2 = hipFuncGetAttributes(&fa, (const void*)k_linearize<DM, CT, LPU, BLK, false>);
+      fprintf(stderr, "[empc] k_linearize BLK=%d dyn smem=%zu B: max active blocks/CU=%d (%s); regs=%d static smem=%zu local=%zu (%s)\n", BLK,
+              smem, nb, hipGetErrorString(e), fa.numRegs, fa.sharedSizeBytes, fa.localSizeBytes, hipGetErrorString(e2));
+    }
+    return true;
+  }();
+  (void)once;
+  // lean body over the knots without operational frames, full body over the rest; every unit runs in exactly one of them
+  const int bpk = (D.B + UPB - 1) / UPB;  // blocks per knot: a block never straddles two knots
+  const int n_lean = bpk * D.n_lean, n_full = bpk * (D.T + 1 - D.n_lean);
+  if (n_lean > 0) hipLaunchKernelGGL((k_linearize<DM, CT, LPU, BLK, false>), dim3(n_lean), dim3(BLK), smem, s, D);
+  if (n_full > 0) hipLaunchKernelGGL((k_linearize<DM, CT, LPU, BLK, true>), dim3(n_full), dim3(BLK), smem, s, D);
+}
+template <class DM, bool CT>
+static void launch_linearize(DevBuffers D, hipStream_t s) {
+  static const int blk = [] {
+    const char* e = getenv("EMPC_LIN_BLOCK");
+    return e ? atoi(e) : 256;  // 4 wavefronts: chain | Euler step | state differences on their own wavefronts (LinRole)
+  }();
+  if (blk == 64)
+    launch_linearize_blk<DM, CT, 64>(D, s);
+  else if (blk == 128)
+    launch_linearize_blk<DM, CT, 128>(D, s);
+  else
+    launch_linearize_blk<DM, CT, 256>(D, s);
+}
+template <class DM>
+static void launch_backward(DevBuffers D, hipStream_t s) {
+  static const int version = [] {
+    const char* e = getenv("EMPC_BACKWARD");  // 2 = vector form, 3 = matrix-core form
+    return e ? atoi(e) : 3;
+  }();
+  if (version == 2)
+    hipLaunchKernelGGL(k_backward<DM>, dim3(D.B), dim3(EMPC_BWD_NL), sizeof(double) * Bwd2Smem<DM>::SIZE, s, D);
+  else
+    hipLaunchKernelGGL(k_backward3<DM>, dim3(D.B), dim3(64), sizeof(double) * Bwd3Smem<DM>::SIZE, s, D);
+}
+template <class DM, bool CT>
+static void launch_rollout(DevBuffers D, hipStream_t s) {
+  const int n = D.B * D.NA;
+  static const int version = [] {
+    const char* e = getenv("EMPC_ROLLOUT");  // 1 = per-lane form (also the fallback for more than MAX_ALPHAS step lengths)
+    return e ? atoi(e) : 5;
+  }();
+  if (version == 1 || D.NA > MAX_ALPHAS) {
+    hipLaunchKernelGGL((k_rollout<DM, CT>), dim3((n + 63) / 64), dim3(64), 0, s, D);
+  } else {
+    hipLaunchKernelGGL((k_rollout5<DM, CT>), dim3(D.B), dim3(64), sizeof(double) * Roll5Smem<DM>::SIZE, s, D);
+  }
+}
+template <class DM>
+static void launch_select(DevBuffers D, hipStream_t s) {
+  hipLaunchKernelGGL(k_select<DM>, dim3(D.B), dim3(64), 0, s, D);
+}
+template <class DM>
+static void launch_squash_out(DevBuffers D, double* out, hipStream_t s) {
+  const int n = D.B * D.T * DM::NU;
+  hipLaunchKernelGGL(k_squash_out<DM>, dim3((n + 255) / 256), dim3(256), 0, s, D, out);
+}
+template <class DM>
+static void launch_pack_rows(DevBuffers D, double* out, hipStream_t s) {
+  const size_t n = (size_t)D.B * ((size_t)(D.T + 1) * DM::NX + (size_t)D.T * DM::NU + 2);
+  hipLaunchKernelGGL(k_pack_rows<DM>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, D, out);
+}
+template <class DM>
+static void launch_plant(DevBuffers D, double* x, const double* u, double dt, int nsub, hipStream_t s) {
+  hipLaunchKernelGGL(k_plant_rk4<DM>, dim3((D.B + 63) / 64), dim3(64), 0, s, D, x, u, dt, nsub);
+}
+template <class DM, bool CT>
+static KernelTable make_table() {
+  KernelTable k;
+  k.calc = launch_calc<DM, CT>;
+  k.linearize = launch_linearize<DM, CT>;
+  k.backward = launch_backward<DM>;
+  k.rollout = launch_rollout<DM, CT>;
+  k.select = launch_select<DM>;
+  k.squash_out = launch_squash_out<DM>;
+  k.pack_rows = launch_pack_rows<DM>;
+  k.plant = launch_plant<DM>;
+  k.nx = DM::NX;
+  k.ndx = DM::NDX;
+  k.nu = DM::NU;
+  k.nv = DM::NV;
+  k.nacc = DM::NACC;
+  k.rec = DM::REC;
+  const int off[9] = {DM::OFF_FX, DM::OFF_FU, DM::OFF_LXX, DM::OFF_LXU, DM::OFF_LUU, DM::OFF_LX, DM::OFF_LU, DM::OFF_GAP, DM::OFF_COST};
+  std::memcpy(k.off, off, sizeof(off));
+  const int ld[5] = {DM::NM, DM::NM, DM::NM, DM::NM, DM::NU};  // Fx, Fu, Lxx, Lxu, Luu leading dimensions
+  std::memcpy(k.ld, ld, sizeof(ld));
+  return k;
+}
+#endif  // EMPC_INSTANTIATE

@@ -7,7 +7,7 @@
 
 int main(int argc, char** argv) {
   const std::string root = argc > 1 ? argv[1] : ".";
-  eagle_mpc::set_yaml_dir(root + "/tests/golden/yaml");
+  eagle_mpc::set_yaml_dir(root + "/eagle-mpc_amd/data/yaml");
   eagle_mpc::set_robot_data_dir(root + "/eagle-mpc_amd/data/robots");
   try {
     auto trajectory = eagle_mpc::Trajectory::create();

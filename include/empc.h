@@ -106,6 +106,15 @@ int empc_solver_get_status(EmpcSolver* s, int* status /* batch: EMPC_STATUS_* bi
  * multi-GPU gather; dst_device == NULL only returns the row length in doubles */
 int empc_solver_pack_results_device(EmpcSolver* s, double* dst_device /* batch x row, device memory */, int* row_doubles);
 
+/* Per-iteration trace: the record a crocoddyl callback would see each iteration (reference: setCallbacks +
+ * src/sbfddp.cpp:303-307, 381-385; src/mpc-base.cpp:52-57 installs CallbackVerbose when the YAML asks for it).
+ * enable_trace allocates a device ring of `capacity` records per trajectory (0 switches it off); it is filled by
+ * every later solve.  get_trace copies trajectory b's records of the last solve, oldest first:
+ * records x EMPC_TRACE_WORDS doubles (layout: include/empc_types.h), at most max_records; *n_records = records
+ * written by the solve (may exceed the ring's capacity, then only the newest `capacity` are available). */
+int empc_solver_enable_trace(EmpcSolver* s, int capacity);
+int empc_solver_get_trace(EmpcSolver* s, int b, double* records, int max_records, int* n_records);
+
 /* timing / accounting of the last solve (device time measured with HIP events on the solver's stream) */
 typedef struct EmpcSolveStats {
   int sweeps;                 /* host-side sweeps (one sweep = one pass of the kernel sequence)             */

@@ -171,6 +171,13 @@ typedef struct EmpcSolverParams {
 #define EMPC_STATUS_MAXITER 4     /* an inner loop ran out of iterations              */
 #define EMPC_STATUS_DDP_CLEANUP 8 /* solveDDP ran because the FDDP result was infeasible */
 
+/* One record of the per-iteration trace (empc_solver_enable_trace / empc_solver_get_trace): what a
+ * crocoddyl::CallbackAbstract sees after stoppingCriteria() in solveFDDP / solveDDP
+ * (reference src/sbfddp.cpp:303-307, 381-385).  EMPC_TRACE_WORDS doubles per record:
+ *   0 phase (0,1,.. = FDDP pass; 100 = DDP clean-up)  1 iter  2 cost  3 stop  4 xreg  5 steplength
+ *   6 is_feasible  7 dV  8 dVexp  9 gap norm  10 d0  11 d1                                          */
+#define EMPC_TRACE_WORDS 12
+
 #ifdef __cplusplus
 }
 #endif

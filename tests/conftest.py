@@ -13,7 +13,7 @@ def pytest_configure(config):
 
 
 CONFIGS = {
-    # name: (yaml relative to tests/golden/yaml, dt in ms)  -- BASELINE.json configs 1-4
+    # name: (yaml relative to eagle-mpc_amd/data/yaml, dt in ms)  -- BASELINE.json configs 1-4
     "hover": ("hexacopter370/trajectories/hover.yaml", 40),
     "displacement": ("hexacopter370_flying_arm_3/trajectories/displacement.yaml", 80),
     "eagle_catch": ("hexacopter370_flying_arm_3/trajectories/eagle_catch.yaml", 32),

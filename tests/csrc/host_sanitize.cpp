@@ -25,7 +25,7 @@ int empc_solver_get_status(EmpcSolver*, int*) { return -1; }
 using namespace eagle_mpc;
 int main(int argc, char** argv) {
   const std::string root = argc > 1 ? argv[1] : ".";
-  set_yaml_dir(root + "/tests/golden/yaml");
+  set_yaml_dir(root + "/eagle-mpc_amd/data/yaml");
   set_robot_data_dir(root + "/eagle-mpc_amd/data/robots");
   const char* files[] = {"hexacopter370/trajectories/hover.yaml", "hexacopter370_flying_arm_3/trajectories/displacement.yaml",
                          "hexacopter370_flying_arm_3/trajectories/eagle_catch.yaml", "hextilt_flying_arm_5/trajectories/push_slide.yaml"};

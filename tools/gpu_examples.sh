@@ -1,5 +1,7 @@
 # GPU box: run the examples and the bench line with its parity block
-cd $GRAFT_REPO_ROOT
+set -uo pipefail  # no -e: every step reports, a failing step does not hide the later ones
+ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)}"
+cd "$ROOT"
 python3 examples/python/trajectory.py 2>&1 | tail -3
 python3 examples/python/mpc.py 2>&1 | tail -2
 ./examples/cpp/trajectory . 2>&1 | tail -2

@@ -1,8 +1,10 @@
 set -x
-cd $GRAFT_REPO_ROOT
+set -euo pipefail
+ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)}"
+cd "$ROOT"
 export TMPDIR=/tmp
-O=$GRAFT_REPO_ROOT/gpurun_out/prof_final
-rm -rf $O; mkdir -p $O
+O="$ROOT/gpurun_out/prof_final"
+rm -rf "$O"; mkdir -p "$O"
 python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > $O/bench.json 2> $O/bench.err
 tail -c 3000 $O/bench.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.err
