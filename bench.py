@@ -1,15 +1,21 @@
 #!/usr/bin/env python3
 """bench.py -- DDP iterations/s of the batched Squash-box FDDP solver on MI355X.
 
-Workload (BASELINE.json configs[1]): hexacopter370_flying_arm_3 `displacement.yaml`, dt = 80 ms -> 100 knots,
-batch 1024 rollouts per GPU from perturbed initial states (recipe of benchmark/utils/utils.hpp:15-27), empty
-initial guess, SolverSbFDDP.solve(maxiter = 100).  One "step" = one full batched solve from scratch.
+Default workload (the north-star target of BASELINE.json): hexacopter370_flying_arm_3 `eagle_catch.yaml` (contact
+dynamics), dt = 32 ms -> 100 nodes, batch 1024 rollouts per GPU from perturbed initial states (recipe of
+benchmark/utils/utils.hpp:15-27), empty initial guess, SolverSbFDDP.solve(maxiter = 100).  One "step" = one full batched
+solve from scratch.  `--config displacement` is BASELINE.json configs[1] (the round-1 default); at N = 1 a short run of it
+is appended to the same JSON line under "secondary".  configs[2] (eagle_catch, 4096 rollouts over 8 GPUs) is
+`python bench.py --gpus 8 --batch 512`.
 
 metric/value: batched DDP iterations per second = (sum over trajectories of DDP iterations executed) / batch / time,
-i.e. trajectory-iterations/s divided by 1024; with N GPUs every rank solves its own 1024 rollouts (weak scaling) and
+i.e. trajectory-iterations/s divided by the per-GPU batch; with N GPUs every rank solves its own batch (weak scaling) and
 `value` is the whole-job aggregate.  The only collective is the gather of results to rank 0 (RCCL).
 
-Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--config displacement|eagle_catch|hover|push_slide]
+`python bench.py --gpus N` starts itself: the parent spawns N worker processes (one per GPU, torch.distributed.run on
+127.0.0.1) BEFORE it touches torch or the HIP library, relays rank 0's JSON line and exits with the workers' code.
+
+Usage: python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--config eagle_catch|displacement|hover|push_slide|*_mpc]
 """
 import argparse
 import json
@@ -50,13 +56,138 @@ def algorithmic_words(nx, ndx, nu):
                 iteration=a_in + a_out + b_in + b_out + c_in + c_out)
 
 
+def host_threads():
+    """Threads for the all-core CPU baseline: the physical cores this process may run on (SMT siblings counted once,
+    CPU affinity and the cgroup quota respected) -- more threads than that only slow the FP64 oracle down."""
+    try:
+        allowed = os.sched_getaffinity(0)
+    except AttributeError:
+        allowed = set(range(os.cpu_count() or 1))
+    cores, cur = set(), {}
+    try:
+        for line in open("/proc/cpuinfo"):
+            if ":" in line:
+                k, v = [x.strip() for x in line.split(":", 1)]
+                cur[k] = v
+            elif cur:
+                if int(cur.get("processor", -1)) in allowed:
+                    cores.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor"))))
+                cur = {}
+        if cur and int(cur.get("processor", -1)) in allowed:
+            cores.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor"))))
+    except OSError:
+        pass
+    n = len(cores) or len(allowed)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def secondary_displacement(empc, B, maxiter, device):
+    """BASELINE.json configs[1] (the round-1 headline) measured in the same process: 1 warm-up + 3 timed solves."""
+    import torch
+    rel, dt = CONFIGS["displacement"]
+    traj = empc.Trajectory()
+    traj.autoSetup(empc.yaml_path(rel))
+    problem = traj.createProblem(dt, True, "IntegratedActionModelEuler")
+    d = problem.desc
+    x0s = empc.perturbed_x0s(problem.x0, B, nq=d.model.nq)
+    solver = empc.SolverSbFDDP(problem, batch=B, device=device)
+    solver.solve([], [], maxiter, x0s=x0s)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    agg, steps = {}, 3
+    for _ in range(steps):
+        solver.solve([], [], maxiter, x0s=x0s)
+        for k, v in solver.stats().items():
+            agg[k] = agg.get(k, 0) + v
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    return {"workload": "%s dt=%dms T=%d batch=%d (BASELINE configs[1])" % (rel, dt, d.T, B),
+            "value": agg["total_iters"] / B / el, "ms_per_step": el / steps * 1e3, "steps": steps,
+            "sweeps_per_solve": agg["sweeps"] / steps,
+            "kernel_ms_per_launch": {k: agg["ms_" + k] / max(agg["n_" + k], 1) for k in ("linearize", "backward", "rollout")}}
+
+
+def cpu_baseline_and_parity(empc, solver, d, x0s, B, maxiter, unit):
+    """Rank 0, N = 1, after the timed region: the oracle (CPU restatement, `kind: port`) on the host cores of this box as
+    the reported CPU baseline, and -- on the same oracle results -- the parity block of the north star.  The oracle is the
+    checker / baseline here, never part of what was measured above."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding as ob
+    import parity_criteria as pc
+    threads = host_threads()
+    # all-core leg: a bounded sample of the batch (whole batch on a box with >= 64 cores), OpenMP over rollouts
+    n_sample = int(min(B, max(64, threads * 16)))
+    ref = ob.solve_batch(d, x0s[:n_sample], maxiter, nthreads=threads, want_traj=True)
+    cpu_iters = float((ref["iter"] + 1).sum())
+    # single-thread leg (how the reference itself runs): three rollouts, one at a time, us per DDP iteration
+    us_per_it, it_single, t_single = [], 0.0, 0.0
+    for b in range(min(3, n_sample)):
+        r1 = ob.solve_batch(d, x0s[b:b + 1], maxiter, nthreads=1, want_traj=False)
+        n_it = float(r1["iter"][0] + 1)
+        us_per_it.append(r1["seconds"] * 1e6 / n_it)
+        it_single += n_it
+        t_single += r1["seconds"]
+    us_per_it = np.array(us_per_it)
+    out = {"cpu_baseline": {
+        "value": cpu_iters / B / ref["seconds"], "unit": unit, "cores": threads, "kind": "port",
+        "sample": "%d of the %d rollouts of rank 0 (mean %.1f iterations each), OpenMP over rollouts on %d threads = physical "
+                  "cores available to the process; oracle/liboracle.so (FP64 C++ restatement of the Crocoddyl/Pinocchio "
+                  "arithmetic, not the reference binary: it cannot be built here)" % (n_sample, B, cpu_iters / n_sample, threads),
+        "cpu_model": cpu_model(), "logical_cpus": os.cpu_count(),
+        "trajectory_iters_per_s": cpu_iters / ref["seconds"], "seconds": ref["seconds"],
+        "single_thread": {"trajectory_iters_per_s": it_single / t_single, "rollouts": int(len(us_per_it)),
+                          "us_per_iteration": {"AVG": float(us_per_it.mean()), "STDDEV": float(us_per_it.std()),
+                                               "MAX": float(us_per_it.max()), "MIN": float(us_per_it.min())},
+                          "format": "benchmark/mpc-main-carrot-timings.cpp:42-55 (Avg. time per iteration)"}}}
+    # parity: one more (untimed) solve of the same batch with the iteration trace on -- the solver is deterministic
+    solver.enable_trace(3 * maxiter + 20)
+    solver.solve([], [], maxiter, x0s=x0s)
+    gpu = dict(xs=solver.xs_batch[:n_sample], us=solver.us_batch[:n_sample], cost=solver.cost_batch[:n_sample],
+               iter=solver.iter_batch[:n_sample], status=solver.status_batch[:n_sample])
+    stats = pc.batch_statistics(gpu, ref)
+    sample = sorted(set(int(i) for i in np.linspace(0, n_sample - 1, 8)))
+    prm = empc.default_params()
+    smp = pc.sample_checks(ob, d, x0s, gpu, {b: solver.trace(b) for b in sample}, sample,
+                           final_smooth=prm.smooth_init * prm.smooth_mult, th_stop=prm.convergence_stop, maxiter=maxiter)
+    solver.enable_trace(0)
+    per_roll = np.maximum(np.abs(gpu["xs"] - ref["xs"]).reshape(n_sample, -1).max(axis=1),
+                          np.abs(gpu["us"] - ref["us"]).reshape(n_sample, -1).max(axis=1))
+    out["parity"] = {"reference": "oracle/liboracle.so (CPU restatement; parity unpinned, DESIGN.md)", "tolerance": 1e-4,
+                     "rollouts_compared": n_sample,
+                     "unperturbed_rollout_max_abs_err": float(per_roll[0]),
+                     "unperturbed_rollout_iterations_equal": bool(gpu["iter"][0] == ref["iter"][0]),
+                     "batch": stats, "sample_checks": smp, "criteria": pc.verdict(stats, smp),
+                     "criterion": "tests/parity_criteria.py (A early path, B agreement rate >= %.2f of the oracle-solved, "
+                                  "C median cost error <= 1e-6, D same problem, E stationarity); oracle-vs-oracle' baseline: "
+                                  "profiles/r02_oracle_sensitivity.json" % pc.AGREEMENT_MIN}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=None, help="rollouts per GPU (default 1024; 256 for the *_mpc configs)")
-    ap.add_argument("--config", default="displacement", choices=sorted(CONFIGS))
+    ap.add_argument("--config", default="eagle_catch", choices=sorted(CONFIGS))
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short displacement run appended at N = 1")
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-launched workers (0 = pick a free one)")
     ap.add_argument("--maxiter", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -68,8 +199,23 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Self-launch: N fresh worker processes, one per GPU, started as CHILDREN before this process has imported torch
+        # or loaded libempc.so (no exec: under rocprofv3 the parent already holds the GPU).  Rank 0 prints the JSON line
+        # straight to the inherited stdout.
+        import socket
+        import subprocess
+        port = args.master_port
+        if not port:
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+            sk.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this driver
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
     import torch
     import empc_loader
@@ -194,14 +340,20 @@ def main():
         bytes_per_launch = units / max(nlaunch, 1) * words[dom] * 8.0
         avg_ms = ms / max(nlaunch, 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # HBM bytes per launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE, tools/run_profiles.sh) of this very
+        # workload, averaged over the launches of a solve like `achieved`; null when no such measurement is committed
         traffic = None
-        prof = os.path.join(ROOT, "profiles", "traffic_%s.json" % dom)
-        # the committed PMC measurement belongs to the default workload only
-        if os.path.exists(prof) and args.config == "displacement" and B == 1024:
+        for prof in (os.path.join(ROOT, "profiles", "traffic_%s_%s.json" % (args.config, dom)),
+                     os.path.join(ROOT, "profiles", "traffic_%s.json" % dom)):
+            if not os.path.exists(prof) or B != 1024:
+                continue
             try:
-                traffic = json.load(open(prof)).get("hbm_bytes_per_launch")
+                j = json.load(open(prof))
             except Exception:
-                traffic = None
+                continue
+            if j.get("config", "displacement") == args.config:
+                traffic = j.get("hbm_bytes_per_launch")
+                break
         out = {
             "metric": "DDP iters/sec (batch=%d per GPU, %d knots)" % (B, d.T),
             "value": value,
@@ -227,6 +379,7 @@ def main():
             "kernel_ms_per_solve": {k: kern[k][0] / args.steps for k in kern},
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "achieved_from_counter_bytes_GBs": (traffic / (avg_ms * 1e-3) / 1e9) if (traffic and avg_ms > 0) else None,
                          "algorithmic_bytes_per_unit": words[dom] * 8, "units_per_launch": units / max(nlaunch, 1),
                          "unit_definition": "(trajectory, step length, knot): one launch rolls out all %d step lengths of "
                                             "the line search" % solver.stats_na() if dom == "rollout" else "(trajectory, knot)",
@@ -242,33 +395,10 @@ def main():
         if is_mpc:
             out["mpc_cycles_per_s"] = args.steps * MPC_CYCLES_PER_STEP / elapsed
             out["plant_controller_cycles_per_s"] = args.steps * MPC_CYCLES_PER_STEP * B * world / elapsed
+        if world == 1 and not is_mpc and not args.no_secondary and args.config != "displacement":
+            out["secondary"] = secondary_displacement(empc, B, args.maxiter, local_dev)
         if not args.no_cpu_baseline and not is_mpc and world == 1:  # rank 0 at N = 1 only
-            sys.path.insert(0, os.path.join(ROOT, "tests"))
-            import oracle_binding as ob  # the oracle timed as the CPU baseline ("port"), never part of the product path
-            cores = os.cpu_count() or 1
-            n_sample = int(min(B, max(cores * 4, 8)))
-            r = ob.solve_batch(d, x0s[:n_sample], args.maxiter, nthreads=cores, want_traj=False)
-            cpu_iters = float((r["iter"] + 1).sum())
-            # north-star parity figure: max-abs error of the GPU trajectories against the CPU oracle on identical inputs
-            # (a few rollouts of the same batch; the oracle here is the checker, never the thing measured)
-            n_par = int(min(8, n_sample))
-            rp = ob.solve_batch(d, x0s[:n_par], args.maxiter, nthreads=min(cores, n_par), want_traj=True)
-            gx, gu, gc, gi = solver.xs_batch[:n_par], solver.us_batch[:n_par], solver.cost_batch[:n_par], solver.iter_batch[:n_par]
-            per_roll = np.maximum(np.abs(gx - rp["xs"]).reshape(n_par, -1).max(axis=1),
-                                  np.abs(gu - rp["us"]).reshape(n_par, -1).max(axis=1))
-            out["parity"] = {"rollouts": n_par, "rollouts_within_tolerance": int((per_roll < 1e-4).sum()),
-                             "unperturbed_rollout_max_abs_err": float(per_roll[0]),
-                             "note": "rollout 0 is the YAML initial state; the perturbed contact / hover problems are "
-                                     "ill-conditioned for the oracle too (DESIGN.md, parity at full batch size)",
-                             "xs_max_abs_err": float(np.abs(gx - rp["xs"]).max()),
-                             "us_max_abs_err": float(np.abs(gu - rp["us"]).max()),
-                             "cost_max_rel_err": float((np.abs(gc - rp["cost"]) / (1.0 + np.abs(rp["cost"]))).max()),
-                             "iterations_equal": bool((gi == rp["iter"]).all()), "tolerance": 1e-4,
-                             "reference": "oracle/liboracle.so (CPU restatement; parity unpinned, DESIGN.md)"}
-            out["cpu_baseline"] = {"value": cpu_iters / B / r["seconds"], "unit": out["unit"], "cores": cores, "kind": "port",
-                                   "sample": "%d of the %d rollouts of rank 0, OpenMP over rollouts, oracle/liboracle.so "
-                                             "(FP64 C++ restatement, not Crocoddyl)" % (n_sample, B),
-                                   "trajectory_iters_per_s": cpu_iters / r["seconds"], "seconds": r["seconds"]}
+            out.update(cpu_baseline_and_parity(empc, solver, d, x0s, B, args.maxiter, out["unit"]))
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

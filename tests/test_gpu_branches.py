@@ -1,0 +1,159 @@
+"""GPU parity tests of the branches round 1 left without a direct test:
+
+  * the DDP clean-up pass: forwardPassDDP (gap-free rollout), expectedImprovementDDP, and whole solves that provably go
+    through solveDDP (EMPC_STATUS_DDP_CLEANUP asserted on both sides)           -- reference src/sbfddp.cpp:317-460
+  * every non-default value of the option block that selects among the fork-only behaviours:
+    stop_criteria, gap_norm, terminal_dt_scaling, smoothsat_power                -- src/sbfddp.cpp:27-31,301,309,379,387
+  * the per-iteration trace (the callback hook, src/sbfddp.cpp:303-307,381-385) against the oracle's IterRecord
+
+All through the C ABI (ctypes), oracle = checker.  FP64; tolerances stated per test.
+"""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from test_gpu_parity import random_candidate, rel
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["displacement", "eagle_catch"])
+def test_phase_parity_ddp_rollout(empc, problems, name):
+    """forwardPassDDP(alpha): the rollout kernel in its gap-free form (xs_try[0] = x0, no gap contraction, no dv term)
+    and expectedImprovementDDP (d0 = sum Qu.k, d1 = -sum k.Quu k) against the oracle, on random candidates."""
+    _, problem = problems[name]
+    d = problem.desc
+    B = 3
+    xs, us = random_candidate(d, B, seed=23)
+    x0s = empc.perturbed_x0s(problem.x0, B, nq=d.model.nq, seed=9)
+    solver = empc.SolverSbFDDP(problem, batch=B)
+    solver.linearize(xs, us, smooth=0.1, is_feasible=False, x0s=x0s, fetch=False)
+    # solveDDP runs its backward pass with the gaps still in Vx (is_feasible = false on entry) but sums only the control
+    # terms into d0 / d1: take those from a backward pass flagged feasible = no gap terms in dg / dq
+    K, k, Vx, dgdq_inf, ok = solver.backward(xreg=1e-9, is_feasible=False)
+    assert ok.all()
+    for alpha in (0.25, 0.0625):
+        xt, ut, ct, okr = solver.rollout(alpha, ddp=True, is_feasible=False)
+        for b in range(B):
+            o = ob.OracleSolver(d)
+            o.set_x0(x0s[b])
+            o.set_smooth(0.1)
+            o.phase_calcdiff(xs[b], us[b])
+            o.phase_backward(1e-9)
+            oko, xo, uo, co, d01 = o.phase_forward(alpha, ddp=True)
+            assert bool(okr[b]) == oko
+            if oko and np.isfinite(co) and abs(co) < 1e12:
+                assert np.abs(xt[b, 0] - x0s[b]).max() == 0.0  # the DDP rollout starts at x0 itself
+                assert rel(xt[b], xo) < 1e-6 and rel(ut[b], uo) < 1e-6, (name, alpha, b)
+                assert abs(ct[b] - co) < 1e-6 * (1 + abs(co))
+    # expectedImprovementDDP: control terms only
+    solver.linearize(xs, us, smooth=0.1, is_feasible=False, x0s=x0s, fetch=False)
+    _, _, _, dgdq_feas, _ = solver.backward(xreg=1e-9, is_feasible=True)
+    for b in range(B):
+        o = ob.OracleSolver(d)
+        o.set_x0(x0s[b])
+        o.set_smooth(0.1)
+        o.phase_calcdiff(xs[b], us[b], is_feasible=True, was_feasible=True)
+        o.phase_backward(1e-9)
+        _, _, _, _, d01 = o.phase_forward(0.25, ddp=True)
+        assert np.allclose(dgdq_feas[b], d01, rtol=1e-6), (dgdq_feas[b], d01)
+
+
+@pytest.mark.parametrize("name,maxiter", [("displacement", 1), ("displacement", 2), ("eagle_catch", 2), ("hover", 3)])
+def test_solve_goes_through_ddp_cleanup(empc, problems, name, maxiter):
+    """Solves that end their FDDP passes infeasible and therefore run solveDDP (src/sbfddp.cpp:215-218): with one or two
+    iterations per pass no full step has closed the gaps yet.  Both sides must report EMPC_STATUS_DDP_CLEANUP, the same
+    iteration counts and the same trajectories (few iterations: 1e-7 absolute)."""
+    _, problem = problems[name]
+    d = problem.desc
+    B = 8
+    x0s = empc.perturbed_x0s(problem.x0, B, nq=d.model.nq)
+    solver = empc.SolverSbFDDP(problem, batch=B)
+    solver.enable_trace(64)
+    solver.solve([], [], maxiter, x0s=x0s)
+    ref = ob.solve_batch(d, x0s, maxiter, nthreads=4)
+    cleanup = (ref["status"] & empc.T.STATUS_DDP_CLEANUP) != 0
+    assert cleanup.sum() >= B // 2, "test input no longer reaches the clean-up pass"
+    assert np.array_equal(solver.status_batch, ref["status"]), (solver.status_batch, ref["status"])
+    assert np.array_equal(solver.iter_batch, ref["iter"])
+    assert np.abs(solver.xs_batch - ref["xs"]).max() < 1e-7
+    assert np.abs(solver.us_batch - ref["us"]).max() < 1e-7
+    assert np.abs(solver.us_squash_batch - ref["us_squash"]).max() < 1e-7
+    assert np.all(np.abs(solver.cost_batch - ref["cost"]) < 1e-9 * (1 + np.abs(ref["cost"])))
+    # the trace shows the clean-up iterations themselves (phase 100)
+    b = int(np.argmax(cleanup))
+    tr = solver.trace(b)
+    assert (tr[:, 0] == 100).sum() >= 1 and tr[-1, 0] == 100
+
+
+OPTION_CASES = [
+    ("stop_criteria", 1, {}),            # EMPC_STOP_EXPECTED_REDUCTION: stop = |d0 + d1 / 2|
+    ("stop_criteria", 2, {}),            # EMPC_STOP_QU_NORM: upstream crocoddyl's sum |Qu|^2
+    ("gap_norm", 1, {"th_stop_gaps": 1e-7}),   # EMPC_GAP_LINF with a gap threshold that actually decides
+    ("gap_norm", 0, {"th_stop_gaps": 1e-7}),   # L1 norm under the same threshold
+    ("terminal_dt_scaling", 0, {}),      # crocoddyl >= 1.9 terminal node: cost not scaled by dt
+    ("smoothsat_power", 4, {}),          # smooth-sat with d^4 under the roots
+]
+
+
+@pytest.mark.parametrize("key,value,extra", OPTION_CASES)
+def test_option_branches(empc, problems, key, value, extra):
+    """One solve per non-default option value, GPU vs oracle with the same EmpcSolverParams: identical iteration counts
+    and status, xs / us within 1e-4 (north-star tolerance), cost within 1e-6 relative.  displacement is the
+    well-conditioned workload (profiles/r02_oracle_sensitivity.json)."""
+    _, problem = problems["displacement"]
+    d = problem.desc
+    B = 4
+    x0s = empc.perturbed_x0s(problem.x0, B, nq=d.model.nq)
+    prm, oprm = empc.default_params(), ob.default_params()
+    for p in (prm, oprm):
+        setattr(p, key, value)
+        for k, v in extra.items():
+            setattr(p, k, v)
+    s = empc.SolverSbFDDP(problem, batch=B, params=prm)
+    s.solve([], [], 100, x0s=x0s)
+    r = ob.solve_batch(d, x0s, 100, nthreads=4, params=oprm)
+    assert np.array_equal(s.iter_batch, r["iter"]), (key, value, s.iter_batch, r["iter"])
+    assert np.array_equal(s.status_batch, r["status"])
+    assert np.abs(s.xs_batch - r["xs"]).max() < 1e-4 and np.abs(s.us_batch - r["us"]).max() < 1e-4
+    assert np.all(np.abs(s.cost_batch - r["cost"]) < 1e-6 * (1 + np.abs(r["cost"])))
+    if not extra:
+        # the option is live: the default solve of the same inputs ends elsewhere
+        s0 = empc.SolverSbFDDP(problem, batch=B)
+        s0.solve([], [], 100, x0s=x0s)
+        assert not np.array_equal(s0.iter_batch, s.iter_batch) or np.abs(s0.xs_batch - s.xs_batch).max() > 1e-3
+
+
+@pytest.mark.parametrize("name,B,amp", [("displacement", 4, 0.05), ("eagle_catch", 1, 0.0), ("push_slide", 2, 0.05)])
+def test_iteration_trace_matches_oracle(empc, problems, name, B, amp):
+    """Every iteration record of the device trace against the oracle's: phase, iteration, step length, feasibility and
+    regularisation exactly; cost / stop / dV / dVexp / d0 / d1 / gap norm to 1e-6 relative (scaled by the cost)."""
+    _, problem = problems[name]
+    d = problem.desc
+    x0s = empc.perturbed_x0s(problem.x0, B, nq=d.model.nq, amplitude=amp)
+    s = empc.SolverSbFDDP(problem, batch=B)
+    s.enable_trace(400)
+    s.solve([], [], 100, x0s=x0s)
+    for b in range(B):
+        o = ob.OracleSolver(d)
+        o.set_x0(x0s[b])
+        o.solve(None, None, 100)
+        ref = o.trace()
+        got = s.trace(b)
+        assert got.shape == ref.shape, (got.shape, ref.shape)
+        exact = [0, 1, 4, 5, 6]  # phase, iter, xreg, steplength, feasible
+        assert np.array_equal(got[:, exact], ref[:, exact])
+        scale = 1.0 + np.abs(ref[:, 2:3])
+        assert (np.abs(got[:, [2, 3, 7, 8, 10, 11]] - ref[:, [2, 3, 7, 8, 10, 11]]) / scale).max() < 1e-6
+        assert (np.abs(got[:, 9] - ref[:, 9]) / (1.0 + np.abs(ref[:, 9]))).max() < 1e-6
+    # ring semantics: a ring shorter than the solve keeps the newest records
+    s.enable_trace(5)
+    s.solve([], [], 100, x0s=x0s)
+    short = s.trace(0)
+    o = ob.OracleSolver(d)
+    o.set_x0(x0s[0])
+    o.solve(None, None, 100)
+    assert short.shape[0] == 5 and np.array_equal(short[:, 1], o.trace()[-5:, 1])
+    s.enable_trace(0)
+    with pytest.raises(empc.EmpcError):
+        s.trace(0)

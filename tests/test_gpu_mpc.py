@@ -58,8 +58,10 @@ def planned_trajectory(empc, dt_traj=80):
     return traj, np.array(tsolver.xs), np.array(tsolver.us)
 
 
-def closed_loop(empc, mpc, xs_ref, us_ref, nq, B=4, n_steps=6, dt_sim=2, tol=1e-6):
-    """examples/python/mpc.py:30-62 on the GPU (B plants at once) and on the oracle (one plant at a time)."""
+def closed_loop(empc, mpc, xs_ref, us_ref, nq, B=4, n_steps=6, dt_sim=2, tol=1e-6, sample=None):
+    """examples/python/mpc.py:30-62 on the GPU (B plants at once) and on the oracle (one plant at a time; `sample` =
+    the plants the oracle follows, default all of them)."""
+    sample = list(range(B)) if sample is None else list(sample)
     T_ = mpc.problem.T
     x_plants = empc.perturbed_x0s(xs_ref[0], B, nq=nq, amplitude=0.02)
     d = mpc.problem.desc
@@ -70,16 +72,16 @@ def closed_loop(empc, mpc, xs_ref, us_ref, nq, B=4, n_steps=6, dt_sim=2, tol=1e-
     # first solve: warm start = the head of the planned trajectory (mpc.py:38)
     solver.solve(xs_ref[:T_ + 1], us_ref[:T_], 100, x0s="plant")
     solver.convergence_init = 1e-3                                   # mpc.py:39
-    o_xs, o_us, o_x = [], [], x_plants.copy()
-    for b in range(B):
+    o_xs, o_us, o_x = {}, {}, x_plants.copy()
+    for b in sample:
         s = ob.OracleSolver(d)
         s.set_x0(o_x[b])
         s.solve(xs_ref[:T_ + 1], us_ref[:T_], 100)
         r = s.result()
-        o_xs.append(r["xs"])
-        o_us.append(r["us"])
-    assert np.abs(solver.xs_batch - np.array(o_xs)).max() < tol
-    assert np.abs(solver.us_batch - np.array(o_us)).max() < tol
+        o_xs[b] = r["xs"]
+        o_us[b] = r["us"]
+    assert np.abs(solver.xs_batch[sample] - np.array([o_xs[b] for b in sample])).max() < tol
+    assert np.abs(solver.us_batch[sample] - np.array([o_us[b] for b in sample])).max() < tol
 
     t = 0
     worst = 0.0
@@ -89,7 +91,7 @@ def closed_loop(empc, mpc, xs_ref, us_ref, nq, B=4, n_steps=6, dt_sim=2, tol=1e-
         usq = solver.us_squash_batch[:, 0]
         solver.plant_step(dt_sim)
         gx = solver.plant_states
-        for b in range(B):
+        for b in sample:
             s = ob.OracleSolver(d)
             ob.orc().oracle_solver_set_convergence_init(s.h, C.c_double(1e-3))
             s.set_x0(o_x[b])
@@ -98,12 +100,45 @@ def closed_loop(empc, mpc, xs_ref, us_ref, nq, B=4, n_steps=6, dt_sim=2, tol=1e-
             o_xs[b], o_us[b] = r["xs"], r["us"]
             assert np.abs(usq[b] - r["us_squash"][0]).max() < tol, (step, b)
             o_x[b] = ob.plant_rk4(d, o_x[b], r["us_squash"][0], dt_sim / 1000.0)[0]
-        worst = max(worst, np.abs(gx - o_x).max())
+        worst = max(worst, np.abs(gx[sample] - o_x[sample]).max())
         t += dt_sim
     assert worst < tol
     # the plants moved and stayed bounded
     assert np.isfinite(gx).all() and np.abs(gx - x_plants).max() > 1e-5
     return worst
+
+
+def test_carrot_50_knots_batch_256(empc):
+    """BASELINE.json configs[4] at its stated size: 50-knot receding horizon, 256 perturbed plants, RK4 plant at 2 ms.
+    The oracle follows a sample of the plants through every controller cycle (1e-6 on controls and plant states); all
+    256 stay finite, and a plant's closed loop does not depend on its neighbours in the batch (bitwise re-run of a subset)."""
+    import os
+    traj, xs_ref, us_ref = planned_trajectory(empc)
+    yaml50 = os.path.join(os.path.dirname(empc.YAML_DIR), "mpc", "carrot_50knots.yaml")
+    B, sample = 256, [0, 1, 100, 255]
+    mpc = empc.CarrotMpc(traj, xs_ref, 80, yaml50, batch=B)
+    assert mpc.knots == 50
+    nq = traj.nx - traj.ndx // 2
+    closed_loop(empc, mpc, xs_ref, us_ref, nq=nq, B=B, n_steps=8, sample=sample)
+    full_states = mpc.solver.plant_states
+    assert np.isfinite(full_states).all() and np.isfinite(mpc.solver.us_squash_batch).all()
+    # batch independence: the same four plants alone
+    traj2, _, _ = planned_trajectory(empc)
+    mpc2 = empc.CarrotMpc(traj2, xs_ref, 80, yaml50, batch=len(sample))
+    x_all = empc.perturbed_x0s(xs_ref[0], B, nq=nq, amplitude=0.02)
+    T_ = mpc2.problem.T
+    mpc2.updateProblem(0)
+    s2 = mpc2.solver
+    s2.plant_states = np.ascontiguousarray(x_all[sample])
+    s2.solve(xs_ref[:T_ + 1], us_ref[:T_], 100, x0s="plant")
+    s2.convergence_init = 1e-3
+    t = 0
+    for _ in range(8):
+        mpc2.updateProblem(t)
+        s2.solve("previous", "previous", mpc2.iters, x0s="plant")
+        s2.plant_step(2)
+        t += 2
+    assert np.array_equal(s2.plant_states, full_states[sample])
 
 
 def test_closed_loop_matches_oracle(empc):

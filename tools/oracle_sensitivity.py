@@ -97,6 +97,73 @@ def compare(a, b, tol=1e-4):
             "cost_rel_err_q50_q90_max_solved_by_both": q(ec, both)}
 
 
+def bind_solver_api(L):
+    L.oracle_solver_create.restype = C.c_void_p
+    L.oracle_solver_create.argtypes = [C.POINTER(T.ProblemDesc), C.POINTER(T.SolverParams)]
+    L.oracle_solver_destroy.argtypes = [C.c_void_p]
+    L.oracle_solver_set_x0.argtypes = [C.c_void_p, _dp]
+    L.oracle_solver_solve.argtypes = [C.c_void_p, _dp, _dp, C.c_int, C.c_int]
+    L.oracle_solver_trace.argtypes = [C.c_void_p, _dp, C.c_int]
+
+
+def trace_of(L, desc, prm, x0, maxiter):
+    h = C.c_void_p(L.oracle_solver_create(C.byref(desc), C.byref(prm)))
+    x0 = np.ascontiguousarray(x0, dtype=np.float64)
+    L.oracle_solver_set_x0(h, x0.ctypes.data_as(_dp))
+    L.oracle_solver_solve(h, None, None, int(maxiter), 0)
+    n = L.oracle_solver_trace(h, None, 0)
+    tr = np.zeros((n, 12))
+    L.oracle_solver_trace(h, tr.ctypes.data_as(_dp), n)
+    L.oracle_solver_destroy(h)
+    return tr
+
+
+def first_divergence(ta, tb, rtol=1e-6):
+    """index of the first iteration record at which two traces differ: another step length / feasibility / pass, or a
+    cost that differs by more than rtol relative; len(shorter) when one is a prefix of the other"""
+    n = min(len(ta), len(tb))
+    for i in range(n):
+        a, b = ta[i], tb[i]
+        if a[0] != b[0] or a[1] != b[1] or a[5] != b[5] or a[6] != b[6] or abs(a[2] - b[2]) > rtol * (1 + abs(a[2])):
+            return i
+    return n
+
+
+def _trace_job(args):
+    name, b, maxiter = args
+    rel, dt = CONFIGS[name]
+    tr = empc.Trajectory()
+    tr.autoSetup(empc.yaml_path(rel))
+    pb = tr.createProblem(dt, True, "IntegratedActionModelEuler")
+    d = pb.desc
+    base = build_variant("base", ["-ffp-contract=off"])
+    fma = build_variant("fma", ["-ffp-contract=fast"])
+    bind_solver_api(base)
+    bind_solver_api(fma)
+    x0s = empc.perturbed_x0s(pb.x0, b + 1, nq=d.model.nq)
+    prm = ob.default_params()
+    prm13 = ob.default_params()
+    prm13.th_gaptol = 1e-13
+    t_base = trace_of(base, d, prm, x0s[b], maxiter)
+    t_fma = trace_of(fma, d, prm13, x0s[b], maxiter)
+    t_ulp = trace_of(base, d, prm, nudge_ulp(x0s)[b], maxiter)
+    return b, len(t_base), first_divergence(t_base, t_fma), first_divergence(t_base, t_ulp)
+
+
+def trace_study(name, n, maxiter, procs):
+    """first iteration at which the oracle and its rounding variants part ways, per rollout"""
+    import multiprocessing as mp
+    with mp.get_context("fork").Pool(procs) as pool:
+        rows = pool.map(_trace_job, [(name, b, maxiter) for b in range(n)])
+    rows = np.array(rows)
+    q = lambda v: [int(x) for x in np.quantile(v, [0.0, 0.05, 0.25, 0.5])]
+    return {"rollouts": int(n), "iterations_base_q0_q5_q25_q50": q(rows[:, 1]),
+            "first_divergent_iteration_base_vs_fma_q0_q5_q25_q50": q(rows[:, 2]),
+            "first_divergent_iteration_base_vs_ulp_q0_q5_q25_q50": q(rows[:, 3]),
+            "rollouts_identical_path_base_vs_fma": int((rows[:, 2] >= rows[:, 1]).sum()),
+            "rollouts_identical_path_base_vs_ulp": int((rows[:, 3] >= rows[:, 1]).sum())}
+
+
 def nudge_ulp(x0s, seed=7):
     rng = np.random.default_rng(seed)
     out = x0s.copy()
@@ -112,6 +179,7 @@ def main():
     ap.add_argument("--configs", default="eagle_catch,hover,displacement")
     ap.add_argument("--maxiter", type=int, default=100)
     ap.add_argument("--threads", type=int, default=os.cpu_count() or 1)
+    ap.add_argument("--trace-rollouts", type=int, default=64, help="rollouts of the per-iteration trace comparison (0 = skip)")
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02_oracle_sensitivity.json"))
     args = ap.parse_args()
     ob.build_oracle()
@@ -142,6 +210,8 @@ def main():
                      "mean_iterations_base": float(r_base["iter"].mean() + 1),
                      "base_vs_gaptol13": compare(r_base, r_g13), "base_vs_fma": compare(r_base, r_fma),
                      "base_vs_ulp": compare(r_base, r_ulp), "seconds": round(time.time() - t0, 1)}
+        if args.trace_rollouts > 0 and name != "displacement":
+            res[name]["trace_study"] = trace_study(name, min(args.trace_rollouts, args.batch), args.maxiter, args.threads)
         print(name, json.dumps(res[name], indent=1), flush=True)
     with open(args.out, "w") as f:
         json.dump(res, f, indent=1)

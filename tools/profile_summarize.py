@@ -2,9 +2,9 @@
 """Condense rocprofv3 output directories into the small files kept under profiles/.
 
   python tools/profile_summarize.py stats   <rocprof dir> <out.csv>          # --kernel-trace --stats run
-  python tools/profile_summarize.py traffic <fetch dir> <write dir> <tag>     # two --pmc passes (FETCH_SIZE / WRITE_SIZE)
+  python tools/profile_summarize.py traffic <fetch dir> <write dir> <tag> [config]  # two --pmc passes (FETCH_SIZE / WRITE_SIZE)
 
-`traffic` writes profiles/traffic_<kernel>.json per hot kernel: HBM bytes per launch as /opt/skills/guides/
+`traffic` writes profiles/traffic_<config>_<kernel>.json per hot kernel: HBM bytes per launch as /opt/skills/guides/
 MI355X_MICROARCH.md prescribes -- FETCH_SIZE and WRITE_SIZE are reported in KiB-sized units by rocprofv3 (x1024) and, on
 gfx950, FETCH_SIZE tallies 128-B requests at 64 B, so reads are doubled; the raw values are kept next to the corrected one.
 """
@@ -54,7 +54,7 @@ def counters(src, counter):
     return agg
 
 
-def traffic(fetch_dir, write_dir, tag):
+def traffic(fetch_dir, write_dir, tag, config="displacement"):
     fe = counters(fetch_dir, "FETCH_SIZE")
     wr = counters(write_dir, "WRITE_SIZE")
     if "k_linearize_full" in fe and "k_linearize_full" in wr:  # one linearize step of a sweep = both bodies
@@ -68,14 +68,14 @@ def traffic(fetch_dir, write_dir, tag):
         # bench's per-launch algorithmic bytes describe on average, so report the mean over all launches of the run
         f_raw = sum(fe[k]) / len(fe[k]) * 1024.0
         w_raw = sum(wr[k]) / len(wr[k]) * 1024.0
-        out = {"kernel": k, "tag": tag, "launches": len(fe[k]),
+        out = {"kernel": k, "tag": tag, "config": config, "launches": len(fe[k]),
                "fetch_bytes_raw_per_launch": f_raw, "write_bytes_raw_per_launch": w_raw,
                "hbm_bytes_per_launch": 2.0 * f_raw + w_raw,
                "correction": "FETCH_SIZE x1024 x2 (gfx950 tallies 128-B read requests at 64 B), WRITE_SIZE x1024; 8-B/lane "
                              "accesses are outside the guide's calibrated 16-B/lane pattern, so the absolute value is "
                              "indicative, ratios between builds are exact"}
         name = k.replace("k_", "")
-        with open(os.path.join(ROOT, "profiles", "traffic_%s.json" % name), "w") as f:
+        with open(os.path.join(ROOT, "profiles", "traffic_%s_%s.json" % (config, name)), "w") as f:
             json.dump(out, f, indent=1)
         print(json.dumps(out))
 
@@ -115,6 +115,6 @@ if __name__ == "__main__":
     elif len(sys.argv) >= 4 and sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
     elif len(sys.argv) >= 5 and sys.argv[1] == "traffic":
-        traffic(sys.argv[2], sys.argv[3], sys.argv[4])
+        traffic(sys.argv[2], sys.argv[3], sys.argv[4], *(sys.argv[5:6]))
     else:
         raise SystemExit(__doc__)
