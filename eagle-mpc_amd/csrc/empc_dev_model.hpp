@@ -590,6 +590,113 @@ EMPC_HD void cone_rows(const double* nsurf, double mu, double AR[5][3]) {
     for (int j = 0; j < 3; ++j) AR[i][j] = A[i][0] * Rn[3 * j] + A[i][1] * Rn[3 * j + 1] + A[i][2] * Rn[3 * j + 2];
 }
 
+// ContactModel3D forward dynamics on top of the free solution: [M Jc^T; Jc 0][a; -lam] = [tau - h; -a0].
+// In: the Cholesky factor L of M (reciprocal diagonal), a = M^-1 (tau - h), the contact frame's capture ck (from the bias
+// pass: placement, LOCAL velocity, LOCAL acceleration at qdd = 0 with the gravity offset).  Out: a corrected in place,
+// lam[0..2] = contact force (LOCAL frame).  Three constraint rows, fixed at compile time (6D contacts are refused by
+// prepare_problem): every loop unrolls and Jc / M^-1 Jc^T stay in registers.
+template <class DM, class ContactT>
+EMPC_HD void contact_forward(const EMPC_K EmpcModelDesc& m, const ContactT& ct, const FrameCap<double>& ck, const double* R0,
+                             const double* q, const double* cs, const double* sn, const double* L, double* a, double* lam) {
+  constexpr int NV = DM::NV;
+  constexpr int nc = 3;
+  // drift (frame acceleration at qdd = 0, no gravity): the bias pass carries gravity as a base acceleration -g, which
+  // reaches every frame as the pure translation R_f^T (-g); take it out again
+  double ng[3] = {-m.gravity[0], -m.gravity[1], -m.gravity[2]}, gf[3], a0[6];
+  matTvec3<double>(ck.R, ng, gf);
+  {
+    double wxv[3];
+    cross3<double>(ck.v + 3, ck.v, wxv);  // classical acceleration of the contact point
+#pragma unroll
+    for (int r = 0; r < 3; ++r) a0[r] = (ck.a[r] - gf[r]) + wxv[r];
+  }
+  if (ct.gains[0] != 0.0) {
+    double dp[3], dpl[3];
+    for (int r = 0; r < 3; ++r) dp[r] = ck.p[r] - ct.ref_p[r];
+    matTvec3<double>(ck.R, dp, dpl);
+    for (int r = 0; r < 3; ++r) a0[r] += ct.gains[0] * dpl[r];
+  }
+  if (ct.gains[1] != 0.0)
+#pragma unroll
+    for (int r = 0; r < nc; ++r) a0[r] += ct.gains[1] * ck.v[r];
+  // Jc: LOCAL frame Jacobian from the kinematics (column j = [R_f^T (z_j x (p_f - o_j)); R_f^T z_j] for a rotation about
+  // the world axis z_j through o_j, R_f^T e_j for the base translations), joints after the frame's body contribute nothing
+  double Jc[nc][NV], MiJt[nc][NV];
+  {
+    const int bf = m.frame_body[ct.frame];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      double w[3] = {R0[j], R0[3 + j], R0[6 + j]}, lin[3];
+      matTvec3<double>(ck.R, w, lin);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) Jc[r][j] = lin[r];
+    }
+    double Rw[9], pw[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Rw[i] = R0[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) pw[i] = q[i];
+#pragma unroll
+    for (int j = 3; j < NV; ++j) {
+      double z[3];
+      bool on_path = true;
+      if (j < 6) {
+        z[0] = R0[j - 3];
+        z[1] = R0[3 + j - 3];
+        z[2] = R0[6 + j - 3];
+      } else {
+        const int b = j - 6 + 1;
+        double Rj[9], XR[9], Rr[3], Rn[9];
+        axis_rot<double>(m.axis[b], cs[b - 1], sn[b - 1], Rj);
+        matmul3<double>(m.jplace_R[b], Rj, XR);
+        matvec3<double>(Rw, m.jplace_p[b], Rr);
+        matmul3<double>(Rw, XR, Rn);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Rw[i] = Rn[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) pw[i] += Rr[i];
+        double ax[3] = {m.axis[b][0], m.axis[b][1], m.axis[b][2]};
+        matvec3<double>(Rw, ax, z);
+        on_path = (b <= bf);
+      }
+      double d[3] = {ck.p[0] - pw[0], ck.p[1] - pw[1], ck.p[2] - pw[2]}, zxd[3], lin[3];
+      cross3<double>(z, d, zxd);
+      matTvec3<double>(ck.R, zxd, lin);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) Jc[r][j] = on_path ? lin[r] : 0.0;
+    }
+  }
+  double G[nc * (nc + 1) / 2];  // packed nc x nc
+#pragma unroll
+  for (int r = 0; r < nc; ++r) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) MiJt[r][i] = Jc[r][i];
+    chol_solve_packed<NV>(L, MiJt[r]);
+  }
+#pragma unroll
+  for (int r = 0; r < nc; ++r)
+#pragma unroll
+    for (int c = 0; c <= r; ++c) {
+      double g = 0;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) g += Jc[r][i] * MiJt[c][i];
+      G[r * (r + 1) / 2 + c] = g;
+    }
+  chol_packed<nc>(G);
+#pragma unroll
+  for (int r = 0; r < nc; ++r) {
+    double g = a0[r];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) g += Jc[r][i] * a[i];
+    lam[r] = -g;
+  }
+  chol_solve_packed<nc>(G, lam);
+#pragma unroll
+  for (int r = 0; r < nc; ++r)
+#pragma unroll
+    for (int i = 0; i < NV; ++i) a[i] += MiJt[r][i] * lam[r];
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Nominal evaluation of one node by ONE lane: IAM.calc(x, s)  (used by the rollout and calc kernels).
 //   terminal: the reference's IAM.calc(x) == calc(x, u = 0)   
@@ -782,109 +889,11 @@ EMPC_HD void node_nominal(const EMPC_K DevProblem& P, const SetT& set, double sm
   EMPC_STAMP(4);  // Cholesky + solve
   double lam[6] = {0, 0, 0, 0, 0, 0};
   if constexpr (CT) if (use_contact) {
-    // ContactModel3D: [M Jc^T; Jc 0][a; -lam] = [tau - h; -a0].  Three constraint rows, fixed at compile time
-    // (prepare_problem refuses 6D contacts): every loop below unrolls and Jc / M^-1 Jc^T stay in registers.
-    const auto& ct = set.contacts[0];
-    constexpr int nc = 3;
     FrameCap<double> ck = caps[0];
 #pragma unroll
     for (int kk = 1; kk < NCAP; ++kk)
       if (kk == ccap) ck = caps[kk];
-    // drift (frame acceleration at qdd = 0, no gravity): the bias pass carries gravity as a base acceleration -g, which
-    // reaches every frame as the pure translation R_f^T (-g); take it out again
-    double ng[3] = {-m.gravity[0], -m.gravity[1], -m.gravity[2]}, gf[3], a0[6];
-    matTvec3<double>(ck.R, ng, gf);
-    {
-      double wxv[3];
-      cross3<double>(ck.v + 3, ck.v, wxv);  // classical acceleration of the contact point
-#pragma unroll
-      for (int r = 0; r < 3; ++r) a0[r] = (ck.a[r] - gf[r]) + wxv[r];
-    }
-    if (ct.gains[0] != 0.0) {
-      double dp[3], dpl[3];
-      for (int r = 0; r < 3; ++r) dp[r] = ck.p[r] - ct.ref_p[r];
-      matTvec3<double>(ck.R, dp, dpl);
-      for (int r = 0; r < 3; ++r) a0[r] += ct.gains[0] * dpl[r];
-    }
-    if (ct.gains[1] != 0.0)
-#pragma unroll
-      for (int r = 0; r < nc; ++r) a0[r] += ct.gains[1] * ck.v[r];
-    // Jc: LOCAL frame Jacobian from the kinematics (column j = [R_f^T (z_j x (p_f - o_j)); R_f^T z_j] for a rotation about
-    // the world axis z_j through o_j, R_f^T e_j for the base translations), joints after the frame's body contribute nothing
-    double Jc[nc][NV], MiJt[nc][NV];
-    {
-      const int bf = m.frame_body[ct.frame];
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        double w[3] = {R0[j], R0[3 + j], R0[6 + j]}, lin[3];
-        matTvec3<double>(ck.R, w, lin);
-#pragma unroll
-        for (int r = 0; r < 3; ++r) Jc[r][j] = lin[r];
-      }
-      double Rw[9], pw[3];
-#pragma unroll
-      for (int i = 0; i < 9; ++i) Rw[i] = R0[i];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) pw[i] = q[i];
-#pragma unroll
-      for (int j = 3; j < NV; ++j) {
-        double z[3];
-        bool on_path = true;
-        if (j < 6) {
-          z[0] = R0[j - 3];
-          z[1] = R0[3 + j - 3];
-          z[2] = R0[6 + j - 3];
-        } else {
-          const int b = j - 6 + 1;
-          double Rj[9], XR[9], Rr[3], Rn[9];
-          axis_rot<double>(m.axis[b], cs[b - 1], sn[b - 1], Rj);
-          matmul3<double>(m.jplace_R[b], Rj, XR);
-          matvec3<double>(Rw, m.jplace_p[b], Rr);
-          matmul3<double>(Rw, XR, Rn);
-#pragma unroll
-          for (int i = 0; i < 9; ++i) Rw[i] = Rn[i];
-#pragma unroll
-          for (int i = 0; i < 3; ++i) pw[i] += Rr[i];
-          double ax[3] = {m.axis[b][0], m.axis[b][1], m.axis[b][2]};
-          matvec3<double>(Rw, ax, z);
-          on_path = (b <= bf);
-        }
-        double d[3] = {ck.p[0] - pw[0], ck.p[1] - pw[1], ck.p[2] - pw[2]}, zxd[3], lin[3];
-        cross3<double>(z, d, zxd);
-        matTvec3<double>(ck.R, zxd, lin);
-#pragma unroll
-        for (int r = 0; r < 3; ++r) Jc[r][j] = on_path ? lin[r] : 0.0;
-      }
-    }
-    double G[nc * (nc + 1) / 2];  // packed nc x nc
-#pragma unroll
-    for (int r = 0; r < nc; ++r) {
-#pragma unroll
-      for (int i = 0; i < NV; ++i) MiJt[r][i] = Jc[r][i];
-      chol_solve_packed<NV>(L, MiJt[r]);
-    }
-#pragma unroll
-    for (int r = 0; r < nc; ++r)
-#pragma unroll
-      for (int c = 0; c <= r; ++c) {
-        double g = 0;
-#pragma unroll
-        for (int i = 0; i < NV; ++i) g += Jc[r][i] * MiJt[c][i];
-        G[r * (r + 1) / 2 + c] = g;
-      }
-    chol_packed<nc>(G);
-#pragma unroll
-    for (int r = 0; r < nc; ++r) {
-      double g = a0[r];
-#pragma unroll
-      for (int i = 0; i < NV; ++i) g += Jc[r][i] * a[i];
-      lam[r] = -g;
-    }
-    chol_solve_packed<nc>(G, lam);
-#pragma unroll
-    for (int r = 0; r < nc; ++r)
-#pragma unroll
-      for (int i = 0; i < NV; ++i) a[i] += MiJt[r][i] * lam[r];
+    contact_forward<DM>(m, set.contacts[0], ck, R0, q, cs, sn, L, a, lam);
   }
 #pragma unroll
   for (int i = 0; i < NV; ++i) acc[i] = a[i];

@@ -66,6 +66,11 @@ struct DevBuffers {
   const int* lin_count = nullptr;
   int* lin_list_out = nullptr;   // the list select builds for the next sweep (nullptr = none)
   int* lin_count_out = nullptr;
+  // trajectories still iterating (phase != DONE), same hand-over: the packed rollout forms its wavefronts from this list,
+  // so a sweep with few stragglers launches few workgroups.  act_count is the previous sweep's n_active.
+  const int* act_list = nullptr;
+  const int* act_count = nullptr;
+  int* act_list_out = nullptr;
   unsigned long long* dbg;  // [64] cycle stamps of diagnostic builds (EMPC_STAMPS); unused otherwise
   // optional per-iteration record (the reference's callback hook, src/sbfddp.cpp:303-307,381-385): ring of trace_cap
   // records of EMPC_TRACE_WORDS doubles per trajectory, written by select; nullptr = off
@@ -465,6 +470,10 @@ EMPC_HD void select_decide(const DevBuffers& D, int b, int& accepted_ai, int& la
   } else {
     st.need_lin = 0;
     st.need_calc = 0;
+    if (ddp) {  // expectedImprovementDDP() runs once, before the line search (src/sbfddp.cpp:344): d_ is set even if every trial fails
+      st.d0 = st.dg_u;
+      st.d1 = st.dq_u;
+    }
     for (int ai = 0; ai < NA; ++ai) {
       const double alpha = ldexp(1.0, -ai);
       st.steplength = alpha;

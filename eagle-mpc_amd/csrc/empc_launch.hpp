@@ -17,6 +17,7 @@
 #include "empc_linearize2.hpp"
 #include "empc_backward2.hpp"
 #include "empc_backward3.hpp"
+#include "empc_rollout6.hpp"
 #endif
 
 using namespace empc;
@@ -74,6 +75,27 @@ __global__ void __launch_bounds__(64) k_rollout5(DevBuffers D) {
   static_assert(DM::NU <= 64, "feedback rows must fit one wavefront");
   LaneExec ex{(int)threadIdx.x};
   rollout_wave5<DM, CT>(ex, D, blockIdx.x, 64, smem_roll5);
+}
+
+// the shipped rollout: G trajectories x NA step lengths per wavefront, four role wavefronts per workgroup (empc_rollout6.hpp)
+struct RoleExec {
+  int lane, wave;  // wave is wave-uniform (an SGPR): the role switch is a scalar branch
+  static constexpr int SLOTS = 1;
+  template <class F>
+  __device__ __forceinline__ void role(int w, F&& f) {
+    if (wave == w) f(lane, 0);
+  }
+  template <class F>
+  __device__ __forceinline__ void all(F&& f) {
+    f(lane, 0);
+  }
+  __device__ __forceinline__ void sync() { __syncthreads(); }
+};
+template <class DM, bool CT>
+__global__ void __launch_bounds__(64 * R6_WAVES) k_rollout6(DevBuffers D) {
+  extern __shared__ double smem_roll6[];
+  RoleExec ex{(int)(threadIdx.x & 63), __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))};
+  rollout_group6<DM, CT>(ex, D, blockIdx.x, smem_roll6);
 }
 
 template <class DM, bool CT, int LPU, int BLK, bool FR>
@@ -178,7 +200,8 @@ __global__ void __launch_bounds__(64) k_select(DevBuffers D) {
     sh[0] = acc_ai;
     sh[1] = last_ai;
     if (D.st[b].phase != PHASE_DONE) {
-      atomicAdd(D.n_active, 1);
+      const int pos = atomicAdd(D.n_active, 1);
+      if (D.act_list_out) D.act_list_out[pos] = b;
       if (D.lin_count_out && D.st[b].need_lin) D.lin_list_out[atomicAdd(D.lin_count_out, 1)] = b;
     }
   }
@@ -312,11 +335,20 @@ template <class DM, bool CT>
 static void launch_rollout(DevBuffers D, hipStream_t s) {
   const int n = D.B * D.NA;
   static const int version = [] {
-    const char* e = getenv("EMPC_ROLLOUT");  // 1 = per-lane form (also the fallback for more than MAX_ALPHAS step lengths)
-    return e ? atoi(e) : 5;
+    const char* e = getenv("EMPC_ROLLOUT");  // 6 = packed role-split form (default), 5 = wave per trajectory, 1 = per-lane form (also the fallback for more than MAX_ALPHAS step lengths)
+    return e ? atoi(e) : 6;
   }();
   if (version == 1 || D.NA > MAX_ALPHAS) {
     hipLaunchKernelGGL((k_rollout<DM, CT>), dim3((n + 63) / 64), dim3(64), 0, s, D);
+  } else if (version == 6) {
+    const size_t smem = sizeof(double) * Roll6Smem<DM>::SIZE;
+    static const bool once = [&] {  // more than 64 KB of dynamic LDS needs the opt-in
+      (void)hipFuncSetAttribute((const void*)k_rollout6<DM, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      return true;
+    }();
+    (void)once;
+    const int G = roll6_group_size(D.NA);
+    hipLaunchKernelGGL((k_rollout6<DM, CT>), dim3((D.B + G - 1) / G), dim3(64 * R6_WAVES), smem, s, D);
   } else {
     hipLaunchKernelGGL((k_rollout5<DM, CT>), dim3(D.B), dim3(64), sizeof(double) * Roll5Smem<DM>::SIZE, s, D);
   }

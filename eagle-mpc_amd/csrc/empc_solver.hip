@@ -57,6 +57,7 @@ struct EmpcSolver {
   int* dknot = nullptr;
   int* dlin_knots = nullptr;
   int* dlin_list = nullptr;  // [2][B] linearize lists of the two sweep slots
+  int* dact_list = nullptr;  // [2][B] lists of the trajectories still iterating, same slots
   double* dscratch = nullptr;  // output staging (squashed controls)
   double* dplant_x = nullptr;  // [B][NX] plant states of closed-loop runs (empc_plant_*)
   double* dplant_u = nullptr;  // [B][NU] staging of caller-supplied plant controls
@@ -223,6 +224,7 @@ EmpcSolver* empc_solver_create(const EmpcProblemDesc* problem, const EmpcSolverP
   D.us_last = s->dalloc<double>(B * T * k.nu);
   D.n_active = s->dalloc<int>(4 * EmpcSolver::MAX_STREAMS);  // per chunk and sweep slot: {active trajectories, entries of the linearize list}
   s->dlin_list = s->dalloc<int>(2 * (size_t)batch);          // per sweep slot: the linearize list of every chunk, chunk after chunk
+  s->dact_list = s->dalloc<int>(2 * (size_t)batch);
   D.dbg = s->dalloc<unsigned long long>(64);
   HIP_CHECK(hipMemsetAsync(D.dbg, 0, 64 * sizeof(unsigned long long), s->stream));
   D.B = batch;
@@ -477,9 +479,12 @@ int empc_solver_solve(EmpcSolver* s, int maxiter, int is_feasible) {
     Dq.n_active = c.D.n_active + 2 * q;
     Dq.lin_count_out = Dq.n_active + 1;
     Dq.lin_list_out = s->dlin_list + (size_t)q * s->B + c.b0;
-    if (queued[c.idx] > 0) {  // the list written by the previous sweep's select; the first sweep takes every trajectory
+    Dq.act_list_out = s->dact_list + (size_t)q * s->B + c.b0;
+    if (queued[c.idx] > 0) {  // the lists written by the previous sweep's select; the first sweep takes every trajectory
       Dq.lin_count = c.D.n_active + 2 * (1 - q) + 1;
       Dq.lin_list = s->dlin_list + (size_t)(1 - q) * s->B + c.b0;
+      Dq.act_count = c.D.n_active + 2 * (1 - q);
+      Dq.act_list = s->dact_list + (size_t)(1 - q) * s->B + c.b0;
     }
     HIP_CHECK(hipMemsetAsync(Dq.n_active, 0, 2 * sizeof(int), c.stream));
     HIP_CHECK(hipEventRecord(c.ev[q][0], c.stream));

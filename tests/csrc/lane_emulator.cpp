@@ -10,6 +10,7 @@
 #include "../../eagle-mpc_amd/csrc/empc_linearize2.hpp"
 #include "../../eagle-mpc_amd/csrc/empc_backward2.hpp"
 #include "../../eagle-mpc_amd/csrc/empc_backward3.hpp"
+#include "../../eagle-mpc_amd/csrc/empc_rollout6.hpp"
 
 using namespace empc;
 
@@ -42,6 +43,20 @@ struct CpuExec {
     for (int i = 0; i < 16; ++i)
       for (int j = 0; j < 16; ++j) c[(i % 4) * 16 + j][im][in][i / 4] = Dm[i][j];
   }
+};
+
+// role-split kernels: the four wavefronts of a workgroup one after another (roles of a phase are independent)
+struct CpuRoleExec {
+  static constexpr int SLOTS = 64;
+  template <class F>
+  void role(int, F&& f) {
+    for (int l = 0; l < 64; ++l) f(l, l);
+  }
+  template <class F>
+  void all(F&& f) {
+    for (int l = 0; l < 64; ++l) f(l, l);
+  }
+  void sync() {}
 };
 
 struct Emu {
@@ -170,10 +185,25 @@ static void emu_backward(Emu& e) {
     }
   }
 }
-static int g_roll_version = 5;
+static int g_roll_version = 6;
 template <class DM>
 static void emu_rollout(Emu& e) {
   const bool ct = e.H.P.has_contact != 0;
+  if (g_roll_version == 6 && e.NA <= MAX_ALPHAS) {  // the shipped form: packed trajectories, role wavefronts
+    const int G = roll6_group_size(e.NA);
+    std::vector<double> smem6(Roll6Smem<DM>::SIZE);
+    for (int grp = 0; grp * G < e.B; ++grp) {
+      CpuRoleExec ex;
+      if constexpr (DM::NB == 4) {
+        if (ct) {
+          rollout_group6<DM, true>(ex, e.D, grp, smem6.data());
+          continue;
+        }
+      }
+      rollout_group6<DM, false>(ex, e.D, grp, smem6.data());
+    }
+    return;
+  }
   for (int b = 0; b < e.B; ++b)
     for (int ai = 0; ai < e.NA; ++ai) {
       if (g_roll_version == 5) {
