@@ -35,9 +35,23 @@ struct TrajState {
   double gapnorm, qu2;
 };
 
+// Per-cost-set work lists, built once on the host (prepare_problem) so that the kernels walk only the costs a stage needs
+// instead of scanning the whole table with dependent scalar loads: indices into EmpcCostSet::costs, active costs only,
+// each list in table (= alphabetical = CostModelSum) order.
+struct SetInfo {
+  int ncap, capf[NCAP], ccap;  // operational frames captured by the bias pass: frame costs first, then the contact frame
+  int n_sc, n_state, n_ctrl, n_frame, n_cone;
+  int sc_ci[EMPC_MAX_COSTS];     // State and Control costs, interleaved as they appear in the table (order of the cost sum)
+  int state_ci[EMPC_MAX_COSTS];  // State costs
+  int ctrl_ci[EMPC_MAX_COSTS];   // Control costs (incl. the solver's barrier)
+  int frame_ci[EMPC_MAX_COSTS];  // FramePlacement / Rotation / Translation / Velocity costs
+  int cone_ci[EMPC_MAX_COSTS];   // ContactFrictionCone costs
+};
+
 struct DevBuffers {
   const DevProblem* P;
   const EmpcCostSet* sets;
+  const SetInfo* set_info;  // [n_sets]
   const int* knot_set;
   const int* lin_knots;  // [T+1] knots sorted: first the n_lean knots whose cost set captures no operational frames, then the rest
   int n_lean;            // linearize runs its lean body over the first group and the full body over the second

@@ -79,23 +79,30 @@ __global__ void __launch_bounds__(64) k_rollout5(DevBuffers D) {
 
 // the shipped rollout: G trajectories x NA step lengths per wavefront, four role wavefronts per workgroup (empc_rollout6.hpp)
 struct RoleExec {
-  int lane, wave;  // wave is wave-uniform (an SGPR): the role switch is a scalar branch
+  int lane;
   static constexpr int SLOTS = 1;
   template <class F>
-  __device__ __forceinline__ void role(int w, F&& f) {
-    if (wave == w) f(lane, 0);
-  }
-  template <class F>
-  __device__ __forceinline__ void all(F&& f) {
+  __device__ __forceinline__ void each(F&& f) {
     f(lane, 0);
   }
-  __device__ __forceinline__ void sync() { __syncthreads(); }
+  // Workgroup barrier that orders LDS traffic only: the roles hand everything over through LDS, while their global
+  // loads (next knot's nominal data) and stores (trial trajectories) stay in flight across it -- __syncthreads() would
+  // drain them (vmcnt(0)) twice per knot.
+  __device__ __forceinline__ void sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 };
 template <class DM, bool CT>
 __global__ void __launch_bounds__(64 * R6_WAVES) k_rollout6(DevBuffers D) {
   extern __shared__ double smem_roll6[];
-  RoleExec ex{(int)(threadIdx.x & 63), __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))};
-  rollout_group6<DM, CT>(ex, D, blockIdx.x, smem_roll6);
+  RoleExec ex{(int)(threadIdx.x & 63)};
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: the role switch is a scalar branch
+  if (wave == R6_A)
+    rollout_group6<DM, CT, R6_A>(ex, D, blockIdx.x, smem_roll6);
+  else if (wave == R6_B)
+    rollout_group6<DM, CT, R6_B>(ex, D, blockIdx.x, smem_roll6);
+  else if (wave == R6_C)
+    rollout_group6<DM, CT, R6_C>(ex, D, blockIdx.x, smem_roll6);
+  else
+    rollout_group6<DM, CT, R6_D>(ex, D, blockIdx.x, smem_roll6);
 }
 
 template <class DM, bool CT, int LPU, int BLK, bool FR>

@@ -16,6 +16,7 @@ namespace empc {
 struct HostProblem {
   DevProblem P;
   std::vector<EmpcCostSet> sets;
+  std::vector<SetInfo> set_info;
   std::vector<int> knot_set;
   std::vector<double> x0;
 };
@@ -136,6 +137,46 @@ inline void prepare_problem(const EmpcProblemDesc& d, const EmpcSolverParams& pr
     if (s.ncontacts > 1) throw std::runtime_error("more than one contact per stage is not supported by the kernels");
     if (s.ncontacts == 1 && s.contacts[0].type != EMPC_CONTACT_3D)
       throw std::runtime_error("only ContactModel3D is implemented in the linearize kernel (ContactModel6D is not)");
+  }
+  // work lists per cost set (SetInfo); the capture order is the one node_nominal derives by scanning the table
+  H.set_info.assign(H.sets.size(), SetInfo());
+  for (size_t k = 0; k < H.sets.size(); ++k) {
+    const EmpcCostSet& s = H.sets[k];
+    SetInfo& I = H.set_info[k];
+    std::memset(&I, 0, sizeof(I));
+    for (int i = 0; i < s.ncosts; ++i) {
+      const EmpcCost& c = s.costs[i];
+      if (!c.active) continue;
+      if (c.type == EMPC_COST_STATE) {
+        I.state_ci[I.n_state++] = i;
+        I.sc_ci[I.n_sc++] = i;
+      } else if (c.type == EMPC_COST_CONTROL) {
+        I.ctrl_ci[I.n_ctrl++] = i;
+        I.sc_ci[I.n_sc++] = i;
+      } else if (c.type == EMPC_COST_CONTACT_FRICTION_CONE) {
+        I.cone_ci[I.n_cone++] = i;
+      } else {
+        I.frame_ci[I.n_frame++] = i;
+      }
+      if (c.frame >= 0 && c.type != EMPC_COST_CONTACT_FRICTION_CONE) {
+        bool seen = false;
+        for (int q = 0; q < I.ncap; ++q) seen = seen || I.capf[q] == c.frame;
+        if (!seen && I.ncap < NCAP) I.capf[I.ncap++] = c.frame;
+      }
+    }
+    if (d.has_contact && s.ncontacts > 0) {
+      const int cframe = s.contacts[0].frame;
+      bool seen = false;
+      for (int q = 0; q < I.ncap; ++q)
+        if (I.capf[q] == cframe) {
+          seen = true;
+          I.ccap = q;
+        }
+      if (!seen) {
+        I.ccap = I.ncap;
+        if (I.ncap < NCAP) I.capf[I.ncap++] = cframe;
+      }
+    }
   }
 }
 

@@ -28,10 +28,22 @@ constexpr int R6_GMAX = 8;  // most trajectories packed into one wavefront (LDS 
 template <class DM>
 struct Roll6Smem {
   static constexpr int NX = DM::NX, NU = DM::NU, NV = DM::NV, NDX = DM::NDX, NL = 64;
-  // nominal data of one trajectory at one knot
-  static constexpr int NOM_X = 0, NOM_GAP = NOM_X + NX, NOM_VF = NOM_GAP + NDX, NOM_US = NOM_VF + NDX, NOM_KF = NOM_US + NU,
-                       NOM_K = NOM_KF + NU;
-  static constexpr int NOMSZ = (NOM_K + NU * NDX) | 1;  // odd stride: the G broadcast addresses of a read fall in distinct banks
+  // nominal data of the packed trajectories at one knot, one array per quantity: [trajectory][stride].  A read by the
+  // 60 trial lanes touches G addresses (one per trajectory, broadcast to its step lengths); odd strides (in doubles) put
+  // those in distinct banks; the gain rows need an even stride (16-byte stores) = 2 x odd.
+  static constexpr int XS = NX | 1, GS = NDX | 1, US = NU | 1;
+  static constexpr int KS = ((NU * NDX) % 4 == 2) ? NU * NDX : NU * NDX + 2;
+  static constexpr int NOM_K = 0;                               // K[t]      (staged by B)
+  static constexpr int NOM_X = NOM_K + R6_GMAX * KS;            // xs[t]     (the rest staged by D)
+  static constexpr int NOM_GAP = NOM_X + R6_GMAX * XS;          // fs[t]
+  static constexpr int NOM_VF = NOM_GAP + R6_GMAX * GS;         // Vxx[t] fs[t]
+  static constexpr int NOM_US = NOM_VF + R6_GMAX * GS;          // us[t]
+  static constexpr int NOM_KF = NOM_US + R6_GMAX * US;          // k[t]
+  static constexpr int NOMSZ = (NOM_KF + R6_GMAX * US + 1) / 2 * 2;
+  // staging work items per lane (compile-time upper bounds for GMAX trajectories)
+  static constexpr int KE = NU * NDX / 2;                       // 16-byte elements of one K[t]
+  static constexpr int NKI = (R6_GMAX * KE + NL - 1) / NL;
+  static constexpr int NXI = (R6_GMAX * NX + NL - 1) / NL, NGI = (R6_GMAX * NDX + NL - 1) / NL, NUI = (R6_GMAX * NU + NL - 1) / NL;
   // per-lane exchange slots, laid out [item][lane]
   static constexpr int OFF_XT = 0;                            // x_try of the current knot            (C -> A, B, C, D)
   static constexpr int OFF_UT = OFF_XT + NX * NL;             // control of the trial (unsquashed s)  (A -> D)
@@ -42,10 +54,30 @@ struct Roll6Smem {
   static constexpr int OFF_ELLF = OFF_ACC + DM::NACC * NL;    // frame-cost sum, by knot parity       (B -> D)
   static constexpr int OFF_VAL = OFF_ELLF + 2 * NL;           // activation value per cost            (D -> D)
   static constexpr int OFF_FLAG = OFF_VAL + EMPC_MAX_COSTS * NL;  // ok flag of role C
-  static constexpr int OFF_TB = OFF_FLAG + NL;                // trajectory index of each packed slot (ints)
-  static constexpr int OFF_NOM = OFF_TB + R6_GMAX;            // [2][GMAX][NOMSZ]
-  static constexpr int SIZE = (OFF_NOM + 2 * R6_GMAX * NOMSZ + 1) / 2 * 2;
+  static constexpr int OFF_DUMP = OFF_FLAG + NL;              // write-only: staging items without work land here (2 per lane)
+  static constexpr int OFF_TB = OFF_DUMP + 2 * NL;            // trajectory index of each packed slot (ints)
+  static constexpr int OFF_NOM = OFF_TB + R6_GMAX;            // [2][NOMSZ], 16-byte aligned
+  static constexpr int SIZE = (OFF_NOM + 2 * NOMSZ + 1) / 2 * 2;
+  static_assert(OFF_NOM % 2 == 0 && OFF_DUMP % 2 == 0 && KS % 2 == 0 && (NU * NDX) % 2 == 0, "gain rows are staged in 16-byte pieces");
 };
+
+// keeps the instruction scheduler from moving anything across this point (it otherwise sinks every staging load next to
+// its LDS write: load, wait, write, load, wait, write ... -- one exposed memory latency per item)
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+#define R6_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define R6_SCHED_FENCE() \
+  do {                   \
+  } while (0)
+#endif
+
+// 16-byte piece of a gain row; a native vector type so that an array of them lives in registers (a struct array stayed in
+// scratch memory: load, wait, scratch store, ..., scratch load, wait, LDS write)
+#if defined(__HIPCC__)
+typedef double R6Pair __attribute__((ext_vector_type(2)));
+#else
+typedef double R6Pair __attribute__((vector_size(16)));
+#endif
 
 // trajectories per wavefront for NA step lengths
 EMPC_HD int roll6_group_size(int NA) {
@@ -81,9 +113,10 @@ EMPC_HD Roll6Lane roll6_lane(const DevBuffers& D, const int* TB, int lane, int G
   return L;
 }
 
-// Exec concept: ex.role(w, f) runs f(lane, slot) on wavefront w only, ex.all(f) on every wavefront; ex.sync() is a
-// workgroup barrier.
-template <class DM, bool CT, class Exec>
+// One instantiation per role: a wavefront runs the whole rollout of ITS role (warp specialisation), so the registers of a
+// role hold that role's state only; the four instantiations execute the same sequence of workgroup barriers.
+// Exec concept: ex.each(f) runs f(lane, slot) on the lanes of the calling wavefront; ex.sync() is the workgroup barrier.
+template <class DM, bool CT, int ROLE, class Exec>
 EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N) {
   typedef Roll6Smem<DM> SM;
   constexpr int NX = DM::NX, NU = DM::NU, NV = DM::NV, NQ = DM::NQ, NDX = DM::NDX, REC = DM::REC, NB = DM::NB, NROT = DM::NROT;
@@ -108,7 +141,7 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
   const double dt = P.dt;
 
   // ---- packed slots -> trajectories ---------------------------------------------------------------------------------
-  ex.role(R6_A, [&](int lane, int sl) {
+  if constexpr (ROLE == R6_A) ex.each([&](int lane, int sl) {
     if (lane < R6_GMAX) {
       const int i = group * G + lane;
       TB[lane] = (lane < G && i < nlist) ? (D.act_list ? D.act_list[i] : i) : -1;
@@ -116,36 +149,123 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
   });
   ex.sync();
 
-  // nominal data of knot t for every packed trajectory -> staging buffer t & 1 (all lanes of the calling wavefront)
-  auto stage_nominal = [&](int t, int lane) {
-    double* dst = NOM + (size_t)(t & 1) * R6_GMAX * SM::NOMSZ;
-    const int per = (t < T) ? SM::NOMSZ : SM::NOM_US;  // the terminal node has no control / gains
-    for (int i = lane; i < G * SM::NOMSZ; i += NL) {
-      const int g = i / SM::NOMSZ, j = i % SM::NOMSZ;
-      const int b = TB[g];
-      if (b < 0 || j >= per || j >= SM::NOM_K + NU * NDX) continue;
-      double v;
-      if (j < SM::NOM_GAP)
-        v = D.xs[((size_t)b * (T + 1) + t) * NX + (j - SM::NOM_X)];
-      else if (j < SM::NOM_VF)
-        v = D.tape[((size_t)b * (T + 1) + t) * REC + DM::OFF_GAP + (j - SM::NOM_GAP)];
-      else if (j < SM::NOM_US)
-        v = D.Vf[((size_t)b * (T + 1) + t) * NDX + (j - SM::NOM_VF)];
-      else if (j < SM::NOM_KF)
-        v = D.us[((size_t)b * T + t) * NU + (j - SM::NOM_US)];
-      else if (j < SM::NOM_K)
-        v = D.kff[((size_t)b * T + t) * NU + (j - SM::NOM_KF)];
-      else
-        v = D.K[((size_t)b * T + t) * NU * NDX + (j - SM::NOM_K)];
-      dst[(size_t)g * SM::NOMSZ + j] = v;
+  // ---- staging of the nominal data: work items of this lane, fixed for the whole rollout ----------------------------------
+  // item = (element offset at knot 0 in its global array, offset inside one staging buffer); -1 = nothing to do.
+  // B moves the gain rows (16 bytes per item), D everything else (8 bytes per item).
+  int kI[Exec::SLOTS][SM::NKI], kO[Exec::SLOTS][SM::NKI];
+  int xI[Exec::SLOTS][SM::NXI], xO[Exec::SLOTS][SM::NXI], gI[Exec::SLOTS][SM::NGI], gO[Exec::SLOTS][SM::NGI];
+  int vI[Exec::SLOTS][SM::NGI], uI[Exec::SLOTS][SM::NUI], uO[Exec::SLOTS][SM::NUI];
+  if constexpr (ROLE == R6_B) ex.each([&](int lane, int sl) {
+#pragma unroll
+    for (int k = 0; k < SM::NKI; ++k) {
+      const int idx = lane + NL * k, g = idx / SM::KE, e = idx % SM::KE;
+      const int b = (g < G) ? TB[g] : -1;
+      kI[sl][k] = (b >= 0) ? (b * T * NU * NDX + 2 * e) : -1;
+      kO[sl][k] = SM::NOM_K + g * SM::KS + 2 * e;  // inside a staging buffer
+    }
+  });
+  if constexpr (ROLE == R6_A || ROLE == R6_D) ex.each([&](int lane, int sl) {
+#pragma unroll
+    for (int k = 0; k < SM::NXI; ++k) {
+      const int idx = lane + NL * k, g = idx / NX, e = idx % NX;
+      const int b = (g < G) ? TB[g] : -1;
+      xI[sl][k] = (b >= 0) ? (b * (T + 1) * NX + e) : -1;
+      xO[sl][k] = SM::NOM_X + g * SM::XS + e;
+    }
+#pragma unroll
+    for (int k = 0; k < SM::NGI; ++k) {
+      const int idx = lane + NL * k, g = idx / NDX, e = idx % NDX;
+      const int b = (g < G) ? TB[g] : -1;
+      gI[sl][k] = (b >= 0) ? (b * (T + 1) * REC + DM::OFF_GAP + e) : -1;
+      vI[sl][k] = (b >= 0) ? (b * (T + 1) * NDX + e) : -1;
+      gO[sl][k] = g * SM::GS + e;  // relative to NOM_GAP resp. NOM_VF
+    }
+#pragma unroll
+    for (int k = 0; k < SM::NUI; ++k) {
+      const int idx = lane + NL * k, g = idx / NU, e = idx % NU;
+      const int b = (g < G) ? TB[g] : -1;
+      uI[sl][k] = (b >= 0) ? (b * T * NU + e) : -1;
+      uO[sl][k] = g * SM::US + e;  // relative to NOM_US resp. NOM_KF
+    }
+  });
+  // the two halves of a transfer: loads into registers (issued first, in flight while the role computes), LDS writes last
+  R6Pair kV[Exec::SLOTS][SM::NKI];
+  double xV[Exec::SLOTS][SM::NXI], gV[Exec::SLOTS][SM::NGI], vV[Exec::SLOTS][SM::NGI], uV[Exec::SLOTS][SM::NUI], fV[Exec::SLOTS][SM::NUI];
+  // (loads AND LDS writes are unconditional -- an item without work reads element 0 of its array and writes to a dump
+  // slot -- so that the compiler issues all loads back to back; a predicated write makes it sink each load into the
+  // predicated block and wait for it there, one memory latency per item: measured 9k cycles per knot)
+  double* const dumpl = N + SM::OFF_DUMP;
+  auto fetch_gains = [&](int t, int sl) {  // K[t], t < T
+#pragma unroll
+    for (int k = 0; k < SM::NKI; ++k) {
+      const size_t o = (kI[sl][k] >= 0) ? (size_t)kI[sl][k] + (size_t)t * NU * NDX : 0;
+      kV[sl][k] = *reinterpret_cast<const R6Pair*>(D.K + o);
     }
   };
-  ex.role(R6_D, [&](int lane, int sl) { stage_nominal(0, lane); });
+  auto put_gains = [&](int t, int lane, int sl) {
+    double* dst = NOM + (size_t)(t & 1) * SM::NOMSZ;
+#pragma unroll
+    for (int k = 0; k < SM::NKI; ++k)
+      *reinterpret_cast<R6Pair*>((kI[sl][k] >= 0) ? dst + kO[sl][k] : dumpl + 2 * lane) = kV[sl][k];
+  };
+  // A moves xs, Vxx f, us and k of the next knot while it waits for C in phase II; D moves the gaps in phase I (C contracts
+  // the next trial state towards them right after the barrier)
+  auto fetch_nom = [&](int t, int sl) {
+#pragma unroll
+    for (int k = 0; k < SM::NXI; ++k) xV[sl][k] = D.xs[(xI[sl][k] >= 0) ? (size_t)xI[sl][k] + (size_t)t * NX : 0];
+#pragma unroll
+    for (int k = 0; k < SM::NGI; ++k) vV[sl][k] = D.Vf[(gI[sl][k] >= 0) ? (size_t)vI[sl][k] + (size_t)t * NDX : 0];
+    if (t < T) {
+#pragma unroll
+      for (int k = 0; k < SM::NUI; ++k) {
+        const size_t o = (uI[sl][k] >= 0) ? (size_t)uI[sl][k] + (size_t)t * NU : 0;
+        uV[sl][k] = D.us[o];
+        fV[sl][k] = D.kff[o];
+      }
+    }
+  };
+  auto put_nom = [&](int t, int lane, int sl) {
+    double* dst = NOM + (size_t)(t & 1) * SM::NOMSZ;
+#pragma unroll
+    for (int k = 0; k < SM::NXI; ++k) *((xI[sl][k] >= 0) ? dst + xO[sl][k] : dumpl + lane) = xV[sl][k];
+#pragma unroll
+    for (int k = 0; k < SM::NGI; ++k) *((gI[sl][k] >= 0) ? dst + SM::NOM_VF + gO[sl][k] : dumpl + lane) = vV[sl][k];
+    if (t < T) {
+#pragma unroll
+      for (int k = 0; k < SM::NUI; ++k) {
+        *((uI[sl][k] >= 0) ? dst + SM::NOM_US + uO[sl][k] : dumpl + lane) = uV[sl][k];
+        *((uI[sl][k] >= 0) ? dst + SM::NOM_KF + uO[sl][k] : dumpl + lane) = fV[sl][k];
+      }
+    }
+  };
+  auto fetch_gap = [&](int t, int sl) {
+#pragma unroll
+    for (int k = 0; k < SM::NGI; ++k) gV[sl][k] = D.tape[(gI[sl][k] >= 0) ? (size_t)gI[sl][k] + (size_t)t * REC : 0];
+  };
+  auto put_gap = [&](int t, int lane, int sl) {
+    double* dst = NOM + (size_t)(t & 1) * SM::NOMSZ;
+#pragma unroll
+    for (int k = 0; k < SM::NGI; ++k) *((gI[sl][k] >= 0) ? dst + SM::NOM_GAP + gO[sl][k] : dumpl + lane) = gV[sl][k];
+  };
+  if constexpr (ROLE == R6_B) ex.each([&](int lane, int sl) {
+    if (T > 0) {
+      fetch_gains(0, sl);
+      put_gains(0, lane, sl);
+    }
+  });
+  if constexpr (ROLE == R6_A) ex.each([&](int lane, int sl) {
+    fetch_nom(0, sl);
+    put_nom(0, lane, sl);
+  });
+  if constexpr (ROLE == R6_D) ex.each([&](int lane, int sl) {
+    fetch_gap(0, sl);
+    put_gap(0, lane, sl);
+  });
   ex.sync();
 
   // every wavefront keeps the same lane -> (trajectory, step length) view in registers
   Roll6Lane LL[Exec::SLOTS];
-  ex.all([&](int lane, int sl) { LL[sl] = roll6_lane(D, TB, lane, G); });
+  ex.each([&](int lane, int sl) { LL[sl] = roll6_lane(D, TB, lane, G); });
 
   // ---- per-role state that lives across the knots -----------------------------------------------------------------------
   double dvA[Exec::SLOTS];                    // A: -f^T Vxx (xs (-) xs_try) summed over the knots
@@ -155,11 +275,11 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
   int okD[Exec::SLOTS];
 
   // x_try of knot 0 (C): x0, contracted towards the nominal start by the gap when the pass keeps gaps
-  ex.role(R6_C, [&](int lane, int sl) {
+  if constexpr (ROLE == R6_C) ex.each([&](int lane, int sl) {
     const Roll6Lane& L = LL[sl];
     okC[sl] = 1;
     if (!L.live) return;
-    const double* nom = NOM + (size_t)L.g * SM::NOMSZ;
+    const double* gap0 = NOM + SM::NOM_GAP + L.g * SM::GS;  // staging buffer 0
     double xn[NX], xt[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) xn[i] = D.x0[(size_t)L.b * NX + i];
@@ -169,14 +289,14 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
     } else {
       double step[NDX];
 #pragma unroll
-      for (int i = 0; i < NDX; ++i) step[i] = nom[SM::NOM_GAP + i] * (L.alpha - 1.0);
+      for (int i = 0; i < NDX; ++i) step[i] = gap0[i] * (L.alpha - 1.0);
       state_integrate<DM>(xn, step, xt, nullptr);
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i) XT[i * NL + lane] = xt[i];
   });
-  ex.role(R6_A, [&](int lane, int sl) { dvA[sl] = 0.0; });
-  ex.role(R6_D, [&](int lane, int sl) {
+  if constexpr (ROLE == R6_A) ex.each([&](int lane, int sl) { dvA[sl] = 0.0; });
+  if constexpr (ROLE == R6_D) ex.each([&](int lane, int sl) {
     costD[sl] = 0.0;
     okD[sl] = 1;
   });
@@ -184,18 +304,18 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
 
   // cost of knot tp for D's lane, from the values D left in VAL, the contact force in ACC and B's frame-cost sum
   auto finish_cost = [&](int tp, int lane, int sl, const Roll6Lane& L) {
-    const EMPC_K EmpcCostSet& set = EMPC_KPTR(EmpcCostSet, D.sets)[EMPC_KPTR(int, D.knot_set)[tp]];
+    const int kset = EMPC_KPTR(int, D.knot_set)[tp];
+    const EMPC_K EmpcCostSet& set = EMPC_KPTR(EmpcCostSet, D.sets)[kset];
+    const EMPC_K SetInfo& si = EMPC_KPTR(SetInfo, D.set_info)[kset];
     const bool terminal = (tp == T);
     const bool use_contact = CT && P.has_contact && set.ncontacts > 0;
     double ell = 0;
-    for (int ci = 0; ci < set.ncosts; ++ci) {
-      const auto& c = set.costs[ci];
-      if (!c.active) continue;
-      if (c.type == EMPC_COST_STATE || c.type == EMPC_COST_CONTROL) ell += c.weight * VAL[ci * NL + lane];
+    for (int k = 0; k < si.n_sc; ++k) {
+      const int ci = si.sc_ci[k];
+      ell += set.costs[ci].weight * VAL[ci * NL + lane];
     }
-    for (int ci = 0; ci < set.ncosts; ++ci) {
-      const auto& c = set.costs[ci];
-      if (!c.active || c.type != EMPC_COST_CONTACT_FRICTION_CONE) continue;
+    for (int k = 0; k < si.n_cone; ++k) {
+      const auto& c = set.costs[si.cone_ci[k]];
       double lam[3], r[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
       for (int i = 0; i < 3; ++i) lam[i] = ACC[(NV + i) * NL + lane];
@@ -214,32 +334,65 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
     for (int i = 0; i < DM::NACC; ++i) ac_o[i] = ACC[i * NL + lane];
   };
 
+#if defined(EMPC_STAMPS) && defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+  // diagnostic builds: cycles of this role in {phase I work, wait at barrier 1, phase II work, wait at barrier 2}
+  unsigned long long r6st[5] = {0, 0, 0, 0, __builtin_readcyclecounter()};
+#define R6_STAMP(i)                                                 \
+  do {                                                              \
+    const unsigned long long now_ = __builtin_readcyclecounter();   \
+    r6st[i] += now_ - r6st[4];                                      \
+    r6st[4] = now_;                                                 \
+  } while (0)
+  unsigned long long r6b[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define R6_SUB(i)                                                   \
+  do {                                                              \
+    __builtin_amdgcn_sched_barrier(0);                              \
+    const unsigned long long now_ = __builtin_readcyclecounter();   \
+    r6b[i] += now_ - r6b[7];                                        \
+    r6b[7] = now_;                                                  \
+    __builtin_amdgcn_sched_barrier(0);                              \
+  } while (0)
+#else
+#define R6_STAMP(i) \
+  do {              \
+  } while (0)
+#define R6_SUB(i) \
+  do {            \
+  } while (0)
+#endif
   for (int t = 0; t <= T; ++t) {
-    const EMPC_K EmpcCostSet& set = EMPC_KPTR(EmpcCostSet, D.sets)[EMPC_KPTR(int, D.knot_set)[t]];
+    const int kset = EMPC_KPTR(int, D.knot_set)[t];
+    const EMPC_K EmpcCostSet& set = EMPC_KPTR(EmpcCostSet, D.sets)[kset];
+    const EMPC_K SetInfo& si = EMPC_KPTR(SetInfo, D.set_info)[kset];
     const bool terminal = (t == T);
     const bool use_contact = CT && P.has_contact && set.ncontacts > 0;
     // =============================================== phase I ===========================================================
     // ---- A: state difference to the nominal trajectory, feedback, squashing, generalized force ----------------------------
-    ex.role(R6_A, [&](int lane, int sl) {
+    if constexpr (ROLE == R6_A) ex.each([&](int lane, int sl) {
       const Roll6Lane& L = LL[sl];
       if (!L.live) return;
-      const double* nom = NOM + ((size_t)(t & 1) * R6_GMAX + L.g) * SM::NOMSZ;
+      const double* nom = NOM + (size_t)(t & 1) * SM::NOMSZ;
+      const double* n_x = nom + SM::NOM_X + L.g * SM::XS;
+      const double* n_vf = nom + SM::NOM_VF + L.g * SM::GS;
+      const double* n_us = nom + SM::NOM_US + L.g * SM::US;
+      const double* n_kf = nom + SM::NOM_KF + L.g * SM::US;
+      const double* n_K = nom + SM::NOM_K + L.g * SM::KS;
       double x[NX], dx[NDX], s[NU], u[NU], tau[NV];
 #pragma unroll
       for (int i = 0; i < NX; ++i) x[i] = XT[i * NL + lane];
-      state_diff<DM>(nom + SM::NOM_X, x, dx, nullptr);
+      state_diff<DM>(n_x, x, dx, nullptr);
       if (L.need_dv) {
         double dv = dvA[sl];
 #pragma unroll
-        for (int i = 0; i < NDX; ++i) dv += nom[SM::NOM_VF + i] * dx[i];  // +(Vxx f).(xs_try (-) xs)
+        for (int i = 0; i < NDX; ++i) dv += n_vf[i] * dx[i];  // +(Vxx f).(xs_try (-) xs)
         dvA[sl] = dv;
       }
       if (!terminal) {
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
-          double a_ = nom[SM::NOM_US + i] - nom[SM::NOM_KF + i] * L.alpha;
+          double a_ = n_us[i] - n_kf[i] * L.alpha;
 #pragma unroll
-          for (int j = 0; j < NDX; ++j) a_ -= nom[SM::NOM_K + i * NDX + j] * dx[j];
+          for (int j = 0; j < NDX; ++j) a_ -= n_K[i * NDX + j] * dx[j];
           s[i] = a_;
         }
       } else {
@@ -278,9 +431,10 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
       for (int i = 0; i < NU; ++i) UT[i * NL + lane] = s[i];
     });
     // ---- B: bias forces with the frame captures; frame costs; contact frame for C ------------------------------------------
-    ex.role(R6_B, [&](int lane, int sl) {
+    if constexpr (ROLE == R6_B) ex.each([&](int lane, int sl) {
       const Roll6Lane& L = LL[sl];
-      if (!L.live) return;
+      R6_SUB(6);
+      if (L.live) {
       double x[NX];
 #pragma unroll
       for (int i = 0; i < NX; ++i) x[i] = XT[i * NL + lane];
@@ -290,47 +444,19 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
       quat_to_R(q + 3, R0);
 #pragma unroll
       for (int b = 1; b < NB; ++b) fsincos(q[7 + b - 1], &sn[b - 1], &cs[b - 1]);
-      // frames referenced by this node's costs / contacts (same scan as node_nominal)
-      int capf[NCAP] = {0, 0};
-      int ncap = 0;
-      for (int ci = 0; ci < set.ncosts; ++ci) {
-        const auto& c = set.costs[ci];
-        if (!c.active || c.frame < 0 || c.type == EMPC_COST_CONTACT_FRICTION_CONE) continue;
-        bool seen = false;
+      // operational frames this node captures (frame costs, contact): the host made the list (SetInfo), same order as the
+      // table scan of node_nominal
+      int capf[NCAP];
 #pragma unroll
-        for (int k = 0; k < NCAP; ++k) seen = seen || (k < ncap && capf[k] == c.frame);
-        if (!seen) {
-#pragma unroll
-          for (int k = 0; k < NCAP; ++k)
-            if (k == ncap) capf[k] = c.frame;
-          ncap = (ncap < NCAP) ? ncap + 1 : ncap;
-        }
-      }
-      int ccap = 0;
-      if constexpr (CT) {
-        if (use_contact) {
-          const int cframe = set.contacts[0].frame;
-          bool seen = false;
-#pragma unroll
-          for (int k = 0; k < NCAP; ++k)
-            if (k < ncap && capf[k] == cframe) {
-              seen = true;
-              ccap = k;
-            }
-          if (!seen) {
-#pragma unroll
-            for (int k = 0; k < NCAP; ++k)
-              if (k == ncap) capf[k] = cframe;
-            ccap = ncap;
-            ncap = (ncap < NCAP) ? ncap + 1 : ncap;
-          }
-        }
-      }
+      for (int k = 0; k < NCAP; ++k) capf[k] = si.capf[k];
+      const int ncap = si.ncap, ccap = si.ccap;
       FrameCap<double> caps[NCAP];
       double zero[NV], h[NV];
 #pragma unroll
       for (int i = 0; i < NV; ++i) zero[i] = 0.0;
+      R6_SUB(1);
       rnea_chain<NB, double>(m, R0, q, cs, sn, v, zero, true, -1, nullptr, h, ncap, capf, caps);
+      R6_SUB(2);
 #pragma unroll
       for (int i = 0; i < NV; ++i) HB[i * NL + lane] = h[i];
       if constexpr (CT) {
@@ -349,12 +475,11 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
           for (int i = 0; i < 6; ++i) CAP[(18 + i) * NL + lane] = ck.a[i];
         }
       }
+      R6_SUB(3);
       // frame costs (value only), summed in cost order
       double ell_frames = 0;
-      for (int ci = 0; ci < set.ncosts; ++ci) {
-        const auto& c = set.costs[ci];
-        if (!c.active || c.type == EMPC_COST_STATE || c.type == EMPC_COST_CONTROL || c.type == EMPC_COST_CONTACT_FRICTION_CONE)
-          continue;
+      for (int kf = 0; kf < si.n_frame; ++kf) {
+        const auto& c = set.costs[si.frame_ci[kf]];
         double cval = 0;
         {
           FrameCap<double> fk = caps[0];
@@ -393,9 +518,11 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
         ell_frames += c.weight * cval;
       }
       ELLF[(t & 1) * NL + lane] = ell_frames;
+      R6_SUB(4);
+      }
     });
     // ---- C: joint-space inertia and its Cholesky factor ------------------------------------------------------------------------
-    ex.role(R6_C, [&](int lane, int sl) {
+    if constexpr (ROLE == R6_C) ex.each([&](int lane, int sl) {
       const Roll6Lane& L = LL[sl];
       if (!L.live) return;
       double cs[NB], sn[NB];
@@ -405,8 +532,10 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
       chol_packed<NV>(Lc[sl]);
     });
     // ---- D: cost of the previous knot, State costs of this one, stores, staging of the next knot's nominal data ----------------
-    ex.role(R6_D, [&](int lane, int sl) {
+    if constexpr (ROLE == R6_D) ex.each([&](int lane, int sl) {
       const Roll6Lane& L = LL[sl];
+      if (t < T) fetch_gap(t + 1, sl);  // in flight behind the State costs
+      R6_SCHED_FENCE();
       if (L.live) {
         if (t > 0) finish_cost(t - 1, lane, sl, L);
         double x[NX];
@@ -417,9 +546,9 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
         for (int i = 0; i < NX; ++i) xs_o[i] = x[i];
         double rstate[NDX];
         int rstate_of = -1;
-        for (int ci = 0; ci < set.ncosts; ++ci) {
+        for (int ks = 0; ks < si.n_state; ++ks) {
+          const int ci = si.state_ci[ks];
           const auto& c = set.costs[ci];
-          if (!c.active || c.type != EMPC_COST_STATE) continue;
           if (!(c.ref_share >= 0 && c.ref_share == rstate_of)) {
             state_diff<DM>(c.ref, x, rstate, nullptr);
             rstate_of = (c.ref_share >= 0) ? c.ref_share : ci;
@@ -427,12 +556,15 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
           VAL[ci * NL + lane] = activation_value<NDX>(c, rstate, NDX);
         }
       }
-      if (t < T) stage_nominal(t + 1, lane);
+      R6_SCHED_FENCE();
+      if (t < T) put_gap(t + 1, lane, sl);
     });
+    R6_STAMP(0);
     ex.sync();
+    R6_STAMP(1);
     // =============================================== phase II ==========================================================
     // ---- C: acceleration, contact, Euler step, next trial state -------------------------------------------------------------
-    ex.role(R6_C, [&](int lane, int sl) {
+    if constexpr (ROLE == R6_C) ex.each([&](int lane, int sl) {
       const Roll6Lane& L = LL[sl];
       if (!L.live) return;
       double x[NX], a[NV], lam[6] = {0, 0, 0, 0, 0, 0};
@@ -484,27 +616,42 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
 #pragma unroll
           for (int i = 0; i < NX; ++i) xt[i] = xn[i];
         } else {
-          const double* nomn = NOM + ((size_t)((t + 1) & 1) * R6_GMAX + L.g) * SM::NOMSZ;
+          const double* gapn = NOM + (size_t)((t + 1) & 1) * SM::NOMSZ + SM::NOM_GAP + L.g * SM::GS;
           double step[NDX];
 #pragma unroll
-          for (int i = 0; i < NDX; ++i) step[i] = nomn[SM::NOM_GAP + i] * (L.alpha - 1.0);
+          for (int i = 0; i < NDX; ++i) step[i] = gapn[i] * (L.alpha - 1.0);
           state_integrate<DM>(xn, step, xt, nullptr);
         }
 #pragma unroll
         for (int i = 0; i < NX; ++i) XT[i * NL + lane] = xt[i];
       }
     });
+    // ---- B: next knot's gain rows into the staging buffer (A reads them in phase I of the next knot) ---------------------------
+    if constexpr (ROLE == R6_B) ex.each([&](int lane, int sl) {
+      if (t + 1 < T) {
+        fetch_gains(t + 1, sl);
+        R6_SCHED_FENCE();
+        put_gains(t + 1, lane, sl);
+      }
+    });
+    // ---- A: the rest of the next knot's nominal data (xs, Vxx f, us, k) -------------------------------------------------------
+    if constexpr (ROLE == R6_A) ex.each([&](int lane, int sl) {
+      if (t < T) {
+        fetch_nom(t + 1, sl);
+        R6_SCHED_FENCE();
+        put_nom(t + 1, lane, sl);
+      }
+    });
     // ---- D: Control costs of this knot, control of the trial to memory -----------------------------------------------------------
-    ex.role(R6_D, [&](int lane, int sl) {
+    if constexpr (ROLE == R6_D) ex.each([&](int lane, int sl) {
       const Roll6Lane& L = LL[sl];
       if (!L.live) return;
       double s[NU];
 #pragma unroll
       for (int i = 0; i < NU; ++i) s[i] = terminal ? 0.0 : UT[i * NL + lane];
-      for (int ci = 0; ci < set.ncosts; ++ci) {
-        const auto& c = set.costs[ci];
-        if (!c.active || c.type != EMPC_COST_CONTROL) continue;
-        VAL[ci * NL + lane] = control_cost_value<NU>(c, s, L.smooth, P);
+      for (int kc = 0; kc < si.n_ctrl; ++kc) {
+        const int ci = si.ctrl_ci[kc];
+        VAL[ci * NL + lane] = control_cost_value<NU>(set.costs[ci], s, L.smooth, P);
       }
       if (!terminal) {
         double* us_o = D.us_try + ((size_t)L.b * NA + L.ai) * T * NU + (size_t)t * NU;
@@ -512,16 +659,27 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
         for (int i = 0; i < NU; ++i) us_o[i] = s[i];
       }
     });
+    R6_STAMP(2);
     ex.sync();
+    R6_STAMP(3);
   }
+#if defined(EMPC_STAMPS) && defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+  if (group == 0 && D.dbg)
+    ex.each([&](int lane, int sl) {
+      if (lane == 0)
+        for (int i = 0; i < 4; ++i) D.dbg[48 + ROLE * 4 + i] = r6st[i];
+      if (lane == 0 && ROLE == R6_B)
+        for (int i = 0; i < 7; ++i) D.dbg[i] = r6b[i];
+    });
+#endif
   // ---- results of the trials -------------------------------------------------------------------------------------------------------
-  ex.role(R6_C, [&](int lane, int sl) { FLAG[lane] = okC[sl] ? 1.0 : 0.0; });
-  ex.role(R6_A, [&](int lane, int sl) {
+  if constexpr (ROLE == R6_C) ex.each([&](int lane, int sl) { FLAG[lane] = okC[sl] ? 1.0 : 0.0; });
+  if constexpr (ROLE == R6_A) ex.each([&](int lane, int sl) {
     const Roll6Lane& L = LL[sl];
     if (L.live) D.try_dv[(size_t)L.b * NA + L.ai] = dvA[sl];
   });
   ex.sync();
-  ex.role(R6_D, [&](int lane, int sl) {
+  if constexpr (ROLE == R6_D) ex.each([&](int lane, int sl) {
     const Roll6Lane& L = LL[sl];
     if (!L.live) return;
     finish_cost(T, lane, sl, L);

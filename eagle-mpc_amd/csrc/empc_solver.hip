@@ -54,6 +54,7 @@ struct EmpcSolver {
   DevBuffers D;
   DevProblem* dP = nullptr;
   EmpcCostSet* dsets = nullptr;
+  SetInfo* dset_info = nullptr;
   int* dknot = nullptr;
   int* dlin_knots = nullptr;
   int* dlin_list = nullptr;  // [2][B] linearize lists of the two sweep slots
@@ -100,6 +101,7 @@ struct EmpcSolver {
 static void upload_problem(EmpcSolver* s) {
   HIP_CHECK(hipMemcpyAsync(s->dP, &s->H.P, sizeof(DevProblem), hipMemcpyHostToDevice, s->stream));
   HIP_CHECK(hipMemcpyAsync(s->dsets, s->H.sets.data(), sizeof(EmpcCostSet) * s->H.sets.size(), hipMemcpyHostToDevice, s->stream));
+  HIP_CHECK(hipMemcpyAsync(s->dset_info, s->H.set_info.data(), sizeof(SetInfo) * s->H.set_info.size(), hipMemcpyHostToDevice, s->stream));
   HIP_CHECK(hipMemcpyAsync(s->dknot, s->H.knot_set.data(), sizeof(int) * s->H.knot_set.size(), hipMemcpyHostToDevice, s->stream));
   {
     std::vector<int> order;
@@ -197,10 +199,12 @@ EmpcSolver* empc_solver_create(const EmpcProblemDesc* problem, const EmpcSolverP
   const KernelTable& k = s->kt;
   s->dP = s->dalloc<DevProblem>(1);
   s->dsets = s->dalloc<EmpcCostSet>(s->H.sets.size());
+  s->dset_info = s->dalloc<SetInfo>(s->H.sets.size());
   s->dknot = s->dalloc<int>(T + 1);
   DevBuffers& D = s->D;
   D.P = s->dP;
   D.sets = s->dsets;
+  D.set_info = s->dset_info;
   D.knot_set = s->dknot;
   s->dlin_knots = s->dalloc<int>(T + 1);
   D.lin_knots = s->dlin_knots;

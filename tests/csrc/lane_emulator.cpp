@@ -2,7 +2,9 @@
 // It executes exactly the code the GPU executes (same templates), one lane after another, so that the kernels' index
 // arithmetic and staging logic can be checked against the oracle on machines without a GPU.  It is NOT a product path:
 // nothing in the package loads it, and libempc.so never falls back to it.
+#include <barrier>
 #include <cstdio>
+#include <thread>
 #include <cstring>
 #include <vector>
 
@@ -45,19 +47,27 @@ struct CpuExec {
   }
 };
 
-// role-split kernels: the four wavefronts of a workgroup one after another (roles of a phase are independent)
+// role-split kernels (warp specialisation): the four role wavefronts of a workgroup run as four host threads that meet
+// at a real barrier wherever the kernel has its workgroup barrier
 struct CpuRoleExec {
   static constexpr int SLOTS = 64;
+  std::barrier<>* bar;
   template <class F>
-  void role(int, F&& f) {
+  void each(F&& f) {
     for (int l = 0; l < 64; ++l) f(l, l);
   }
-  template <class F>
-  void all(F&& f) {
-    for (int l = 0; l < 64; ++l) f(l, l);
-  }
-  void sync() {}
+  void sync() { bar->arrive_and_wait(); }
 };
+template <class DM, bool CT>
+static void emu_rollout_group6(const DevBuffers& D, int grp, double* smem) {
+  std::barrier<> bar(R6_WAVES);
+  std::thread th[R6_WAVES];
+  th[0] = std::thread([&] { CpuRoleExec ex{&bar}; rollout_group6<DM, CT, R6_A>(ex, D, grp, smem); });
+  th[1] = std::thread([&] { CpuRoleExec ex{&bar}; rollout_group6<DM, CT, R6_B>(ex, D, grp, smem); });
+  th[2] = std::thread([&] { CpuRoleExec ex{&bar}; rollout_group6<DM, CT, R6_C>(ex, D, grp, smem); });
+  th[3] = std::thread([&] { CpuRoleExec ex{&bar}; rollout_group6<DM, CT, R6_D>(ex, D, grp, smem); });
+  for (auto& t : th) t.join();
+}
 
 struct Emu {
   HostProblem H;
@@ -100,6 +110,7 @@ static void emu_alloc(Emu& e) {
   DevBuffers& D = e.D;
   D.P = &e.H.P;
   D.sets = e.H.sets.data();
+  D.set_info = e.H.set_info.data();
   D.knot_set = e.H.knot_set.data();
   D.st = e.st.data();
   D.x0 = e.x0.data();
@@ -193,14 +204,13 @@ static void emu_rollout(Emu& e) {
     const int G = roll6_group_size(e.NA);
     std::vector<double> smem6(Roll6Smem<DM>::SIZE);
     for (int grp = 0; grp * G < e.B; ++grp) {
-      CpuRoleExec ex;
       if constexpr (DM::NB == 4) {
         if (ct) {
-          rollout_group6<DM, true>(ex, e.D, grp, smem6.data());
+          emu_rollout_group6<DM, true>(e.D, grp, smem6.data());
           continue;
         }
       }
-      rollout_group6<DM, false>(ex, e.D, grp, smem6.data());
+      emu_rollout_group6<DM, false>(e.D, grp, smem6.data());
     }
     return;
   }

@@ -22,7 +22,7 @@ def emu(empc):
     hdrs = [os.path.join(ROOT, "eagle-mpc_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "eagle-mpc_amd", "csrc"))
             if f.endswith(".hpp")] + [os.path.join(ROOT, "include", "empc_types.h")]
     if not os.path.exists(EMU) or any(os.path.getmtime(h) > os.path.getmtime(EMU) for h in hdrs + [src]):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"), src,
+        subprocess.check_call(["g++", "-O2", "-std=c++20", "-pthread", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"), src,
                                "-o", EMU])
     L = C.CDLL(EMU)
     L.emu_create.restype = C.c_void_p

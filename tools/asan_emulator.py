@@ -11,7 +11,7 @@ import sys, os, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 LIB = '/tmp/liblane_emulator_asan.so'
-subprocess.check_call(['g++', '-O1', '-g', '-std=c++17', '-fPIC', '-shared', '-fsanitize=address,undefined', '-fno-omit-frame-pointer',
+subprocess.check_call(['g++', '-O1', '-g', '-std=c++20', '-pthread', '-fPIC', '-shared', '-fsanitize=address,undefined', '-fno-omit-frame-pointer',
                        '-I' + os.path.join(ROOT, 'include'), os.path.join(ROOT, 'tests', 'csrc', 'lane_emulator.cpp'), '-o', LIB])
 import empc_loader, oracle_binding as ob
 empc = empc_loader.load()

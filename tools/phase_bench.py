@@ -38,11 +38,14 @@ units = {"linearize": B * (d.T + 1), "backward": B * d.T, "rollout": B * 10 * (d
 out = {k: {"ms": v, "GBs": units[k] * w[k] * 8 / (v * 1e-3) / 1e9} for k, v in res.items()}
 print(json.dumps(out))
 import ctypes as C
-cnt = (C.c_ulonglong * 48)()
+cnt = (C.c_ulonglong * 64)()
 empc.lib().empc_solver_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
-empc.lib().empc_solver_debug_counters(s._h, cnt, 48)
+empc.lib().empc_solver_debug_counters(s._h, cnt, 64)
 print('stage cycles (EMPC_STAMPS builds; rollout v1, trajectory 0, alpha 1/2): feedback|prep|rnea|crba|chol|kkt|euler|costs|-|tail', list(cnt)[:10])
 
 
 print('linearize stage cycles (unit b=0,t=10): S0 load|S1 squash/trig|S2 nominal+Euler|S3 tangent|S4 chol|S5 solves+Fx,Fu|S6 state costs (column sums)|ctrl costs|frame costs|S7 store|S6 staging|S6 nominal parts|S2 nominal chain only|S6 activations', list(cnt)[32:46])
 print('backward stage cycles (trajectory 0, EMPC_STAMPS builds): load|W|Q|gains|Vxx|sym|gap|looptop', list(cnt)[16:24])
+print('rollout6 role cycles per rollout (EMPC_STAMPS builds; workgroup 0): role A|B|C|D x {phase I work, wait 1, phase II work, wait 2}',
+      [list(cnt)[48 + 4 * r:52 + 4 * r] for r in range(4)])
+print('rollout6 role B sub-stages (cycles per rollout): fetch issue|quat,trig,scan|rnea|H,CAP writes|frame costs|-|outside', list(cnt)[0:7])
