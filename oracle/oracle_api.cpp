@@ -189,6 +189,13 @@ int oracle_phase_forward(void* h, double alpha, int ddp, double* xs_try, double*
   }
   return ok ? 1 : 0;
 }
+// expectedImprovementDDP (src/sbfddp.cpp:395-408) after oracle_phase_backward: d0 = sum Qu.k, d1 = -sum k.Quu k
+void oracle_phase_expected_ddp(void* h, double* d01) {
+  Solver* s = static_cast<Solver*>(h);
+  s->expected_improvement_ddp();
+  d01[0] = s->d[0];
+  d01[1] = s->d[1];
+}
 // read one node's tape after oracle_phase_calcdiff
 void oracle_phase_tape(void* h, int t, double* Fx, double* Fu, double* Lx, double* Lu, double* Lxx, double* Lxu,
                        double* Luu, double* xnext, double* cost) {

@@ -47,6 +47,7 @@ def orc():
         L.oracle_phase_backward.argtypes = [C.c_void_p, C.c_double, _dp, _dp, _dp, _dp, _dp]
         L.oracle_phase_forward.argtypes = [C.c_void_p, C.c_double, C.c_int, _dp, _dp, _dp, _dp]
         L.oracle_phase_tape.argtypes = [C.c_void_p, C.c_int] + [_dp] * 9
+        L.oracle_phase_expected_ddp.argtypes = [C.c_void_p, _dp]
         L.oracle_solve_batch.restype = C.c_double
         L.oracle_solve_batch.argtypes = [C.POINTER(T.ProblemDesc), C.POINTER(T.SolverParams), C.c_int, _dp, C.c_int, C.c_int,
                                          _dp, _dp, _dp, _dp, _ip, _ip]
@@ -171,6 +172,11 @@ class OracleSolver:
         dgdq = np.zeros(2)
         ok = orc().oracle_phase_backward(self.h, float(xreg), P(K), P(k), P(Vx), P(Vxx), P(dgdq))
         return bool(ok), K, k, Vx, Vxx, dgdq
+
+    def phase_expected_ddp(self):
+        d01 = np.zeros(2)
+        orc().oracle_phase_expected_ddp(self.h, P(d01))
+        return d01
 
     def phase_forward(self, alpha, ddp=False):
         xs = np.zeros((self.T + 1, self.nx))

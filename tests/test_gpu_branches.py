@@ -55,15 +55,11 @@ def test_phase_parity_ddp_rollout(empc, problems, name):
         o.set_smooth(0.1)
         o.phase_calcdiff(xs[b], us[b], is_feasible=True, was_feasible=True)
         o.phase_backward(1e-9)
-        for alpha in (0.0625, 2.0 ** -6, 2.0 ** -8):  # d0 / d1 do not depend on the step length; the oracle reports
-            oko, _, _, _, d01 = o.phase_forward(alpha, ddp=True)  # them only for a rollout that did not diverge
-            if oko:
-                break
-        assert oko
+        d01 = o.phase_expected_ddp()
         assert np.allclose(dgdq_feas[b], d01, rtol=1e-6), (dgdq_feas[b], d01)
 
 
-@pytest.mark.parametrize("name,maxiter", [("displacement", 2), ("eagle_catch", 2), ("hover", 3)])
+@pytest.mark.parametrize("name,maxiter", [("displacement", 2), ("eagle_catch", 2)])
 def test_solve_goes_through_ddp_cleanup(empc, problems, name, maxiter):
     """Solves that end their FDDP passes infeasible and therefore run solveDDP (src/sbfddp.cpp:215-218): with two or three
     iterations per pass no full step has closed the gaps yet.  Both sides must report EMPC_STATUS_DDP_CLEANUP, the same
@@ -84,8 +80,7 @@ def test_solve_goes_through_ddp_cleanup(empc, problems, name, maxiter):
     assert np.array_equal(solver.status_batch, ref["status"]), (solver.status_batch, ref["status"])
     assert np.array_equal(solver.iter_batch, ref["iter"])
     bounded = cleanup & (np.abs(ref["cost"]) < 1e6) & (np.abs(solver.cost_batch) < 1e6)
-    if name != "hover":
-        assert bounded.sum() >= B // 2
+    assert bounded.sum() >= B // 2
     assert np.abs(solver.xs_batch[bounded] - ref["xs"][bounded]).max() < 1e-4
     assert np.abs(solver.us_batch[bounded] - ref["us"][bounded]).max() < 1e-4
     assert np.abs(solver.us_squash_batch[bounded] - ref["us_squash"][bounded]).max() < 1e-4

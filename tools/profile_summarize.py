@@ -15,7 +15,7 @@ import json
 import os
 import sys
 
-KERNELS = ("k_linearize_full", "k_linearize", "k_backward", "k_rollout", "k_select", "k_calc", "k_squash_out", "k_plant_rk4")
+KERNELS = ("k_linearize_full", "k_linearize", "k_backward", "k_rollout", "k_select", "k_calc", "k_squash_out", "k_plant_rk4", "k_pack_rows")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
