@@ -13,6 +13,7 @@ import os
 import numpy as np
 
 from . import ctypes_defs as T
+from . import utils  # CallbackLogger / saveLogfile with the reference's layout
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, "libempc.so")
