@@ -85,6 +85,11 @@ struct DevBuffers {
   const int* act_list = nullptr;
   const int* act_count = nullptr;
   int* act_list_out = nullptr;
+  // hand-over of the counters without host commands in the stream: select zeroes the counters of the NEXT sweep's slot
+  // (nobody reads them any more) and the last workgroup to finish publishes the active count to pinned host memory
+  int* counters_next = nullptr;   // {n_active, lin_count} of the other sweep slot
+  int* done_ticket = nullptr;     // workgroups of this select that have finished
+  int* host_active = nullptr;     // host-visible copy of n_active of this sweep
   unsigned long long* dbg;  // [64] cycle stamps of diagnostic builds (EMPC_STAMPS); unused otherwise
   // optional per-iteration record (the reference's callback hook, src/sbfddp.cpp:303-307,381-385): ring of trace_cap
   // records of EMPC_TRACE_WORDS doubles per trajectory, written by select; nullptr = off

@@ -202,6 +202,10 @@ __global__ void __launch_bounds__(64) k_select(DevBuffers D) {
   __shared__ int sh[2];
   const int b = blockIdx.x;
   if (threadIdx.x == 0) {
+    if (b == 0 && D.counters_next) {  // every reader of the other slot's counters ran before this kernel
+      D.counters_next[0] = 0;
+      D.counters_next[1] = 0;
+    }
     int acc_ai, last_ai;
     select_decide<DM>(D, b, acc_ai, last_ai);
     sh[0] = acc_ai;
@@ -214,6 +218,14 @@ __global__ void __launch_bounds__(64) k_select(DevBuffers D) {
   }
   __syncthreads();
   select_copy<DM>(D, b, sh[0], sh[1], threadIdx.x, blockDim.x);
+  if (threadIdx.x == 0 && D.host_active) {
+    __threadfence();
+    if (atomicAdd(D.done_ticket, 1) == (int)gridDim.x - 1) {  // last workgroup: all counts are in
+      *D.host_active = atomicAdd(D.n_active, 0);
+      *D.done_ticket = 0;
+      __threadfence_system();
+    }
+  }
 }
 
 // us_squash[b][t] = sigma(us_last[b][t]) with the trajectory's final smooth (fillSquashedOutputs, src/sbfddp.cpp:479-486)

@@ -65,7 +65,9 @@ struct EmpcSolver {
   double* dtrace = nullptr;    // [B][trace_cap][EMPC_TRACE_WORDS] iteration records (empc_solver_enable_trace)
   int trace_cap = 0;
   hipEvent_t t_begin = nullptr, t_end = nullptr;  // brackets of one solve
-  int* h_active = nullptr;     // pinned
+  int* h_active = nullptr;     // pinned, written by the select kernel itself (no copy command in the stream)
+  int* h_active_dev = nullptr; // the same memory as the device sees it
+  int* dticket = nullptr;      // [MAX_STREAMS] completion tickets of select
   std::vector<TrajState> h_st;
   bool have_state = false;
   EmpcSolveStats stats;
@@ -181,7 +183,8 @@ EmpcSolver* empc_solver_create(const EmpcProblemDesc* problem, const EmpcSolverP
   for (auto& e : s->ev) HIP_CHECK(hipEventCreate(&e));
   HIP_CHECK(hipEventCreate(&s->t_begin));
   HIP_CHECK(hipEventCreate(&s->t_end));
-  HIP_CHECK(hipHostMalloc((void**)&s->h_active, sizeof(int) * 2 * EmpcSolver::MAX_STREAMS));
+  HIP_CHECK(hipHostMalloc((void**)&s->h_active, sizeof(int) * 2 * EmpcSolver::MAX_STREAMS, hipHostMallocMapped));
+  HIP_CHECK(hipHostGetDevicePointer((void**)&s->h_active_dev, s->h_active, 0));
   {
     // independent chunks of the batch run on separate streams (EMPC_STREAMS overrides; 1 = single stream)
     int ns = 1;  // measured on MI355X (profiles/r01_streams.txt): lock-stepped chunks do not overlap usefully
@@ -227,6 +230,8 @@ EmpcSolver* empc_solver_create(const EmpcProblemDesc* problem, const EmpcSolverP
   D.try_ok = s->dalloc<int>(B * NA);
   D.us_last = s->dalloc<double>(B * T * k.nu);
   D.n_active = s->dalloc<int>(4 * EmpcSolver::MAX_STREAMS);  // per chunk and sweep slot: {active trajectories, entries of the linearize list}
+  s->dticket = s->dalloc<int>(EmpcSolver::MAX_STREAMS);
+  HIP_CHECK(hipMemsetAsync(s->dticket, 0, sizeof(int) * EmpcSolver::MAX_STREAMS, s->stream));
   s->dlin_list = s->dalloc<int>(2 * (size_t)batch);          // per sweep slot: the linearize list of every chunk, chunk after chunk
   s->dact_list = s->dalloc<int>(2 * (size_t)batch);
   D.dbg = s->dalloc<unsigned long long>(64);
@@ -490,7 +495,9 @@ int empc_solver_solve(EmpcSolver* s, int maxiter, int is_feasible) {
       Dq.act_count = c.D.n_active + 2 * (1 - q);
       Dq.act_list = s->dact_list + (size_t)(1 - q) * s->B + c.b0;
     }
-    HIP_CHECK(hipMemsetAsync(Dq.n_active, 0, 2 * sizeof(int), c.stream));
+    Dq.counters_next = c.D.n_active + 2 * (1 - q);  // zeroed by this sweep's select for the next sweep
+    Dq.done_ticket = s->dticket + c.idx;
+    Dq.host_active = s->h_active_dev + 2 * c.idx + q;
     HIP_CHECK(hipEventRecord(c.ev[q][0], c.stream));
     k.calc(Dq, c.stream);
     HIP_CHECK(hipEventRecord(c.ev[q][1], c.stream));
@@ -501,14 +508,12 @@ int empc_solver_solve(EmpcSolver* s, int maxiter, int is_feasible) {
     k.rollout(Dq, c.stream);
     HIP_CHECK(hipEventRecord(c.ev[q][4], c.stream));
     k.select(Dq, c.stream);
-    HIP_CHECK(hipEventRecord(c.ev[q][5], c.stream));
-    HIP_CHECK(hipMemcpyAsync(s->h_active + 2 * c.idx + q, Dq.n_active, sizeof(int), hipMemcpyDeviceToHost, c.stream));
-    HIP_CHECK(hipEventRecord(c.ev[q][6], c.stream));
+    HIP_CHECK(hipEventRecord(c.ev[q][5], c.stream));  // the active count is in pinned memory once select is done
     queued[c.idx]++;
   };
   auto retire = [&](Chunk& c) {  // oldest in-flight sweep of the chunk
     const int q = retired[c.idx] & 1;
-    HIP_CHECK(hipEventSynchronize(c.ev[q][6]));
+    HIP_CHECK(hipEventSynchronize(c.ev[q][5]));
     auto el = [&](int a) {
       float ms = 0;
       return hipEventElapsedTime(&ms, c.ev[q][a], c.ev[q][a + 1]) == hipSuccess ? (double)ms : 0.0;
@@ -530,6 +535,10 @@ int empc_solver_solve(EmpcSolver* s, int maxiter, int is_feasible) {
     retired[c.idx]++;
   };
   for (auto& c : chunks) {
+    // counters of both sweep slots and the completion ticket start at zero; from then on select keeps them (no memset
+    // and no copy command per sweep)
+    HIP_CHECK(hipMemsetAsync(c.D.n_active, 0, sizeof(int) * 4, c.stream));
+    HIP_CHECK(hipMemsetAsync(s->dticket + c.idx, 0, sizeof(int), c.stream));
     if (c.idx > 0) HIP_CHECK(hipStreamWaitEvent(c.stream, chunks[c.idx - 1].ev[0][3], 0));  // stagger the first sweep
     enqueue(c);
     if (hard_cap > 1) enqueue(c);

@@ -34,7 +34,7 @@ def test_logger_from_device_trace(empc, problems, tmp_path):
     o.solve(None, None, 100)
     tr = o.trace()
     assert log.iters == [int(v) for v in tr[:, 1]] and log.steps == [float(v) for v in tr[:, 5]]
-    assert np.allclose(log.costs, tr[:, 2], rtol=1e-9) and np.allclose(log.grads, -tr[:, 11], rtol=1e-6)
+    assert np.allclose(log.costs, tr[:, 2], rtol=1e-6) and np.allclose(log.grads, -tr[:, 11], rtol=1e-5, atol=1e-9)
     f = tmp_path / "gpu.pkl"
     empc.utils.saveLogfile(str(f), log, 80, us_squash=list(s.us_squash_batch[1]))
     data = empc.utils.loadLogfile(str(f))
