@@ -1,0 +1,432 @@
+// empc_backward4.hpp -- HOT-B kernel body, matrix-core form with zero-padded LDS tiles (the shipped form).
+//
+// Same mathematics and the same MFMA tiling as empc_backward3.hpp (W = Vxx' [Fx Fu], Q = H + [Fx Fu]^T [W | Vx'],
+// Vxx = Qxx - Qxu K on v_mfma_f64_16x16x4_f64; LLT of Quu, gain solves, symmetrisation, gap terms, regularisation retry:
+// crocoddyl SolverDDP::backwardPass / computeGains; call sites src/sbfddp.cpp:244,256,332).  What changed is
+// how the operands are addressed.  backward3 was bound by its instruction stream (~4k instructions per knot, a quarter of
+// them arithmetic): every operand fetch clamped its indices and selected zeros at the tile edges, every accumulator store
+// was predicated through a computed destination.  Here
+//   * every matrix lives in LDS in a zero-padded tile-shaped array (V 32 x 21, Q 32 x 33, -K 12 x 33, ...): an operand
+//     fetch is one ds_read at (per-lane base, fixed once) + immediate offset, with no select -- padding rows / columns
+//     contribute exact zeros, and where a padded operand meets finite garbage of the other operand the product is zero;
+//   * accumulator tiles are stored whole into the padded arrays (garbage lands in padding that nothing reads as data);
+//   * W never goes through LDS: in the accumulator layout D[i = 4 r + lane / 16][j = lane % 16] register r of tile
+//     (mt, nt) IS the B operand B[k = lane / 16][j] of k step 4 mt + r of the next product;
+//   * the gains stay in the registers of the lane that solved them (column j of K): written to global memory, to LDS as
+//     -K (B operand of the Vxx update) and used for Vx without a round trip.
+#pragma once
+#include "empc_backward3.hpp"
+
+namespace empc {
+
+template <class DM>
+struct Bwd4Smem {
+  static constexpr int n = DM::NDX, m = DM::NU, nm = n + m;
+  static constexpr int MTN = (n + 15) / 16, MTQ = (nm + 15) / 16, NTQ = (nm + 1 + 15) / 16;
+  static constexpr int KSN = (n + 3) / 4, KSM = (m + 3) / 4;
+  static constexpr int VS = 4 * KSN + 1;        // row stride of V (odd: the 16 rows of an operand fetch spread over the banks)
+  static constexpr int QS = 16 * NTQ + 1;       // row stride of Q
+  static constexpr int WS = 16 * MTN + 1;       // row stride of the unsymmetrised Vxx
+  static constexpr int KS = 16 * MTN + 1;       // row stride of -K
+  static constexpr int OFF_REC = 0;                                   // the record, flat, in whole 64-double rows (+ one row of slack)
+  static constexpr int OFF_V = (DM::REC + 63) / 64 * 64 + 64;         // [16 MTN][VS], zero outside n x n
+  static constexpr int OFF_VX = OFF_V + 16 * MTN * VS;                // [4 KSN], zero beyond n
+  static constexpr int OFF_Q = OFF_VX + 4 * KSN;                      // [16 MTQ][QS]
+  static constexpr int OFF_W = OFF_Q + 16 * MTQ * QS;                 // [16 MTN][WS]
+  static constexpr int OFF_KN = OFF_W + 16 * MTN * WS;                // [4 KSM][KS], zero outside m x n
+  static constexpr int OFF_KF = OFF_KN + 4 * KSM * KS;                // k (m), Quuk (m)
+  static constexpr int OFF_RED = OFF_KF + 2 * m;                      // 3 x 32 partial sums
+  static constexpr int OFF_FLAG = OFF_RED + 96;
+  static constexpr int OFF_ZERO = OFF_FLAG + 2;                       // a word that holds 0.0 (H entries outside the matrix)
+  static constexpr int OFF_PRO = OFF_ZERO + 2;                        // prologue reductions: 3 x 64
+  static constexpr int SIZE = (OFF_PRO + 3 * 64 + 1) / 2 * 2;
+};
+
+template <class DM, class Exec>
+EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) {
+  typedef Bwd4Smem<DM> SM;
+  constexpr int NL = 64;
+  constexpr int n = DM::NDX, m = DM::NU, nm = n + m, REC = DM::REC;
+  static_assert(nm <= 47 && n <= 32, "tile counts of the matrix-core backward pass");
+  constexpr int PRE = (REC + NL - 1) / NL;  // prefetch registers per lane
+  constexpr int MTN = SM::MTN, MTQ = SM::MTQ, NTQ = SM::NTQ, KSN = SM::KSN, KSM = SM::KSM;
+  constexpr int VS = SM::VS, QS = SM::QS, WS = SM::WS, KS = SM::KS;
+  TrajState& st = D.st[b];
+  if (st.phase == PHASE_DONE) return;
+  const EMPC_K DevProblem& P = EMPC_KREF(DevProblem, D.P);
+  const int T = D.T;
+  double* rec = smem + SM::OFF_REC;
+  double* V = smem + SM::OFF_V;
+  double* vx = smem + SM::OFF_VX;
+  double* Q = smem + SM::OFF_Q;
+  double* W = smem + SM::OFF_W;
+  double* Kn = smem + SM::OFF_KN;
+  double* kf = smem + SM::OFF_KF;
+  double* red = smem + SM::OFF_RED;
+  double* flag = smem + SM::OFF_FLAG;
+  double* pro = smem + SM::OFF_PRO;
+  const double* tape = D.tape + (size_t)b * (T + 1) * REC;
+
+  // ---- prologue: cost, gap norms, feasibility (as backward3) ---------------------------------------------------------
+  double cost = st.cost, gapnorm = st.gapnorm;
+  int is_feasible = st.is_feasible;
+  if (st.need_lin) {
+    ex.each([&](int lane, int sl) {
+      double c = 0, mx = 0, l1 = 0;
+      for (int t = lane; t <= T; t += NL) {
+        const double* r = tape + (size_t)t * REC;
+        c += r[DM::OFF_COST];
+        for (int i = 0; i < n; ++i) {
+          const double g = fabs(r[DM::OFF_GAP + i]);
+          mx = fmax(mx, g);
+          l1 += g;
+        }
+      }
+      pro[lane] = c;
+      pro[64 + lane] = mx;
+      pro[128 + lane] = l1;
+    });
+    ex.sync();
+    double tot_c = 0, tot_mx = 0, tot_l1 = 0;
+    for (int i = 0; i < NL; ++i) {
+      tot_c += pro[i];
+      tot_mx = fmax(tot_mx, pro[64 + i]);
+      tot_l1 += pro[128 + i];
+    }
+    ex.sync();
+    cost = tot_c;
+    if (!is_feasible) is_feasible = (tot_mx < D.gaptol) ? 1 : 0;
+    gapnorm = (P.prm.gap_norm == EMPC_GAP_L1) ? tot_l1 : tot_mx;
+  }
+  const bool infeas = !is_feasible;
+
+  // ---- loop-invariant addressing -----------------------------------------------------------------------------------------
+  // tile coordinates of this lane: li = row (A operand) / column (B operand, accumulator), lq = k offset / accumulator row group
+  // H entries behind the accumulators of the Q stage: offsets into the record, or the zero word outside H
+  int hidx[Exec::SLOTS][MTQ][NTQ][4];
+  ex.each([&](int lane, int sl) {
+    const int lj = lane % 16, lq = lane / 16;
+#pragma unroll
+    for (int mt = 0; mt < MTQ; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NTQ; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * mt + 4 * r + lq, j = 16 * nt + lj;
+          int idx = SM::OFF_ZERO;
+          if (i < n && j < nm)
+            idx = DM::OFF_HX + i * nm + j;
+          else if (i < n && j == nm)
+            idx = DM::OFF_LX + i;
+          else if (i >= n && i < nm && j >= n && j < nm)
+            idx = DM::OFF_LUU + (i - n) * m + (j - n);
+          else if (i >= n && i < nm && j == nm)
+            idx = DM::OFF_LU + (i - n);
+          hidx[sl][mt][nt][r] = idx;
+        }
+    // zero padding, written once: everything but the record area
+    for (int i = lane; i < SM::SIZE - SM::OFF_V; i += NL) smem[SM::OFF_V + i] = 0.0;
+  });
+  ex.sync();
+
+  double xreg = st.xreg, ureg = st.ureg;
+  double dg_u = 0, dq_u = 0, dg_f = 0, dq_f = 0, qu2 = 0;
+  bool failed_final = false;
+  while (true) {
+    bool fail = false;
+    dg_u = dq_u = dg_f = dq_f = qu2 = 0;
+    // ---- terminal node ---------------------------------------------------------------------------------------
+    {
+      const double* r = tape + (size_t)T * REC;
+      ex.each([&](int lane, int sl) {
+        for (int i = lane; i < n * n; i += NL)
+          V[(i / n) * VS + (i % n)] = r[DM::OFF_LXX + (i / n) * nm + (i % n)] + (((i / n) == (i % n)) ? xreg : 0.0);
+        if (lane < n) {
+          vx[lane] = r[DM::OFF_LX + lane];
+          red[64 + lane] = r[DM::OFF_GAP + lane];  // gap of node T
+        }
+      });
+      ex.sync();
+      ex.each([&](int lane, int sl) {
+        if (lane >= n) return;
+        double a_ = 0;
+        if (infeas)
+          for (int j = 0; j < n; ++j) a_ += V[lane * VS + j] * red[64 + j];
+        const double nv = vx[lane] + (infeas ? a_ : 0.0);
+        D.Vf[((size_t)b * (T + 1) + T) * n + lane] = a_;
+        D.Vx[((size_t)b * (T + 1) + T) * n + lane] = nv;
+        red[lane] = infeas ? nv * red[64 + lane] : 0.0;
+        red[32 + lane] = infeas ? red[64 + lane] * a_ : 0.0;
+        Q[lane] = nv;              // staged: vx is still being read by the other lanes
+      });
+      ex.sync();
+      ex.each([&](int lane, int sl) {
+        if (lane < n) vx[lane] = Q[lane];
+      });
+      for (int i = 0; i < n; ++i) {
+        dg_f -= red[i];
+        dq_f += red[32 + i];
+      }
+      ex.sync();
+    }
+    // first record of the sweep
+    double pre[Exec::SLOTS][PRE];
+    ex.each([&](int lane, int sl) {
+      const double* r = tape + (size_t)(T - 1) * REC;
+#pragma unroll
+      for (int q = 0; q < PRE; ++q) pre[sl][q] = r[lane + q * NL];  // whole rows: the tape has one row of slack
+    });
+#if defined(EMPC_STAMPS) && defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+    unsigned long long bst[16];
+    for (int i = 0; i < 16; ++i) bst[i] = 0;
+    bst[15] = __builtin_readcyclecounter();
+#endif
+    for (int t = T - 1; t >= 0; --t) {
+      BWD_STAMP(7);
+      ex.each([&](int lane, int sl) {
+#pragma unroll
+        for (int q = 0; q < PRE; ++q) rec[lane + q * NL] = pre[sl][q];
+        if (t > 0) {
+          const double* r = tape + (size_t)(t - 1) * REC;
+#pragma unroll
+          for (int q = 0; q < PRE; ++q) pre[sl][q] = r[lane + q * NL];
+        }
+      });
+      ex.sync();
+      BWD_STAMP(0);
+      // accumulators of the Q stage start from H (independent of the value function: issued before the W product)
+      double accQ[Exec::SLOTS][MTQ][NTQ][4];
+      ex.each([&](int lane, int sl) {
+#pragma unroll
+        for (int mt = 0; mt < MTQ; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NTQ; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) accQ[sl][mt][nt][r] = smem[hidx[sl][mt][nt][r]];
+      });
+      // W = V' A, A = [Fx Fu] (flat in the record, row stride nm).  k rows >= n meet the zero columns of V; columns >= nm are
+      // finite garbage that ends in columns nobody uses (column nm is replaced by Vx' below).
+      double accW[Exec::SLOTS][MTN][NTQ][4];
+      ex.each([&](int lane, int sl) {
+#pragma unroll
+        for (int mt = 0; mt < MTN; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NTQ; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) accW[sl][mt][nt][r] = 0.0;
+      });
+#pragma unroll
+      for (int ks = 0; ks < KSN; ++ks) {
+        double aop[Exec::SLOTS][MTN], bop[Exec::SLOTS][NTQ];
+        ex.each([&](int lane, int sl) {
+          const int li = lane % 16, lq = lane / 16;
+#pragma unroll
+          for (int mt = 0; mt < MTN; ++mt) aop[sl][mt] = V[(16 * mt + li) * VS + 4 * ks + lq];
+#pragma unroll
+          for (int nt = 0; nt < NTQ; ++nt) bop[sl][nt] = rec[DM::OFF_A + (4 * ks + lq) * nm + 16 * nt + li];
+        });
+#pragma unroll
+        for (int mt = 0; mt < MTN; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NTQ; ++nt) ex.mfma(aop, mt, bop, nt, accW, mt, nt);
+      }
+      BWD_STAMP(1);
+      // Q = H + A^T [W | Vx'].  A^T[i][k] = A[k][i]: same address pattern as the B operand above.  B operand = the W
+      // accumulators themselves (register r of tile (mt, nt) holds row 4 mt' + r ... of k step ks = 4 mt + r), with column
+      // nm taken from Vx' (zero beyond n).  Rows >= n of W are exact zeros (zero rows of V), so the garbage A^T values of
+      // k >= n contribute nothing.
+#pragma unroll
+      for (int ks = 0; ks < KSN; ++ks) {
+        double aop[Exec::SLOTS][MTQ], bop[Exec::SLOTS][NTQ];
+        ex.each([&](int lane, int sl) {
+          const int li = lane % 16, lq = lane / 16;
+#pragma unroll
+          for (int mt = 0; mt < MTQ; ++mt) aop[sl][mt] = rec[DM::OFF_A + (4 * ks + lq) * nm + 16 * mt + li];
+          const double vxk = vx[4 * ks + lq];
+#pragma unroll
+          for (int nt = 0; nt < NTQ; ++nt) bop[sl][nt] = (16 * nt + li == nm) ? vxk : accW[sl][ks / 4][nt][ks % 4];
+        });
+#pragma unroll
+        for (int mt = 0; mt < MTQ; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NTQ; ++nt) ex.mfma(aop, mt, bop, nt, accQ, mt, nt);
+      }
+      // whole tiles into the padded Q array (column nm = Qx | Qu)
+      ex.each([&](int lane, int sl) {
+        const int lj = lane % 16, lq = lane / 16;
+#pragma unroll
+        for (int mt = 0; mt < MTQ; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NTQ; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Q[(16 * mt + 4 * r + lq) * QS + 16 * nt + lj] = accQ[sl][mt][nt][r];
+      });
+      ex.sync();
+      BWD_STAMP(2);
+      // computeGains: LLT(Quu + ureg I) in every lane; lane j < n solves column j of K = Quu^-1 Qxu^T, lane n solves k and
+      // forms Quu k.  The columns stay in registers.
+      double Kc[Exec::SLOTS][m];
+      ex.each([&](int lane, int sl) {
+        double Lq[m * (m + 1) / 2];
+#pragma unroll
+        for (int i = 0; i < m; ++i)
+#pragma unroll
+          for (int j = 0; j <= i; ++j) Lq[i * (i + 1) / 2 + j] = Q[(n + i) * QS + n + j] + ((i == j) ? ureg : 0.0);
+        const bool pd = chol_packed<m>(Lq);
+        if (lane == 0) flag[0] = pd ? 0.0 : 1.0;
+        if (lane <= n) {
+          double rhs[m];
+#pragma unroll
+          for (int i = 0; i < m; ++i) rhs[i] = Q[((lane < n) ? lane : (n + i)) * QS + ((lane < n) ? (n + i) : nm)];
+          chol_solve_packed<m>(Lq, rhs);
+#pragma unroll
+          for (int i = 0; i < m; ++i) Kc[sl][i] = rhs[i];
+          if (lane < n) {
+            double* Kg = D.K + ((size_t)b * T + t) * m * n;
+#pragma unroll
+            for (int i = 0; i < m; ++i) {
+              Kn[i * KS + lane] = -rhs[i];
+              Kg[i * n + lane] = rhs[i];
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < m; ++i) kf[i] = rhs[i];
+#pragma unroll
+            for (int i = 0; i < m; ++i) {
+              double a_ = 0;
+#pragma unroll
+              for (int j = 0; j < m; ++j) a_ += Q[(n + (i > j ? i : j)) * QS + n + (i > j ? j : i)] * rhs[j];
+              kf[m + i] = a_ + ureg * rhs[i];
+            }
+#pragma unroll
+            for (int i = 0; i < m; ++i) D.kff[((size_t)b * T + t) * m + i] = rhs[i];
+          }
+        }
+      });
+      ex.sync();
+      if (flag[0] != 0.0) {
+        fail = true;
+        break;
+      }
+      for (int i = 0; i < m; ++i) {
+        const double qu = Q[(n + i) * QS + nm];
+        dg_u += qu * kf[i];
+        dq_u -= kf[i] * kf[m + i];
+        qu2 += qu * qu;
+      }
+      BWD_STAMP(3);
+      // Vx = Qx + K^T Quuk - 2 K^T Qu from the lane's own column; Vxx = Qxx + (Qxu)(-K) on the matrix cores: the Qxx tiles
+      // are still in the accumulators of the Q stage, A operand = Qxu (columns n.. of Q; beyond m they meet zero rows of -K)
+      ex.each([&](int lane, int sl) {
+        if (lane < n) {
+          double a_ = Q[lane * QS + nm];
+#pragma unroll
+          for (int l = 0; l < m; ++l) a_ += Kc[sl][l] * kf[m + l];
+#pragma unroll
+          for (int l = 0; l < m; ++l) a_ -= 2.0 * Kc[sl][l] * Q[(n + l) * QS + nm];
+          red[64 + lane] = a_;
+        }
+      });
+#pragma unroll
+      for (int ks = 0; ks < KSM; ++ks) {
+        double aop[Exec::SLOTS][MTN], bop[Exec::SLOTS][MTN];
+        ex.each([&](int lane, int sl) {
+          const int li = lane % 16, lq = lane / 16;
+#pragma unroll
+          for (int mt = 0; mt < MTN; ++mt) {
+            aop[sl][mt] = Q[(16 * mt + li) * QS + n + 4 * ks + lq];
+            bop[sl][mt] = Kn[(4 * ks + lq) * KS + 16 * mt + li];
+          }
+        });
+#pragma unroll
+        for (int mt = 0; mt < MTN; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < MTN; ++nt) ex.mfma(aop, mt, bop, nt, accQ, mt, nt);
+      }
+      ex.each([&](int lane, int sl) {
+        const int lj = lane % 16, lq = lane / 16;
+#pragma unroll
+        for (int mt = 0; mt < MTN; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < MTN; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) W[(16 * mt + 4 * r + lq) * WS + 16 * nt + lj] = accQ[sl][mt][nt][r];
+      });
+      ex.sync();
+      BWD_STAMP(4);
+      // symmetrise + regularise -> V; NaN / overflow guards of Vxx and Vx are collected per lane and reduced once
+      bool badl[Exec::SLOTS];
+      ex.each([&](int lane, int sl) {
+        bool bad = false;
+        for (int i = lane; i < n * n; i += NL) {
+          const int rr = i / n, cc = i % n;
+          const double v_ = 0.5 * (W[rr * WS + cc] + W[cc * WS + rr]) + ((rr == cc) ? xreg : 0.0);
+          V[rr * VS + cc] = v_;
+          bad = bad || bad_number(v_);
+        }
+        badl[sl] = bad;
+      });
+      ex.sync();
+      BWD_STAMP(5);
+      // gap contribution: Vx += Vxx f ; sums for the expected improvement
+      ex.each([&](int lane, int sl) {
+        if (lane >= n) return;
+        double a_ = 0;
+        if (infeas)
+          for (int j = 0; j < n; ++j) a_ += V[lane * VS + j] * rec[DM::OFF_GAP + j];
+        const double nv = red[64 + lane] + (infeas ? a_ : 0.0);
+        vx[lane] = nv;
+        D.Vf[((size_t)b * (T + 1) + t) * n + lane] = a_;
+        D.Vx[((size_t)b * (T + 1) + t) * n + lane] = nv;
+        red[lane] = infeas ? nv * rec[DM::OFF_GAP + lane] : 0.0;
+        red[32 + lane] = infeas ? rec[DM::OFF_GAP + lane] * a_ : 0.0;
+        badl[sl] = badl[sl] || bad_number(nv);  // NaN, inf or >= 1e30 in Vx (crocoddyl's raiseIfNaN on max |Vx|)
+      });
+      const bool badAny = ex.any([&](int lane, int sl) { return badl[sl]; });
+      if (infeas) {  // same order of summation as backward3; with closed gaps every term would be an exact zero
+        for (int i = 0; i < n; ++i) {
+          dg_f -= red[i];
+          dq_f += red[32 + i];
+        }
+      }
+      if (badAny) {
+        fail = true;
+        break;
+      }
+      BWD_STAMP(6);
+    }
+#if defined(EMPC_STAMPS) && defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+    if (b == 0)
+      ex.each([&](int lane, int sl) {
+        if (lane == 0)
+          for (int i = 0; i < 8; ++i) D.dbg[16 + i] = bst[i];
+      });
+#endif
+    ex.sync();
+    if (!fail) break;
+    xreg *= P.prm.reg_incfactor;
+    if (xreg > P.prm.reg_max) xreg = P.prm.reg_max;
+    ureg = xreg;
+    if (xreg == P.prm.reg_max) {
+      failed_final = true;
+      break;
+    }
+  }
+  ex.each([&](int lane, int sl) {
+    if (lane == 0) {
+      st.cost = cost;
+      st.gapnorm = gapnorm;
+      st.is_feasible = is_feasible;
+      st.xreg = xreg;
+      st.ureg = ureg;
+      st.dg_u = dg_u;
+      st.dq_u = dq_u;
+      st.dg_f = dg_f;
+      st.dq_f = dq_f;
+      st.qu2 = qu2;
+      st.bwd_failed = failed_final ? 1 : 0;
+    }
+  });
+}
+
+}  // namespace empc

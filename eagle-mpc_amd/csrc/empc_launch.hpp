@@ -17,6 +17,7 @@
 #include "empc_linearize2.hpp"
 #include "empc_backward2.hpp"
 #include "empc_backward3.hpp"
+#include "empc_backward4.hpp"
 #include "empc_rollout6.hpp"
 #endif
 
@@ -197,6 +198,14 @@ __global__ void __launch_bounds__(64) k_backward3(DevBuffers D) {
   backward_traj3<DM>(ex, D, blockIdx.x, smem_bwd3);
 }
 
+// the shipped backward pass: matrix cores, zero-padded LDS tiles (empc_backward4.hpp)
+template <class DM>
+__global__ void __launch_bounds__(64) k_backward4(DevBuffers D) {
+  extern __shared__ double smem_bwd4[];
+  BlockExec ex{(int)threadIdx.x};
+  backward_traj4<DM>(ex, D, blockIdx.x, smem_bwd4);
+}
+
 template <class DM>
 __global__ void __launch_bounds__(64) k_select(DevBuffers D) {
   __shared__ int sh[2];
@@ -342,11 +351,13 @@ static void launch_linearize(DevBuffers D, hipStream_t s) {
 template <class DM>
 static void launch_backward(DevBuffers D, hipStream_t s) {
   static const int version = [] {
-    const char* e = getenv("EMPC_BACKWARD");  // 2 = vector form, 3 = matrix-core form
-    return e ? atoi(e) : 3;
+    const char* e = getenv("EMPC_BACKWARD");  // 2 = vector form, 3 = matrix-core form, 4 = matrix cores + padded tiles (default)
+    return e ? atoi(e) : 4;
   }();
   if (version == 2)
     hipLaunchKernelGGL(k_backward<DM>, dim3(D.B), dim3(EMPC_BWD_NL), sizeof(double) * Bwd2Smem<DM>::SIZE, s, D);
+  else if (version == 4)
+    hipLaunchKernelGGL(k_backward4<DM>, dim3(D.B), dim3(64), sizeof(double) * Bwd4Smem<DM>::SIZE, s, D);
   else
     hipLaunchKernelGGL(k_backward3<DM>, dim3(D.B), dim3(64), sizeof(double) * Bwd3Smem<DM>::SIZE, s, D);
 }

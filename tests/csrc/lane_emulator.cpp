@@ -12,6 +12,7 @@
 #include "../../eagle-mpc_amd/csrc/empc_linearize2.hpp"
 #include "../../eagle-mpc_amd/csrc/empc_backward2.hpp"
 #include "../../eagle-mpc_amd/csrc/empc_backward3.hpp"
+#include "../../eagle-mpc_amd/csrc/empc_backward4.hpp"
 #include "../../eagle-mpc_amd/csrc/empc_rollout6.hpp"
 
 using namespace empc;
@@ -181,7 +182,13 @@ template <class DM>
 static void emu_backward(Emu& e) {
   std::vector<double> smem(Bwd2Smem<DM>::SIZE);
   std::vector<double> smem3(Bwd3Smem<DM>::SIZE);
+  std::vector<double> smem4(Bwd4Smem<DM>::SIZE);
   for (int b = 0; b < e.B; ++b) {
+    if (g_bwd_version == 4) {
+      CpuExec<64> ex{64};
+      backward_traj4<DM>(ex, e.D, b, smem4.data());  // the shipped form: matrix cores, zero-padded tiles
+      continue;
+    }
     if (g_bwd_version == 3) {
       CpuExec<64> ex{64};
       backward_traj3<DM>(ex, e.D, b, smem3.data());  // the shipped matrix-core form

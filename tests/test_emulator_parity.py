@@ -57,7 +57,7 @@ def candidate(d, seed):
     return xs, us
 
 
-@pytest.mark.parametrize("lin,bwd,roll", [(2, 3, 6), (2, 2, 5), (2, 1, 1)])
+@pytest.mark.parametrize("lin,bwd,roll", [(2, 4, 6), (2, 3, 5), (2, 2, 5), (2, 1, 1)])
 @pytest.mark.parametrize("name", ["hover", "displacement", "push_slide", "eagle_catch"])
 def test_kernel_bodies_vs_oracle(empc, problems, emu, name, lin, bwd, roll):
     _, problem = problems[name]
@@ -148,7 +148,7 @@ def test_emulated_batch_with_perturbed_states(empc, problems, emu):
     B = 3
     prm = ob.default_params()
     emu.emu_set_linearize_version(2)
-    emu.emu_set_backward_version(3)
+    emu.emu_set_backward_version(4)
     emu.emu_set_rollout_version(6)  # three trajectories packed into one wavefront
     e = C.c_void_p(emu.emu_create(C.byref(d), C.byref(prm), B))
     x0s = empc.perturbed_x0s(problem.x0, B, nq=d.model.nq)
