@@ -181,11 +181,28 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
     for (int i = 0; i < 16; ++i) bst[i] = 0;
     bst[15] = __builtin_readcyclecounter();
 #endif
+    // Outputs of a knot (gains, Vx, Vxx f) stay in registers and go to memory at the top of the NEXT knot, right before the
+    // record prefetch is issued: loads and stores share one in-order counter, so a store issued late in a knot would be
+    // waited for when the prefetched record is consumed (measured: ~2k cycles per knot).
+    double Kc[Exec::SLOTS][m], vfo[Exec::SLOTS], vxo[Exec::SLOTS];
+    auto flush_outputs = [&](int tk, int lane, int sl) {
+      if (lane < n) {
+        double* Kg = D.K + ((size_t)b * T + tk) * m * n;
+#pragma unroll
+        for (int i = 0; i < m; ++i) Kg[i * n + lane] = Kc[sl][i];
+        D.Vf[((size_t)b * (T + 1) + tk) * n + lane] = vfo[sl];
+        D.Vx[((size_t)b * (T + 1) + tk) * n + lane] = vxo[sl];
+      } else if (lane == n) {
+#pragma unroll
+        for (int i = 0; i < m; ++i) D.kff[((size_t)b * T + tk) * m + i] = Kc[sl][i];
+      }
+    };
     for (int t = T - 1; t >= 0; --t) {
       BWD_STAMP(7);
       ex.each([&](int lane, int sl) {
 #pragma unroll
         for (int q = 0; q < PRE; ++q) rec[lane + q * NL] = pre[sl][q];
+        if (t < T - 1) flush_outputs(t + 1, lane, sl);
         if (t > 0) {
           const double* r = tape + (size_t)(t - 1) * REC;
 #pragma unroll
@@ -265,7 +282,6 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
       BWD_STAMP(2);
       // computeGains: LLT(Quu + ureg I) in every lane; lane j < n solves column j of K = Quu^-1 Qxu^T, lane n solves k and
       // forms Quu k.  The columns stay in registers.
-      double Kc[Exec::SLOTS][m];
       ex.each([&](int lane, int sl) {
         double Lq[m * (m + 1) / 2];
 #pragma unroll
@@ -282,25 +298,22 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
 #pragma unroll
           for (int i = 0; i < m; ++i) Kc[sl][i] = rhs[i];
           if (lane < n) {
-            double* Kg = D.K + ((size_t)b * T + t) * m * n;
 #pragma unroll
-            for (int i = 0; i < m; ++i) {
-              Kn[i * KS + lane] = -rhs[i];
-              Kg[i * n + lane] = rhs[i];
-            }
+            for (int i = 0; i < m; ++i) Kn[i * KS + lane] = -rhs[i];
           } else {
 #pragma unroll
             for (int i = 0; i < m; ++i) kf[i] = rhs[i];
-#pragma unroll
-            for (int i = 0; i < m; ++i) {
-              double a_ = 0;
-#pragma unroll
-              for (int j = 0; j < m; ++j) a_ += Q[(n + (i > j ? i : j)) * QS + n + (i > j ? j : i)] * rhs[j];
-              kf[m + i] = a_ + ureg * rhs[i];
-            }
-#pragma unroll
-            for (int i = 0; i < m; ++i) D.kff[((size_t)b * T + t) * m + i] = rhs[i];
           }
+        }
+      });
+      ex.sync();
+      // Quu k, one row per lane (same order of summation as the single-lane form)
+      ex.each([&](int lane, int sl) {
+        if (lane < m) {
+          double a_ = 0;
+#pragma unroll
+          for (int j = 0; j < m; ++j) a_ += Q[(n + (lane > j ? lane : j)) * QS + n + (lane > j ? j : lane)] * kf[j];
+          kf[m + lane] = a_ + ureg * kf[lane];
         }
       });
       ex.sync();
@@ -376,8 +389,8 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
           for (int j = 0; j < n; ++j) a_ += V[lane * VS + j] * rec[DM::OFF_GAP + j];
         const double nv = red[64 + lane] + (infeas ? a_ : 0.0);
         vx[lane] = nv;
-        D.Vf[((size_t)b * (T + 1) + t) * n + lane] = a_;
-        D.Vx[((size_t)b * (T + 1) + t) * n + lane] = nv;
+        vfo[sl] = a_;
+        vxo[sl] = nv;
         red[lane] = infeas ? nv * rec[DM::OFF_GAP + lane] : 0.0;
         red[32 + lane] = infeas ? rec[DM::OFF_GAP + lane] * a_ : 0.0;
         badl[sl] = badl[sl] || bad_number(nv);  // NaN, inf or >= 1e30 in Vx (crocoddyl's raiseIfNaN on max |Vx|)
@@ -394,6 +407,7 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
         break;
       }
       BWD_STAMP(6);
+      if (t == 0) ex.each([&](int lane, int sl) { flush_outputs(0, lane, sl); });
     }
 #if defined(EMPC_STAMPS) && defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
     if (b == 0)
