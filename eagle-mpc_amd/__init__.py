@@ -71,6 +71,7 @@ def lib():
     L.empc_solver_create.restype = C.c_void_p
     L.empc_solver_create.argtypes = [C.POINTER(T.ProblemDesc), C.POINTER(T.SolverParams), C.c_int, C.c_int]
     L.empc_solver_destroy.argtypes = [C.c_void_p]
+    L.empc_solver_supported.argtypes = [C.POINTER(T.ProblemDesc), C.POINTER(T.SolverParams)]
     L.empc_solver_update_problem.argtypes = [C.c_void_p, C.POINTER(T.ProblemDesc)]
     L.empc_solver_set_x0.argtypes = [C.c_void_p, _dp]
     L.empc_solver_set_warmstart.argtypes = [C.c_void_p, _dp, _dp]
@@ -127,6 +128,16 @@ def _check(rc):
 
 def device_count():
     return lib().empc_device_count()
+
+
+def solver_supported(problem, params=None):
+    """True when SolverSbFDDP(problem) has a kernel instantiation (needs no GPU); the reason otherwise is in last_error()."""
+    prm = params if params is not None else default_params()
+    return bool(lib().empc_solver_supported(C.byref(problem.desc), C.byref(prm)))
+
+
+def last_error():
+    return lib().empc_last_error().decode()
 
 
 def yaml_path(rel):

@@ -148,6 +148,26 @@ int empc_device_count(void) {
   return n;
 }
 
+int empc_solver_supported(const EmpcProblemDesc* problem, const EmpcSolverParams* params) {
+  try {
+    if (!problem) throw std::invalid_argument("problem is NULL");
+    EmpcSolverParams prm;
+    if (params)
+      prm = *params;
+    else
+      empc_solver_params_default(&prm);
+    HostProblem H;
+    prepare_problem(*problem, prm, H);  // dimension / chain / integrator / contact-type limits of the kernels
+    KernelTable kt;
+    if (!find_table(problem->model.nbodies, problem->n_rotors, problem->has_contact != 0, kt))
+      throw std::runtime_error("no kernel instantiation for this (bodies, rotors, contact) combination");
+    return 1;
+  } catch (const std::exception& e) {
+    empc::set_last_error(e.what());
+    return 0;
+  }
+}
+
 EmpcSolver* empc_solver_create(const EmpcProblemDesc* problem, const EmpcSolverParams* params, int batch, int device) {
   EmpcSolver* s = nullptr;
   EMPC_TRY

@@ -131,6 +131,11 @@ int empc_solver_get_stats(EmpcSolver* s, EmpcSolveStats* stats);
 /* diagnostic builds only (-DEMPC_STAMPS): in-kernel cycle stamps of the backward kernel, trajectory 0 */
 int empc_solver_debug_counters(EmpcSolver* s, unsigned long long* out, int n);
 int empc_solver_dims(const EmpcSolver* s, int* batch, int* T, int* nx, int* ndx, int* nu, int* rec_doubles);
+/* 1 when empc_solver_create would accept this problem (a kernel instantiation exists for its (bodies, rotors, contact)
+ * class and the problem passes the device-side limits), 0 otherwise with the reason in empc_last_error().  Needs no GPU.
+ * Instantiated: (1,4) iris | (1,6) hexacopter370, hextilt | (3,6) hexacopter680_flying_arm_2 |
+ * (4,6) hexacopter370_flying_arm_3, free and ContactModel3D dynamics | (6,6) hextilt_flying_arm_5. */
+int empc_solver_supported(const EmpcProblemDesc* problem, const EmpcSolverParams* params);
 
 /* ---- phase-level entry points (device kernels, one call = one launch over the whole batch) ------------------
  * xs: batch x (T+1) x nx, us: batch x T x nu. `smooth` is the squashing smoothness (0.1 in the first pass).

@@ -199,25 +199,34 @@ def test_yaml_edge_cases(empc, tmp_path):
         empc.Trajectory().autoSetup(str(p))
 
 
-@pytest.mark.skipif(not os.path.isdir("/root/reference/yaml"), reason="reference tree not mounted")
-def test_all_reference_trajectory_yamls_parse(empc):
-    """Every trajectory YAML the reference ships goes through the parser + factories whenever its robot model is one of
-    the build-authored URDFs (the reference tree is read here only in this container, never on the GPU box)."""
-    parsed = 0
-    for f in sorted(glob.glob("/root/reference/yaml/*/trajectories/*.yaml")):
-        robot = f.split("/")[-3]
-        if robot.startswith(("iris", "hexacopter680")):
-            continue  # URDFs not authored in this round (iris has no arm; 680 has a 2-dof arm)
-        import empc_loader  # data dir must point at the reference tree for the 'follow:' includes
-        empc.lib().empc_set_data_dirs(b"/root/reference/yaml", empc.ROBOT_DIR.encode())
+def shipped_trajectories(empc):
+    return sorted(glob.glob(os.path.join(empc.YAML_DIR, "*", "trajectories", "*.yaml")))
+
+
+def test_every_shipped_trajectory_builds_and_has_a_kernel(empc):
+    """Every trajectory file the reference ships (eagle-mpc_amd/data/yaml = its yaml/ tree, unchanged) goes through the
+    parser and the factories, builds a ShootingProblem, and falls in a robot class the solver has kernels for
+    (iris / iris_px4 (4 rotors) and hexacopter680_flying_arm_2 used to fail at empc_solver_create)."""
+    files = shipped_trajectories(empc)
+    assert len(files) == 17
+    classes = set()
+    for f in files:
+        t = empc.Trajectory()
+        t.autoSetup(f)
+        assert t.n_stages >= 1
         try:
-            t = empc.Trajectory()
-            t.autoSetup(f)
-            assert t.n_stages >= 1
-            parsed += 1
-        finally:
-            empc.lib().empc_set_data_dirs(empc.YAML_DIR.encode(), empc.ROBOT_DIR.encode())
-    assert parsed >= 9
+            p = t.createProblem()  # problem_params of the file (only hexacopter370/displacement.yaml has them)
+        except empc.EmpcError:
+            p = t.createProblem(40, True, "IntegratedActionModelEuler")
+        d = p.desc
+        assert empc.solver_supported(p), (f, empc.last_error())
+        classes.add((d.model.nbodies, d.n_rotors, bool(d.has_contact)))
+    assert classes == {(1, 4, False), (1, 6, False), (3, 6, False), (4, 6, False), (4, 6, True), (6, 6, False)}
+    # the options the factory accepts but the device does not implement are refused with a reason, not silently
+    t = empc.Trajectory()
+    t.autoSetup(empc.yaml_path("hexacopter370/trajectories/hover.yaml"))
+    assert not empc.solver_supported(t.createProblem(40, True, "IntegratedActionModelRK4"))
+    assert "IntegratedActionModelEuler" in empc.last_error()
 
 
 def test_robot_models(problems):
