@@ -16,7 +16,7 @@ from . import ctypes_defs as T
 from . import utils  # CallbackLogger / saveLogfile with the reference's layout
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG_DIR, "libempc.so")
+LIB_PATH = os.environ.get("EMPC_LIB_PATH") or os.path.join(_PKG_DIR, "libempc.so")  # EMPC_LIB_PATH: diagnostic builds (make stamps)
 YAML_DIR = os.path.join(_PKG_DIR, "data", "yaml")  # the problem files the reference ships under yaml/ (unchanged: configuration data)
 ROBOT_DIR = os.path.join(_PKG_DIR, "data", "robots")
 
