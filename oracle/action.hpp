@@ -150,9 +150,11 @@ inline double activation(const EmpcCost& c, const double* r, double* Ar, double*
   return a;
 }
 
-// Evaluate one node. u == nullptr means the terminal call IAM.calc(x) == calc(x, u = 0).
-// If diff is false only xnext / cost / u_squash are produced.
-inline void node_calc(const Problem& P, int t, const double* x, const double* u_in, bool diff, NodeData& D) {
+// Differential action model at (x, s): acceleration, contact force, cost sum and -- with diff -- their derivatives, all
+// UNSCALED (the integrator applies dt).  u == nullptr means the terminal call calc(x) == calc(x, u = 0).
+// Outputs: D.xout, D.lambda, D.u_squash, ell; with diff also D.Lx .. D.Luu (unscaled) and da_dx (nv x ndx), da_du (nv x nu).
+inline void dam_eval(const Problem& P, int t, const double* x, const double* u_in, bool diff, NodeData& D, double& ell_out,
+                     double* da_dx, double* da_du) {
   const EmpcModelDesc& m = P.d.model;
   const int nq = m.nq, nv = m.nv, ndx = P.d.ndx, nu = P.d.nu, nr_rot = P.d.n_rotors;
   const EmpcCostSet& set = P.sets[P.knot_set[t]];
@@ -281,14 +283,6 @@ inline void node_calc(const Problem& P, int t, const double* x, const double* u_
   for (int i = 0; i < nv; ++i) D.xout[i] = a[i];
   for (int i = 0; i < 6; ++i) D.lambda[i] = lam[i];
 
-  // --- Euler step (A.3): dx = [v dt + a dt^2; a dt]
-  double dxe[NDX];
-  for (int i = 0; i < nv; ++i) {
-    dxe[i] = v[i] * dt + a[i] * dt * dt;
-    dxe[nv + i] = a[i] * dt;
-  }
-  state_integrate(P, x, dxe, D.xnext);
-
   // --- derivatives of the dynamics
   //   dtau_dx: derivative of RNEA(q,v,a) - Jc^T lam at fixed (a, lam); da0_dx: derivative of the contact drift + Jc a
   double dtau_dx[NV * NDX];
@@ -356,8 +350,8 @@ inline void node_calc(const Problem& P, int t, const double* x, const double* u_
     }
   }
 
-  // da/dx (nv x ndx), da/du (nv x nu), dlam/dx, dlam/du
-  double da_dx[NV * NDX], da_du[NV * NU], dl_dx[6 * NDX], dl_du[6 * NU];
+  // da/dx (nv x ndx), da/du (nv x nu) -> caller; dlam/dx, dlam/du
+  double dl_dx[6 * NDX], dl_du[6 * NU];
   if (diff) {
     // actuation derivative dtau/ds = B diag(sigma')
     double dtau_du[NV * NU];
@@ -602,6 +596,50 @@ inline void node_calc(const Problem& P, int t, const double* x, const double* u_
         }
     }
   }
+  ell_out = ell;
+  (void)dt;
+}
+
+// blkdiag(J (6 x 6), I) applied from the left to an ndx x cols matrix (row-major, in place)
+inline void apply_base_block(const double* J6, double* M, int ndx, int cols) {
+  for (int j = 0; j < cols; ++j) {
+    double col[6];
+    for (int i = 0; i < 6; ++i) {
+      double acc = 0;
+      for (int l = 0; l < 6; ++l) acc += J6[i * 6 + l] * M[l * cols + j];
+      col[i] = acc;
+    }
+    for (int i = 0; i < 6; ++i) M[i * cols + j] = col[i];
+  }
+}
+// Jintegrate of StateMultibody at (x, d): first = d(x (+) d)/dx = blkdiag(Ad(exp6(d)^-1), I), second = d(x (+) d)/dd =
+// blkdiag(Jexp6(d), I)   (SURVEY A.4); only the 6 x 6 base blocks are returned
+inline void state_Jintegrate_blocks(const double* d, double* J1, double* J2) {
+  double Re[9], pe[3], neg[6];
+  Jexp6(d, J2);
+  for (int i = 0; i < 6; ++i) neg[i] = -d[i];
+  exp6(neg, Re, pe);
+  adjoint6(Re, pe, J1);  // Ad(exp6(d)^-1) = Ad(exp6(-d))
+}
+
+// IntegratedActionModelEuler (A.3) on top of dam_eval.  If diff is false only xnext / cost / u_squash are produced.
+inline void node_calc_euler(const Problem& P, int t, const double* x, const double* u_in, bool diff, NodeData& D) {
+  const EmpcModelDesc& m = P.d.model;
+  const int nq = m.nq, nv = m.nv, ndx = P.d.ndx, nu = P.d.nu;
+  const double dt = P.d.dt;
+  const bool terminal = (u_in == nullptr);
+  static thread_local double da_dx[NV * NDX], da_du[NV * NU];
+  double ell = 0;
+  dam_eval(P, t, x, u_in, diff, D, ell, da_dx, da_du);
+  const double* v = x + nq;
+  const double* a = D.xout;
+  // --- Euler step (A.3): dx = [v dt + a dt^2; a dt]
+  double dxe[NDX];
+  for (int i = 0; i < nv; ++i) {
+    dxe[i] = v[i] * dt + a[i] * dt * dt;
+    dxe[nv + i] = a[i] * dt;
+  }
+  state_integrate(P, x, dxe, D.xnext);
   // Euler scaling of the cost (A.3); the terminal node is a running IAM too (src/trajectory.cpp:135, U2)
   const double cscale = (terminal && !P.prm.terminal_dt_scaling) ? 1.0 : dt;
   D.cost = cscale * ell;
@@ -654,6 +692,148 @@ inline void node_calc(const Problem& P, int t, const double* x, const double* u_
       }
     }
   }
+}
+
+
+// IntegratedActionModelRK4 (src/factory/int-action.cpp:29-31; crocoddyl ~1.8 integ-action/rk4.hxx): four evaluations of the
+// differential model at y_i = x (+) c_i dt k_{i-1}, c = (0, 1/2, 1/2, 1), k_i = [v(y_i); a(y_i, u)];
+// xnext = x (+) dt/6 (k0 + 2 k1 + 2 k2 + k3), cost = dt/6 (l0 + 2 l1 + 2 l2 + l3); derivatives by the chain rule through
+// the stages, cost Hessians in Gauss-Newton form (second derivatives of y_i dropped, as crocoddyl does).  The squashing /
+// contact data a caller reads afterwards are those of stage 0 (src/sbfddp.cpp:144-145 takes differential[0]).
+// The terminal node is the same model called with u = 0 (U2).
+inline void node_calc_rk4(const Problem& P, int t, const double* x, const double* u_in, bool diff, NodeData& D) {
+  const EmpcModelDesc& m = P.d.model;
+  const int nq = m.nq, nv = m.nv, n = P.d.ndx, nu = P.d.nu, nx = P.d.nx;
+  const double dt = P.d.dt;
+  const bool terminal = (u_in == nullptr);
+  const double c[4] = {0.0, 0.5, 0.5, 1.0}, w[4] = {1.0, 2.0, 2.0, 1.0};
+  static thread_local NodeData S[4];
+  static thread_local double A[4][NV * NDX], B[4][NV * NU];
+  double y[4][NX], k[4][NDX], dxr[4][NDX], ell[4];
+  for (int i = 0; i < nx; ++i) y[0][i] = x[i];
+  for (int i = 0; i < 4; ++i) {
+    if (i > 0) {
+      for (int j = 0; j < n; ++j) dxr[i][j] = c[i] * dt * k[i - 1][j];
+      state_integrate(P, x, dxr[i], y[i]);
+    }
+    dam_eval(P, t, y[i], u_in, diff, S[i], ell[i], A[i], B[i]);
+    for (int j = 0; j < nv; ++j) {
+      k[i][j] = y[i][nq + j];
+      k[i][nv + j] = S[i].xout[j];
+    }
+  }
+  double dx[NDX];
+  for (int j = 0; j < n; ++j) dx[j] = (k[0][j] + 2.0 * k[1][j] + 2.0 * k[2][j] + k[3][j]) * dt / 6.0;
+  state_integrate(P, x, dx, D.xnext);
+  const double cscale = (terminal && !P.prm.terminal_dt_scaling) ? 1.0 / 6.0 : dt / 6.0;
+  D.cost = (ell[0] + 2.0 * ell[1] + 2.0 * ell[2] + ell[3]) * cscale;
+  for (int j = 0; j < nv; ++j) D.xout[j] = S[0].xout[j];
+  for (int j = 0; j < 6; ++j) D.lambda[j] = S[0].lambda[j];
+  for (int j = 0; j < nu; ++j) D.u_squash[j] = S[0].u_squash[j];
+  if (!diff) return;
+  // dk_i/dx (n x n), dk_i/du (n x nu), dy_i/dx, dy_i/du
+  static thread_local double dkx[4][NDX * NDX], dku[4][NDX * NU], dyx[4][NDX * NDX], dyu[4][NDX * NU];
+  for (int i = 0; i < 4; ++i) {
+    if (i == 0) {
+      std::memset(dyx[0], 0, sizeof(double) * n * n);
+      for (int j = 0; j < n; ++j) dyx[0][j * n + j] = 1.0;
+      std::memset(dyu[0], 0, sizeof(double) * n * nu);
+    } else {
+      double J1[36], J2[36];
+      state_Jintegrate_blocks(dxr[i], J1, J2);
+      for (int j = 0; j < n * n; ++j) dyx[i][j] = c[i] * dt * dkx[i - 1][j];
+      for (int j = 0; j < n * nu; ++j) dyu[i][j] = c[i] * dt * dku[i - 1][j];
+      apply_base_block(J2, dyx[i], n, n);
+      apply_base_block(J2, dyu[i], n, nu);
+      for (int r = 0; r < n; ++r)
+        for (int q = 0; q < n; ++q) dyx[i][r * n + q] += (r < 6 && q < 6) ? J1[r * 6 + q] : ((r >= 6 && r == q) ? 1.0 : 0.0);
+    }
+    // k_i = [v(y_i); a(y_i, u)]: rows 0..nv-1 pick the velocity rows of dy_i, rows nv.. are A_i dy_i (+ B_i)
+    for (int r = 0; r < nv; ++r) {
+      for (int q = 0; q < n; ++q) dkx[i][r * n + q] = dyx[i][(nv + r) * n + q];
+      for (int q = 0; q < nu; ++q) dku[i][r * nu + q] = dyu[i][(nv + r) * nu + q];
+      for (int q = 0; q < n; ++q) {
+        double acc = 0;
+        for (int l = 0; l < n; ++l) acc += A[i][r * n + l] * dyx[i][l * n + q];
+        dkx[i][(nv + r) * n + q] = acc;
+      }
+      for (int q = 0; q < nu; ++q) {
+        double acc = B[i][r * nu + q];
+        for (int l = 0; l < n; ++l) acc += A[i][r * n + l] * dyu[i][l * nu + q];
+        dku[i][(nv + r) * nu + q] = acc;
+      }
+    }
+  }
+  {
+    double J1[36], J2[36];
+    state_Jintegrate_blocks(dx, J1, J2);
+    for (int j = 0; j < n * n; ++j) D.Fx[j] = (dkx[0][j] + 2.0 * dkx[1][j] + 2.0 * dkx[2][j] + dkx[3][j]) * dt / 6.0;
+    for (int j = 0; j < n * nu; ++j) D.Fu[j] = (dku[0][j] + 2.0 * dku[1][j] + 2.0 * dku[2][j] + dku[3][j]) * dt / 6.0;
+    apply_base_block(J2, D.Fx, n, n);
+    apply_base_block(J2, D.Fu, n, nu);
+    for (int r = 0; r < n; ++r)
+      for (int q = 0; q < n; ++q) D.Fx[r * n + q] += (r < 6 && q < 6) ? J1[r * 6 + q] : ((r >= 6 && r == q) ? 1.0 : 0.0);
+  }
+  // costs
+  std::memset(D.Lx, 0, sizeof(double) * n);
+  std::memset(D.Lu, 0, sizeof(double) * nu);
+  std::memset(D.Lxx, 0, sizeof(double) * n * n);
+  std::memset(D.Lxu, 0, sizeof(double) * n * nu);
+  std::memset(D.Luu, 0, sizeof(double) * nu * nu);
+  static thread_local double XX[NDX * NDX], XU[NDX * NU];  // lxx_i dy_i/dx, lxx_i dy_i/du
+  for (int i = 0; i < 4; ++i) {
+    const double wi = w[i] * cscale;
+    const NodeData& Si = S[i];
+    for (int q = 0; q < n; ++q) {
+      double acc = 0;
+      for (int l = 0; l < n; ++l) acc += dyx[i][l * n + q] * Si.Lx[l];
+      D.Lx[q] += wi * acc;
+    }
+    for (int q = 0; q < nu; ++q) {
+      double acc = Si.Lu[q];
+      for (int l = 0; l < n; ++l) acc += dyu[i][l * nu + q] * Si.Lx[l];
+      D.Lu[q] += wi * acc;
+    }
+    for (int r = 0; r < n; ++r) {
+      for (int q = 0; q < n; ++q) {
+        double acc = 0;
+        for (int l = 0; l < n; ++l) acc += Si.Lxx[r * n + l] * dyx[i][l * n + q];
+        XX[r * n + q] = acc;
+      }
+      for (int q = 0; q < nu; ++q) {
+        double acc = 0;
+        for (int l = 0; l < n; ++l) acc += Si.Lxx[r * n + l] * dyu[i][l * nu + q];
+        XU[r * nu + q] = acc;
+      }
+    }
+    for (int r = 0; r < n; ++r) {
+      for (int q = 0; q < n; ++q) {
+        double acc = 0;
+        for (int l = 0; l < n; ++l) acc += dyx[i][l * n + r] * XX[l * n + q];
+        D.Lxx[r * n + q] += wi * acc;
+      }
+      for (int q = 0; q < nu; ++q) {
+        double acc = 0;
+        for (int l = 0; l < n; ++l) acc += dyx[i][l * n + r] * (Si.Lxu[l * nu + q] + XU[l * nu + q]);
+        D.Lxu[r * nu + q] += wi * acc;
+      }
+    }
+    for (int r = 0; r < nu; ++r)
+      for (int q = 0; q < nu; ++q) {
+        double acc = Si.Luu[r * nu + q];
+        for (int l = 0; l < n; ++l) acc += Si.Lxu[l * nu + r] * dyu[i][l * nu + q] + dyu[i][l * nu + r] * Si.Lxu[l * nu + q] +
+                                           dyu[i][l * nu + r] * XU[l * nu + q];
+        D.Luu[r * nu + q] += wi * acc;
+      }
+  }
+}
+
+// One node of the shooting problem with the problem's integrator (EmpcProblemDesc::integrator).
+inline void node_calc(const Problem& P, int t, const double* x, const double* u_in, bool diff, NodeData& D) {
+  if (P.d.integrator == EMPC_INTEGRATOR_RK4)
+    node_calc_rk4(P, t, x, u_in, diff, D);
+  else
+    node_calc_euler(P, t, x, u_in, diff, D);
 }
 
 }  // namespace oracle

@@ -142,6 +142,85 @@ def test_node_derivatives_fd(problems, name, knots):
             assert np.abs(Lu - r["Lu"]).max() < 1e-6 * (1 + np.abs(r["Lu"]).max())
 
 
+@pytest.mark.parametrize("name,dt,knots", [("hover", 40, [0, 50]), ("displacement", 80, [3, 25, 100]), ("eagle_catch", 32, [5, 45, 99])])
+def test_rk4_node_derivatives_fd(empc, name, dt, knots):
+    """IntegratedActionModelRK4 (src/factory/int-action.cpp:29-31) in the oracle: Fx, Fu, Lx, Lu of calcDiff against central
+    differences of calc (free and contact dynamics, running and terminal nodes), symmetric Gauss-Newton Hessians, and the
+    stage-0 squashing data."""
+    from conftest import CONFIGS
+    t = empc.Trajectory()
+    t.autoSetup(empc.yaml_path(CONFIGS[name][0]))
+    problem = t.createProblem(dt, True, "IntegratedActionModelRK4")
+    d = problem.desc
+    assert d.integrator == 1
+    o = ob.OracleSolver(d)
+    rng = np.random.default_rng(2)
+    nx, ndx, nu = d.nx, d.ndx, d.nu
+    for tk in knots:
+        x = np.zeros(nx)
+        x[:3] = rng.normal(size=3) * 0.5
+        q = np.array([0, 0, 0, 1.0]) + rng.normal(size=4) * 0.3
+        x[3:7] = q / np.linalg.norm(q)
+        x[7:] = rng.normal(size=nx - 7) * 0.2
+        u = rng.uniform(1, 8, size=nu)
+        u[d.n_rotors:] = rng.normal(size=nu - d.n_rotors) * 0.3
+        uu = None if tk == d.T else u
+        r = o.node_calc(tk, x, uu, True)
+        assert np.abs(r["Lxx"] - r["Lxx"].T).max() < 1e-9 * (1 + np.abs(r["Lxx"]).max())
+        assert np.abs(r["Luu"] - r["Luu"].T).max() < 1e-9 * (1 + np.abs(r["Luu"]).max())
+        h = 1e-6
+        Fx = np.zeros((ndx, ndx))
+        Lx = np.zeros(ndx)
+        for k in range(ndx):
+            e = np.zeros(ndx)
+            e[k] = h
+            rp = o.node_calc(tk, o.integrate(x, e), uu, False)
+            rm = o.node_calc(tk, o.integrate(x, -e), uu, False)
+            Fx[:, k] = (o.diff(r["xnext"], rp["xnext"]) - o.diff(r["xnext"], rm["xnext"])) / (2 * h)
+            Lx[k] = (rp["cost"] - rm["cost"]) / (2 * h)
+        assert np.abs(Fx - r["Fx"]).max() < 2e-6 * (1 + np.abs(r["Fx"]).max()), (name, tk)
+        assert np.abs(Lx - r["Lx"]).max() < 1e-6 * (1 + np.abs(r["Lx"]).max()), (name, tk)
+        if uu is not None:
+            Fu = np.zeros((ndx, nu))
+            Lu = np.zeros(nu)
+            for k in range(nu):
+                e = np.zeros(nu)
+                e[k] = h
+                rp = o.node_calc(tk, x, u + e, False)
+                rm = o.node_calc(tk, x, u - e, False)
+                Fu[:, k] = (o.diff(r["xnext"], rp["xnext"]) - o.diff(r["xnext"], rm["xnext"])) / (2 * h)
+                Lu[k] = (rp["cost"] - rm["cost"]) / (2 * h)
+            assert np.abs(Fu - r["Fu"]).max() < 2e-6 * (1 + np.abs(r["Fu"]).max()), (name, tk)
+            assert np.abs(Lu - r["Lu"]).max() < 1e-6 * (1 + np.abs(r["Lu"]).max()), (name, tk)
+
+
+def test_rk4_node_matches_the_plant_integrator(empc):
+    """Two independent RK4 codes: the OCP's IntegratedActionModelRK4 without the squashing layer and the closed-loop plant
+    (AerialSimulator, utils/simulator.py) integrate the same free dynamics -- identical next states; and RK4 is fourth
+    order: halving dt divides the one-step error against a fine reference by ~32."""
+    t = empc.Trajectory()
+    t.autoSetup(empc.yaml_path("hexacopter370_flying_arm_3/trajectories/displacement.yaml"))
+    rng = np.random.default_rng(4)
+    errs = []
+    for dt in (80, 40):
+        problem = t.createProblem(dt, False, "IntegratedActionModelRK4")
+        d = problem.desc
+        o = ob.OracleSolver(d)
+        x = np.zeros(d.nx)
+        x[:3] = [0.1, -0.2, 1.0]
+        q = np.array([0.05, -0.02, 0.1, 1.0])
+        x[3:7] = q / np.linalg.norm(q)
+        x[7:] = np.linspace(-0.3, 0.3, d.nx - 7)
+        u = np.array([4.0, 4.5, 3.5, 4.2, 3.8, 4.1, 0.05, -0.03, 0.02])
+        r = o.node_calc(3, x, u, False)
+        plant = ob.plant_rk4(d, x, u, dt / 1000.0)[0]
+        assert np.abs(r["xnext"] - plant).max() < 1e-13
+        fine = ob.plant_rk4(d, x, u, dt / 1000.0 / 64, substeps=64)[0]
+        errs.append(np.abs(o.diff(fine, r["xnext"])).max())
+    assert 16 < errs[0] / errs[1] < 64, errs
+    del rng
+
+
 def test_contact_constraint_holds(problems):
     """ContactModel3D: the acceleration returned by the KKT dynamics keeps the gripper's classical acceleration at zero
     (gains are zero), and the contact force enters the equations of motion with the right sign."""
