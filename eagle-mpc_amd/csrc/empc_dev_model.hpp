@@ -18,6 +18,7 @@ namespace empc {
 struct DevProblem {
   EmpcModelDesc model;
   int nx, ndx, nu, n_rotors, T, n_sets, has_contact, use_squash;
+  int integrator, reserved_;  // EmpcIntegrator
   double dt;
   double tau_f[6 * EMPC_MAX_ROTORS];
   double u_lb[EMPC_MAX_NU];
@@ -698,10 +699,12 @@ EMPC_HD void contact_forward(const EMPC_K EmpcModelDesc& m, const ContactT& ct, 
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Nominal evaluation of one node by ONE lane: IAM.calc(x, s)  (used by the rollout and calc kernels).
+// Nominal evaluation of one node by ONE lane (used by the per-lane rollout and the calc kernels), in two layers:
+//   dam_nominal   DifferentialActionModel{Free,Contact}FwdDynamics::calc(x, s): acceleration, contact force, cost sum
+//   node_nominal  IntegratedActionModel{Euler,RK4}::calc on top of it (P.integrator)
 //   terminal: the reference's IAM.calc(x) == calc(x, u = 0)   
-// Outputs: xnext[NX], acc[NV] (generalized acceleration, reused by linearize), cost, usq[NU] (squashed control),
-//          lam[6] (contact force).
+// Outputs of node_nominal: xnext[NX], acc[NV] (generalized acceleration, reused by linearize), cost, usq[NU] (squashed
+// control), lam[6] (contact force).
 // ---------------------------------------------------------------------------------------------------------
 // diagnostic builds (-DEMPC_STAMPS): cycle counter deltas per section, accumulated in a caller-provided array
 #if defined(EMPC_STAMPS) && defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
@@ -720,10 +723,13 @@ EMPC_HD void contact_forward(const EMPC_K EmpcModelDesc& m, const ContactT& ct, 
   } while (0)
 #endif
 // SetT: the cost set either in the constant address space (scalar loads) or staged in LDS / generic memory
+// dam_nominal: ell_out is the UNSCALED cost sum; with `euler_xnext` != nullptr the semi-implicit Euler step is taken in the
+// middle of the function, where the r01 kernels had it (the compiler's schedule -- and with it the last bits of the
+// iteration path of ill-conditioned problems -- stays what the golden vectors were recorded with)
 template <class DM, bool CT, class SetT>
-EMPC_HD void node_nominal(const EMPC_K DevProblem& P, const SetT& set, double smooth, const double* x, const double* s_in,
-                          bool terminal, double* xnext, double* acc, double& cost_out, double* usq, double* lam_out,
-                          unsigned long long* stp = nullptr) {
+EMPC_HD void dam_nominal(const EMPC_K DevProblem& P, const SetT& set, double smooth, const double* x, const double* s_in,
+                         bool terminal, double* euler_xnext, double* acc, double& ell_out, double* usq, double* lam_out,
+                         unsigned long long* stp = nullptr) {
   constexpr int NB = DM::NB, NV = DM::NV, NQ = DM::NQ, NU = DM::NU, NROT = DM::NROT;
   const EMPC_K EmpcModelDesc& m = P.model;
   const double dt = P.dt;
@@ -901,14 +907,16 @@ EMPC_HD void node_nominal(const EMPC_K DevProblem& P, const SetT& set, double sm
     for (int i = 0; i < 6; ++i) lam_out[i] = lam[i];
 
   // Euler step (A.3)
-  double dxe[DM::NDX];
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    dxe[i] = v[i] * dt + a[i] * dt * dt;
-    dxe[NV + i] = a[i] * dt;
-  }
   EMPC_STAMP(5);  // contact KKT
-  state_integrate<DM>(x, dxe, xnext, nullptr);
+  if (euler_xnext) {
+    double dxe[DM::NDX];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      dxe[i] = v[i] * dt + a[i] * dt * dt;
+      dxe[NV + i] = a[i] * dt;
+    }
+    state_integrate<DM>(x, dxe, euler_xnext, nullptr);
+  }
   EMPC_STAMP(6);  // Euler step
 
   // friction-cone costs need the contact force
@@ -922,9 +930,73 @@ EMPC_HD void node_nominal(const EMPC_K DevProblem& P, const SetT& set, double sm
     ell += c.weight * activation_value<6>(c, r, 5);
   }
   ell += ell_frames;
-  const double cscale = (terminal && !P.prm.terminal_dt_scaling) ? 1.0 : dt;
-  cost_out = cscale * ell;
+  ell_out = ell;
   EMPC_STAMP(7);  // costs
+}
+
+// IntegratedActionModelRK4::calc (src/factory/int-action.cpp:29-31; oracle/action.hpp node_calc_rk4): four evaluations
+// of the differential model at y_i = x (+) c_i dt k_{i-1}, k_i = [v(y_i); a(y_i, s)]; the acceleration / squashing /
+// contact outputs are those of stage 0 (src/sbfddp.cpp:144-145 reads differential[0]).
+template <class DM, bool CT, class SetT>
+EMPC_HD void node_nominal_rk4(const EMPC_K DevProblem& P, const SetT& set, double smooth, const double* x, const double* s_in,
+                              bool terminal, double* xnext, double* acc, double& cost_out, double* usq, double* lam_out) {
+  constexpr int NV = DM::NV, NQ = DM::NQ, NX = DM::NX, NU = DM::NU, NDX = DM::NDX;
+  const double dt = P.dt;
+  const double rk4_c[4] = {0.0, 0.5, 0.5, 1.0};
+  double y[NX], kprev[NDX], ksum[NDX], ellsum = 0;
+#pragma unroll
+  for (int i = 0; i < NX; ++i) y[i] = x[i];
+  for (int st = 0; st < 4; ++st) {
+    if (st > 0) {
+      double dxr[NDX];
+#pragma unroll
+      for (int j = 0; j < NDX; ++j) dxr[j] = rk4_c[st] * dt * kprev[j];
+      state_integrate<DM>(x, dxr, y, nullptr);
+    }
+    double a_[NV], us_[NU], lam_[6], ell_;
+    dam_nominal<DM, CT>(P, set, smooth, y, s_in, terminal, (double*)nullptr, a_, ell_, us_, lam_);
+    const double w = (st == 0 || st == 3) ? 1.0 : 2.0;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      kprev[j] = y[NQ + j];
+      kprev[NV + j] = a_[j];
+    }
+    if (st == 0) {
+#pragma unroll
+      for (int j = 0; j < NDX; ++j) ksum[j] = kprev[j];
+      ellsum = ell_;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) acc[j] = a_[j];
+#pragma unroll
+      for (int j = 0; j < NU; ++j) usq[j] = us_[j];
+      if (lam_out)
+        for (int j = 0; j < 6; ++j) lam_out[j] = lam_[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < NDX; ++j) ksum[j] = ksum[j] + w * kprev[j];
+      ellsum = ellsum + w * ell_;
+    }
+  }
+  double dx[NDX];
+#pragma unroll
+  for (int j = 0; j < NDX; ++j) dx[j] = ksum[j] * dt / 6.0;
+  state_integrate<DM>(x, dx, xnext, nullptr);
+  const double cscale = (terminal && !P.prm.terminal_dt_scaling) ? 1.0 / 6.0 : dt / 6.0;
+  cost_out = ellsum * cscale;
+}
+
+template <class DM, bool CT, class SetT>
+EMPC_HD void node_nominal(const EMPC_K DevProblem& P, const SetT& set, double smooth, const double* x, const double* s_in,
+                          bool terminal, double* xnext, double* acc, double& cost_out, double* usq, double* lam_out,
+                          unsigned long long* stp = nullptr) {
+  if (P.integrator == EMPC_INTEGRATOR_RK4) {
+    node_nominal_rk4<DM, CT>(P, set, smooth, x, s_in, terminal, xnext, acc, cost_out, usq, lam_out);
+    return;
+  }
+  double ell;
+  dam_nominal<DM, CT>(P, set, smooth, x, s_in, terminal, xnext, acc, ell, usq, lam_out, stp);
+  const double cscale = (terminal && !P.prm.terminal_dt_scaling) ? 1.0 : P.dt;
+  cost_out = cscale * ell;
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -96,6 +96,7 @@ struct DevBuffers {
   double* trace = nullptr;  // [B][trace_cap][EMPC_TRACE_WORDS]
   int trace_cap = 0;
   int B, T, NA;
+  int integrator = 0;  // EmpcIntegrator of the problem (host copy: selects the kernel forms that support it)
   double gaptol;    // feasibility tolerance actually used: max(th_gaptol, 1e-13)
 };
 

@@ -50,8 +50,8 @@ inline void insert_barrier(EmpcCostSet& s, const DevProblem& P) {
 inline void prepare_problem(const EmpcProblemDesc& d, const EmpcSolverParams& prm, HostProblem& H) {
   if (!d.sets || !d.knot_set) throw std::invalid_argument("problem descriptor has no cost-set / knot tables");
   if (d.T < 1) throw std::invalid_argument("problem needs at least one running knot");
-  if (d.integrator != EMPC_INTEGRATOR_EULER)
-    throw std::runtime_error("only IntegratedActionModelEuler is implemented on the device");
+  if (d.integrator != EMPC_INTEGRATOR_EULER && d.integrator != EMPC_INTEGRATOR_RK4)
+    throw std::invalid_argument("unknown integrator (IntegratedActionModelEuler or IntegratedActionModelRK4)");
   const EmpcModelDesc& m = d.model;
   for (int b = 1; b < m.nbodies; ++b)
     if (m.parent[b] != b - 1) throw std::runtime_error("the device kernels need a serial kinematic chain");
@@ -69,6 +69,7 @@ inline void prepare_problem(const EmpcProblemDesc& d, const EmpcSolverParams& pr
   H.P.n_sets = d.n_sets;
   H.P.has_contact = d.has_contact;
   H.P.use_squash = d.use_squash;
+  H.P.integrator = d.integrator;
   H.P.dt = d.dt;
   std::memcpy(H.P.tau_f, d.tau_f, sizeof(d.tau_f));
   std::memcpy(H.P.u_lb, d.u_lb, sizeof(d.u_lb));

@@ -41,6 +41,12 @@ static bool find_table(int nb, int nrot, bool contact, KernelTable& k) {
   else return false;
   return true;
 }
+// problem classes the factory accepts but no kernel implements yet
+static void check_device_support(const EmpcProblemDesc& d) {
+  if (d.integrator != EMPC_INTEGRATOR_EULER)
+    throw std::runtime_error("only IntegratedActionModelEuler is implemented in the linearize kernel (IntegratedActionModelRK4: rollouts only)");
+}
+
 struct EmpcSolver {
   HostProblem H;
   KernelTable kt;
@@ -158,6 +164,7 @@ int empc_solver_supported(const EmpcProblemDesc* problem, const EmpcSolverParams
       empc_solver_params_default(&prm);
     HostProblem H;
     prepare_problem(*problem, prm, H);  // dimension / chain / integrator / contact-type limits of the kernels
+    check_device_support(*problem);
     KernelTable kt;
     if (!find_table(problem->model.nbodies, problem->n_rotors, problem->has_contact != 0, kt))
       throw std::runtime_error("no kernel instantiation for this (bodies, rotors, contact) combination");
@@ -185,6 +192,7 @@ EmpcSolver* empc_solver_create(const EmpcProblemDesc* problem, const EmpcSolverP
   s = new EmpcSolver();
   s->device = device;
   prepare_problem(*problem, prm, s->H);
+  check_device_support(*problem);
   if (problem->has_contact)
     for (const auto& cs : s->H.sets)
       for (int i = 0; i < cs.ncontacts; ++i)
@@ -260,6 +268,7 @@ EmpcSolver* empc_solver_create(const EmpcProblemDesc* problem, const EmpcSolverP
   D.T = s->T;
   D.NA = s->NA;
   D.gaptol = std::max(prm.th_gaptol, 1e-13);
+  D.integrator = problem->integrator;
   s->dscratch = s->dalloc<double>(B * T * k.nu);
   s->dplant_x = s->dalloc<double>(B * k.nx);
   s->dplant_u = s->dalloc<double>(B * k.nu);

@@ -207,7 +207,7 @@ static int g_roll_version = 6;
 template <class DM>
 static void emu_rollout(Emu& e) {
   const bool ct = e.H.P.has_contact != 0;
-  if (g_roll_version == 6 && e.NA <= MAX_ALPHAS) {  // the shipped form: packed trajectories, role wavefronts
+  if (g_roll_version == 6 && e.NA <= MAX_ALPHAS && e.H.P.integrator == EMPC_INTEGRATOR_EULER) {  // the shipped form: packed trajectories, role wavefronts (Euler nodes)
     const int G = roll6_group_size(e.NA);
     std::vector<double> smem6(Roll6Smem<DM>::SIZE);
     for (int grp = 0; grp * G < e.B; ++grp) {
@@ -223,7 +223,7 @@ static void emu_rollout(Emu& e) {
   }
   for (int b = 0; b < e.B; ++b)
     for (int ai = 0; ai < e.NA; ++ai) {
-      if (g_roll_version == 5) {
+      if (g_roll_version >= 5 && e.H.P.integrator == EMPC_INTEGRATOR_EULER) {
         if (ai > 0) continue;  // one call per trajectory: the 64 lanes cover every step length
         std::vector<double> smem5(Roll5Smem<DM>::SIZE);
         CpuExec<64> ex{64};
@@ -277,12 +277,35 @@ static void emu_solve(Emu& e, int maxiter, int is_feasible) {
   do {                                                                          \
     if (e->nb == 1 && e->nrot == 6) FN<Dims<1, 6>>(__VA_ARGS__);                \
     else if (e->nb == 1 && e->nrot == 4) FN<Dims<1, 4>>(__VA_ARGS__);           \
+    else if (e->nb == 3 && e->nrot == 6) FN<Dims<3, 6>>(__VA_ARGS__);           \
     else if (e->nb == 4 && e->nrot == 6) FN<Dims<4, 6>>(__VA_ARGS__);           \
     else if (e->nb == 6 && e->nrot == 6) FN<Dims<6, 6>>(__VA_ARGS__);           \
     else { std::fprintf(stderr, "emulator: unsupported dims\n"); }             \
   } while (0)
 
+template <class DM>
+static void emu_node(Emu& e, int t, const double* x, const double* u, double smooth, double* xnext, double* acc, double* cost,
+                     double* usq, double* lam) {
+  const EmpcCostSet& set = e.H.sets[e.H.knot_set[t]];
+  double c = 0;
+  if constexpr (DM::NB == 4) {
+    if (e.H.P.has_contact) {
+      node_nominal<DM, true>(e.H.P, set, smooth, x, u, u == nullptr, xnext, acc, c, usq, lam);
+      *cost = c;
+      return;
+    }
+  }
+  node_nominal<DM, false>(e.H.P, set, smooth, x, u, u == nullptr, xnext, acc, c, usq, lam);
+  *cost = c;
+}
+
 extern "C" {
+// IAM.calc of one node through the device code path (node_nominal: Euler or RK4 as the problem says)
+void emu_node_nominal(void* h, int t, const double* x, const double* u, double smooth, double* xnext, double* acc, double* cost,
+                      double* usq, double* lam) {
+  Emu* e = static_cast<Emu*>(h);
+  DISPATCH(e, emu_node, *e, t, x, u, smooth, xnext, acc, cost, usq, lam);
+}
 void emu_set_linearize_version(int v) { g_lin_version = v; }
 void emu_set_backward_version(int v) { g_bwd_version = v; }
 void emu_set_rollout_version(int v) { g_roll_version = v; }

@@ -37,6 +37,7 @@ def emu(empc):
     L.emu_phase_linearize.argtypes = [C.c_void_p, _dp, _dp]
     L.emu_phase_backward.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _ip, _ip, _dp]
     L.emu_phase_rollout.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _ip]
+    L.emu_node_nominal.argtypes = [C.c_void_p, C.c_int, _dp, _dp, C.c_double, _dp, _dp, _dp, _dp, _dp]
     return L
 
 
@@ -163,4 +164,41 @@ def test_emulated_batch_with_perturbed_states(empc, problems, emu):
     ref = ob.solve_batch(d, x0s, 100, nthreads=2)
     assert (it == ref["iter"]).all() and (st == ref["status"]).all()
     assert np.abs(xs - ref["xs"]).max() < 1e-5
+    emu.emu_destroy(e)
+
+
+@pytest.mark.parametrize("integrator", ["IntegratedActionModelEuler", "IntegratedActionModelRK4"])
+@pytest.mark.parametrize("name,dt", [("hover", 40), ("displacement", 80), ("eagle_catch", 32)])
+def test_node_nominal_vs_oracle(empc, emu, name, dt, integrator):
+    """IAM.calc of single nodes through the device code (node_nominal: dam_nominal + Euler step, or the four RK4 stages)
+    against the oracle's node_calc: next state, stage-0 acceleration / contact force / squashed control, cost."""
+    from conftest import CONFIGS
+    t = empc.Trajectory()
+    t.autoSetup(empc.yaml_path(CONFIGS[name][0]))
+    problem = t.createProblem(dt, True, integrator)
+    d = problem.desc
+    prm = ob.default_params()
+    e = C.c_void_p(emu.emu_create(C.byref(d), C.byref(prm), 1))
+    assert e.value
+    o = ob.OracleSolver(d)
+    o.set_smooth(0.07)
+    rng = np.random.default_rng(5)
+    knots = {"hover": [0, 49, 50], "displacement": [2, 25, 100], "eagle_catch": [3, 43, 46, 99]}[name]
+    for tk in knots:
+        x = np.zeros(d.nx)
+        x[:3] = rng.normal(size=3) * 0.5
+        q = np.array([0, 0, 0, 1.0]) + rng.normal(size=4) * 0.3
+        x[3:7] = q / np.linalg.norm(q)
+        x[7:] = rng.normal(size=d.nx - 7) * 0.2
+        u = rng.uniform(1, 8, size=d.nu)
+        u[d.n_rotors:] = rng.normal(size=d.nu - d.n_rotors) * 0.3
+        uu = None if tk == d.T else u
+        r = o.node_calc(tk, x, uu, False)
+        xn, acc, cost, usq, lam = np.zeros(d.nx), np.zeros(d.model.nv), np.zeros(1), np.zeros(d.nu), np.zeros(6)
+        emu.emu_node_nominal(e, tk, ob.P(x), None if uu is None else ob.P(u), 0.07, ob.P(xn), ob.P(acc), ob.P(cost), ob.P(usq), ob.P(lam))
+        if uu is not None:
+            assert np.abs(xn - r["xnext"]).max() < 1e-12 * (1 + np.abs(r["xnext"]).max()), (name, tk)
+        assert np.abs(acc - r["acc"]).max() < 1e-10 * (1 + np.abs(r["acc"]).max())
+        assert abs(cost[0] - r["cost"]) < 1e-12 * (1 + abs(r["cost"]))
+        assert np.abs(usq - r["u_squash"]).max() < 1e-13 and np.abs(lam - r["lam"]).max() < 1e-9 * (1 + np.abs(r["lam"]).max())
     emu.emu_destroy(e)
