@@ -97,6 +97,8 @@ struct DevBuffers {
   int trace_cap = 0;
   int B, T, NA;
   int integrator = 0;  // EmpcIntegrator of the problem (host copy: selects the kernel forms that support it)
+  int raw = 0;         // linearize: write the differential model's derivatives (da/dx, da/du, unscaled costs) instead of the
+                       // Euler node's -- the stage records of IntegratedActionModelRK4 (empc_rk4.hpp)
   double gaptol;    // feasibility tolerance actually used: max(th_gaptol, 1e-13)
 };
 

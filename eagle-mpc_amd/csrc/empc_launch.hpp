@@ -20,6 +20,7 @@
 #include "empc_backward4.hpp"
 #include "empc_rollout6.hpp"
 #endif
+#include "empc_rk4.hpp"
 
 using namespace empc;
 
@@ -29,6 +30,7 @@ struct KernelTable {
   void (*linearize)(DevBuffers, hipStream_t);
   void (*backward)(DevBuffers, hipStream_t);
   void (*rollout)(DevBuffers, hipStream_t);
+  void (*rk4_linearize)(DevBuffers, Rk4Buffers, hipStream_t);  // IntegratedActionModelRK4 nodes: stages, raw records, assembly
   void (*select)(DevBuffers, hipStream_t);
   void (*squash_out)(DevBuffers, double*, hipStream_t);
   void (*pack_rows)(DevBuffers, double*, hipStream_t);
@@ -348,6 +350,41 @@ static void launch_linearize(DevBuffers D, hipStream_t s) {
   else
     launch_linearize_blk<DM, CT, 256>(D, s);
 }
+// IntegratedActionModelRK4: stage states -> differential-model records of the 4 B stage trajectories (the linearize kernel
+// in RAW mode) -> chain rule per node (empc_rk4.hpp)
+template <class DM, bool CT>
+__global__ void __launch_bounds__(64) k_rk4_stages(DevBuffers D, Rk4Buffers R) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= D.B * (D.T + 1)) return;
+  const int t = idx / D.B, b = idx % D.B;  // consecutive lanes = trajectories of one node: same cost set
+  rk4_stage_thread<DM, CT>(D, R, b, t);
+}
+template <class DM>
+__global__ void __launch_bounds__(64) k_rk4_assemble(DevBuffers D, Rk4Buffers R) {
+  extern __shared__ double smem_rk4[];
+  LaneExec ex{(int)threadIdx.x};
+  const int u = blockIdx.x;
+  rk4_assemble_unit<DM>(ex, D, R, u % D.B, u / D.B, 64, smem_rk4);
+}
+template <class DM, bool CT>
+static void launch_rk4_linearize(DevBuffers D, Rk4Buffers R, hipStream_t s) {
+  const int n = D.B * (D.T + 1);
+  hipLaunchKernelGGL((k_rk4_stages<DM, CT>), dim3((n + 63) / 64), dim3(64), 0, s, D, R);
+  DevBuffers Dv = D;  // the stage batch as the linearize kernel sees it
+  Dv.B = 4 * D.B;
+  Dv.st = R.st4;
+  Dv.xs = R.ys;
+  Dv.us = R.us4;
+  Dv.acc = R.accs;
+  Dv.tape = R.tape4;
+  Dv.x0 = R.ys;  // never read in RAW mode
+  Dv.lin_list = nullptr;
+  Dv.lin_count = nullptr;
+  Dv.raw = 1;
+  launch_linearize<DM, CT>(Dv, s);
+  hipLaunchKernelGGL(k_rk4_assemble<DM>, dim3(n), dim3(64), sizeof(double) * Rk4Smem<DM>::SIZE, s, D, R);
+}
+
 template <class DM>
 static void launch_backward(DevBuffers D, hipStream_t s) {
   static const int version = [] {
@@ -368,7 +405,7 @@ static void launch_rollout(DevBuffers D, hipStream_t s) {
     const char* e = getenv("EMPC_ROLLOUT");  // 6 = packed role-split form (default), 5 = wave per trajectory, 1 = per-lane form (also the fallback for more than MAX_ALPHAS step lengths)
     return e ? atoi(e) : 6;
   }();
-  if (version == 1 || D.NA > MAX_ALPHAS) {
+  if (version == 1 || D.NA > MAX_ALPHAS || D.integrator != EMPC_INTEGRATOR_EULER) {  // RK4 nodes: the per-lane form
     hipLaunchKernelGGL((k_rollout<DM, CT>), dim3((n + 63) / 64), dim3(64), 0, s, D);
   } else if (version == 6) {
     const size_t smem = sizeof(double) * Roll6Smem<DM>::SIZE;
@@ -408,6 +445,7 @@ static KernelTable make_table() {
   k.linearize = launch_linearize<DM, CT>;
   k.backward = launch_backward<DM>;
   k.rollout = launch_rollout<DM, CT>;
+  k.rk4_linearize = launch_rk4_linearize<DM, CT>;
   k.select = launch_select<DM>;
   k.squash_out = launch_squash_out<DM>;
   k.pack_rows = launch_pack_rows<DM>;

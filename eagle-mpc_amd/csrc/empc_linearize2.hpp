@@ -454,7 +454,8 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
   const EMPC_K EmpcCostSet& set = EMPC_KPTR(EmpcCostSet, D.sets)[EMPC_KPTR(int, D.knot_set)[t]];
   const double dt = P.dt;
   const double smooth = st.smooth;
-  const bool feas = st.is_feasible != 0;
+  const bool raw = D.raw != 0;  // RK4 stage record: differential-model derivatives, no integrator, no gaps
+  const bool feas = st.is_feasible != 0 || raw;
   double* out = D.tape + ((size_t)b * (T + 1) + t) * REC;
 
   if (set_uses_frames(set) != FR) return;
@@ -585,7 +586,7 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
 #pragma unroll
       for (int i = 0; i < NDX; ++i) Nu[SM::OFF_GAP + i] = feasu ? 0.0 : gap[i];
     }
-    if (t == 0) {
+    if (t == 0 && !raw) {
       double gap[NDX];
       if (!feasu) state_diff<DM>(x, D.x0 + (size_t)bu * NX, gap, nullptr);
 #pragma unroll
@@ -618,7 +619,7 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
       if (wv == 0) {
         if (live(wl)) chain_section(RL->base + (size_t)wl * RL->usz);
       } else if (wv == 1) {
-        if (live(wl)) euler_section(RL->base + (size_t)wl * RL->usz, traj(wl), D.st[traj(wl)].is_feasible != 0);
+        if (live(wl)) euler_section(RL->base + (size_t)wl * RL->usz, traj(wl), D.st[traj(wl)].is_feasible != 0 || raw);
       }
       if (wv == RW - 1) {
         const int u = wl / SM::NSLOT, q = wl % SM::NSLOT;
@@ -893,6 +894,23 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
 #pragma unroll
         for (int i = 0; i < NV; ++i) da[i] += N[SM::OFF_MIJ + i * 3] * z[0] + N[SM::OFF_MIJ + i * 3 + 1] * z[1] + N[SM::OFF_MIJ + i * 3 + 2] * z[2];
       }
+    }
+    if (raw) {
+      // column of da/dx (x lanes) or da/du (u lanes) in rows NV.. of the block; rows 0..NV-1 (dv/d. = [0 I | 0]) are implied
+      if (xlane) {
+#pragma unroll
+        for (int r = 0; r < NV; ++r) {
+          out[DM::OFF_FX + r * DM::NM + lane] = 0.0;
+          out[DM::OFF_FX + (NV + r) * DM::NM + lane] = da[r];
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < NV; ++r) {
+          out[DM::OFF_FU + r * DM::NM + k] = 0.0;
+          out[DM::OFF_FU + (NV + r) * DM::NM + k] = da[r];
+        }
+      }
+      return;
     }
     double G[NDX];
 #pragma unroll
@@ -1255,7 +1273,7 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
   ex.sync();
   LIN_STAMP(8);
   // ---- S7: scale and store ---------------------------------------------------------------------------------------------
-  const double cscale = (terminal && !P.prm.terminal_dt_scaling) ? 1.0 : dt;
+  const double cscale = raw ? 1.0 : ((terminal && !P.prm.terminal_dt_scaling) ? 1.0 : dt);
   ex.each([&](int lane, int sl) {
     if (lane < NDX) {
       out[DM::OFF_LX + lane] = lx_l[sl] * cscale;

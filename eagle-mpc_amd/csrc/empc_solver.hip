@@ -43,8 +43,7 @@ static bool find_table(int nb, int nrot, bool contact, KernelTable& k) {
 }
 // problem classes the factory accepts but no kernel implements yet
 static void check_device_support(const EmpcProblemDesc& d) {
-  if (d.integrator != EMPC_INTEGRATOR_EULER)
-    throw std::runtime_error("only IntegratedActionModelEuler is implemented in the linearize kernel (IntegratedActionModelRK4: rollouts only)");
+  (void)d;  // every problem class prepare_problem lets through has kernels today
 }
 
 struct EmpcSolver {
@@ -68,6 +67,7 @@ struct EmpcSolver {
   double* dscratch = nullptr;  // output staging (squashed controls)
   double* dplant_x = nullptr;  // [B][NX] plant states of closed-loop runs (empc_plant_*)
   double* dplant_u = nullptr;  // [B][NU] staging of caller-supplied plant controls
+  Rk4Buffers R4 = {};          // stage batch of IntegratedActionModelRK4 problems (empty otherwise)
   double* dtrace = nullptr;    // [B][trace_cap][EMPC_TRACE_WORDS] iteration records (empc_solver_enable_trace)
   int trace_cap = 0;
   hipEvent_t t_begin = nullptr, t_end = nullptr;  // brackets of one solve
@@ -269,6 +269,17 @@ EmpcSolver* empc_solver_create(const EmpcProblemDesc* problem, const EmpcSolverP
   D.NA = s->NA;
   D.gaptol = std::max(prm.th_gaptol, 1e-13);
   D.integrator = problem->integrator;
+  if (problem->integrator == EMPC_INTEGRATOR_RK4) {
+    s->R4.ys = s->dalloc<double>(4 * B * (T + 1) * k.nx);
+    s->R4.accs = s->dalloc<double>(4 * B * (T + 1) * k.nacc);
+    s->R4.us4 = s->dalloc<double>(4 * B * T * k.nu);
+    s->R4.tape4 = s->dalloc<double>(4 * B * (T + 1) * k.rec + 64);
+    s->R4.st4 = s->dalloc<TrajState>(4 * B);
+    HIP_CHECK(hipMemsetAsync(s->R4.tape4, 0, sizeof(double) * 4 * B * (T + 1) * k.rec, s->stream));
+    HIP_CHECK(hipMemsetAsync(s->R4.accs, 0, sizeof(double) * 4 * B * (T + 1) * k.nacc, s->stream));
+    HIP_CHECK(hipMemsetAsync(s->R4.ys, 0, sizeof(double) * 4 * B * (T + 1) * k.nx, s->stream));
+    HIP_CHECK(hipMemsetAsync(s->R4.us4, 0, sizeof(double) * 4 * B * T * k.nu, s->stream));
+  }
   s->dscratch = s->dalloc<double>(B * T * k.nu);
   s->dplant_x = s->dalloc<double>(B * k.nx);
   s->dplant_u = s->dalloc<double>(B * k.nu);
@@ -473,6 +484,18 @@ static DevBuffers chunk_view(const EmpcSolver* s, int b0, int nb, int idx) {
   return D;
 }
 
+static Rk4Buffers chunk_rk4(const EmpcSolver* s, int b0) {
+  Rk4Buffers R = s->R4;
+  const size_t T = s->T, o = (size_t)4 * b0;
+  const KernelTable& k = s->kt;
+  R.ys += o * (T + 1) * k.nx;
+  R.accs += o * (T + 1) * k.nacc;
+  R.us4 += o * T * k.nu;
+  R.tape4 += o * (T + 1) * k.rec;
+  R.st4 += o;
+  return R;
+}
+
 int empc_solver_solve(EmpcSolver* s, int maxiter, int is_feasible) {
   EMPC_TRY
   if (!s) throw std::invalid_argument("solver is NULL");
@@ -530,7 +553,10 @@ int empc_solver_solve(EmpcSolver* s, int maxiter, int is_feasible) {
     HIP_CHECK(hipEventRecord(c.ev[q][0], c.stream));
     k.calc(Dq, c.stream);
     HIP_CHECK(hipEventRecord(c.ev[q][1], c.stream));
-    k.linearize(Dq, c.stream);
+    if (s->D.integrator == EMPC_INTEGRATOR_RK4)
+      k.rk4_linearize(Dq, chunk_rk4(s, c.b0), c.stream);
+    else
+      k.linearize(Dq, c.stream);
     HIP_CHECK(hipEventRecord(c.ev[q][2], c.stream));
     k.backward(Dq, c.stream);
     HIP_CHECK(hipEventRecord(c.ev[q][3], c.stream));
@@ -758,7 +784,10 @@ int empc_linearize_batch(EmpcSolver* s, const double* xs, const double* us, doub
   HIP_CHECK(hipEventRecord(s->ev[0], s->stream));
   s->kt.calc(s->D, s->stream);
   HIP_CHECK(hipEventRecord(s->ev[1], s->stream));
-  s->kt.linearize(s->D, s->stream);
+  if (s->D.integrator == EMPC_INTEGRATOR_RK4)
+    s->kt.rk4_linearize(s->D, s->R4, s->stream);
+  else
+    s->kt.linearize(s->D, s->stream);
   HIP_CHECK(hipEventRecord(s->ev[2], s->stream));
   HIP_CHECK(hipStreamSynchronize(s->stream));
   HIP_CHECK(hipGetLastError());

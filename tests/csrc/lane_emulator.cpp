@@ -14,6 +14,7 @@
 #include "../../eagle-mpc_amd/csrc/empc_backward3.hpp"
 #include "../../eagle-mpc_amd/csrc/empc_backward4.hpp"
 #include "../../eagle-mpc_amd/csrc/empc_rollout6.hpp"
+#include "../../eagle-mpc_amd/csrc/empc_rk4.hpp"
 
 using namespace empc;
 
@@ -158,23 +159,69 @@ static void emu_calc(Emu& e) {
 }
 static int g_lin_version = 2;
 template <class DM>
+static void emu_linearize_view(Emu& e, const DevBuffers& D);
+// IntegratedActionModelRK4 nodes: stage states, raw records of the stage batch, assembly (empc_rk4.hpp)
+template <class DM>
+static void emu_linearize_rk4(Emu& e) {
+  const size_t B = e.B, T = e.T;
+  std::vector<double> ys(4 * B * (T + 1) * DM::NX, 0.0), accs(4 * B * (T + 1) * DM::NACC, 0.0), us4(4 * B * T * DM::NU, 0.0),
+      tape4(4 * B * (T + 1) * DM::REC + 64, 0.0);
+  std::vector<TrajState> st4(4 * B);
+  Rk4Buffers R{ys.data(), accs.data(), us4.data(), tape4.data(), st4.data()};
+  const bool ct = e.H.P.has_contact != 0;
+  for (int t = 0; t <= e.T; ++t)
+    for (int b = 0; b < e.B; ++b) {
+      if constexpr (DM::NB == 4) {
+        if (ct) {
+          rk4_stage_thread<DM, true>(e.D, R, b, t);
+          continue;
+        }
+      }
+      rk4_stage_thread<DM, false>(e.D, R, b, t);
+    }
+  DevBuffers Dv = e.D;
+  Dv.B = 4 * e.B;
+  Dv.st = st4.data();
+  Dv.xs = ys.data();
+  Dv.us = us4.data();
+  Dv.acc = accs.data();
+  Dv.tape = tape4.data();
+  Dv.x0 = ys.data();
+  Dv.raw = 1;
+  emu_linearize_view<DM>(e, Dv);
+  std::vector<double> smem(Rk4Smem<DM>::SIZE);
+  for (int t = 0; t <= e.T; ++t)
+    for (int b = 0; b < e.B; ++b) {
+      CpuExec<64> ex{64};
+      rk4_assemble_unit<DM>(ex, e.D, R, b, t, 64, smem.data());
+    }
+}
+template <class DM>
 static void emu_linearize(Emu& e) {
+  if (e.H.P.integrator == EMPC_INTEGRATOR_RK4) {
+    emu_linearize_rk4<DM>(e);
+    return;
+  }
+  emu_linearize_view<DM>(e, e.D);
+}
+template <class DM>
+static void emu_linearize_view(Emu& e, const DevBuffers& Dl) {
   constexpr int LPU = (3 * DM::NV <= 32) ? 32 : 64;
   std::vector<double> smem(Lin2Smem<DM>::SIZE);
   for (int t = 0; t <= e.T; ++t)
-    for (int b = 0; b < e.B; ++b) {
-      const TrajState& st = e.st[b];
+    for (int b = 0; b < Dl.B; ++b) {
+      const TrajState& st = Dl.st[b];
       if (st.phase == PHASE_DONE || !st.need_lin) continue;
       CpuExec<64> ex{LPU};
       if constexpr (DM::NB == 4) {
         if (e.H.P.has_contact) {
-          linearize_unit2<DM, true, false>(ex, e.D, b, t, LPU, smem.data());
-          linearize_unit2<DM, true, true>(ex, e.D, b, t, LPU, smem.data());
+          linearize_unit2<DM, true, false>(ex, Dl, b, t, LPU, smem.data());
+          linearize_unit2<DM, true, true>(ex, Dl, b, t, LPU, smem.data());
           continue;
         }
       }
-      linearize_unit2<DM, false, false>(ex, e.D, b, t, LPU, smem.data());
-      linearize_unit2<DM, false, true>(ex, e.D, b, t, LPU, smem.data());
+      linearize_unit2<DM, false, false>(ex, Dl, b, t, LPU, smem.data());
+      linearize_unit2<DM, false, true>(ex, Dl, b, t, LPU, smem.data());
     }
 }
 static int g_bwd_version = 2;

@@ -45,16 +45,18 @@ def rel(a, b):
     return np.abs(a - b).max() / (1.0 + np.abs(b).max())
 
 
-def candidate(d, seed):
+def candidate(d, seed, scale=1.0):
+    """random candidate trajectory; scale < 1 keeps it near hover (an RK4 step is unstable on the stiff arm dynamics of the
+    full-size perturbation: |da/dx| dt >> 1 there, Fx entries of 1e5)"""
     rng = np.random.default_rng(seed)
     T, nx, nu = d.T, d.nx, d.nu
     xs = np.zeros((T + 1, nx))
     xs[:, :3] = rng.normal(size=(T + 1, 3)) * 0.3
-    q = np.array([0, 0, 0, 1.0]) + rng.normal(size=(T + 1, 4)) * 0.2
+    q = np.array([0, 0, 0, 1.0]) + rng.normal(size=(T + 1, 4)) * 0.2 * scale
     xs[:, 3:7] = q / np.linalg.norm(q, axis=-1, keepdims=True)
-    xs[:, 7:] = rng.normal(size=(T + 1, nx - 7)) * 0.3
-    us = rng.uniform(2, 6, size=(T, nu))
-    us[:, d.n_rotors:] = rng.normal(size=(T, nu - d.n_rotors)) * 0.2
+    xs[:, 7:] = rng.normal(size=(T + 1, nx - 7)) * 0.3 * scale
+    us = rng.uniform(2, 6, size=(T, nu)) if scale == 1.0 else 4.0 + rng.uniform(-1, 1, size=(T, nu)) * scale
+    us[:, d.n_rotors:] = rng.normal(size=(T, nu - d.n_rotors)) * 0.2 * scale
     return xs, us
 
 
@@ -201,4 +203,91 @@ def test_node_nominal_vs_oracle(empc, emu, name, dt, integrator):
         assert np.abs(acc - r["acc"]).max() < 1e-10 * (1 + np.abs(r["acc"]).max())
         assert abs(cost[0] - r["cost"]) < 1e-12 * (1 + abs(r["cost"]))
         assert np.abs(usq - r["u_squash"]).max() < 1e-13 and np.abs(lam - r["lam"]).max() < 1e-9 * (1 + np.abs(r["lam"]).max())
+    emu.emu_destroy(e)
+
+
+@pytest.mark.parametrize("name,dt", [("hover", 40), ("displacement", 80), ("eagle_catch", 32)])
+def test_rk4_kernel_bodies_vs_oracle(empc, emu, name, dt):
+    """IntegratedActionModelRK4 through the device code on the CPU lane emulator: stage kernel + linearize in RAW mode +
+    assembly kernel against the oracle's RK4 calcDiff (every block of every node), backward + rollout on that tape, and a
+    whole solve (iteration count, status, trajectory)."""
+    from conftest import CONFIGS
+    tr = empc.Trajectory()
+    tr.autoSetup(empc.yaml_path(CONFIGS[name][0]))
+    problem = tr.createProblem(dt, True, "IntegratedActionModelRK4")
+    d = problem.desc
+    prm = ob.default_params()
+    emu.emu_set_linearize_version(2)
+    emu.emu_set_backward_version(4)
+    emu.emu_set_rollout_version(6)  # falls back to the per-lane form for RK4 nodes
+    e = C.c_void_p(emu.emu_create(C.byref(d), C.byref(prm), 1))
+    assert e.value
+    o = ob.OracleSolver(d)
+    T, nx, ndx, nu, nv = d.T, d.nx, d.ndx, d.nu, d.model.nv
+    rec = emu.emu_rec(e)
+    xs, us = candidate(d, 3, scale=0.1)
+    o.set_smooth(0.1)
+    cost_o, fs, feas = o.phase_calcdiff(xs, us)
+    emu.emu_set_warmstart(e, ob.P(xs), ob.P(us))
+    emu.emu_phase_setup(e, 0.1, 0, 1e-9, 0)
+    tape = np.zeros((T + 1, rec))
+    acc = np.zeros((T + 1, nv))
+    emu.emu_phase_linearize(e, ob.P(tape), ob.P(acc))
+    n, m = ndx, nu
+    nm = n + m
+
+    def blocks(r):
+        A = r[:n * nm].reshape(n, nm)
+        HX = r[n * nm:2 * n * nm].reshape(n, nm)
+        o2 = 2 * n * nm
+        return {"Fx": A[:, :n], "Fu": A[:, n:], "Lxx": HX[:, :n], "Lxu": HX[:, n:], "Luu": r[o2:o2 + m * m].reshape(m, m),
+                "Lx": r[o2 + m * m:o2 + m * m + n], "Lu": r[o2 + m * m + n:o2 + m * m + n + m],
+                "gap": r[o2 + m * m + n + m:o2 + m * m + 2 * n + m], "cost": r[o2 + m * m + 2 * n + m:o2 + m * m + 2 * n + m + 1]}
+    for t in range(T + 1):
+        ref = o.phase_tape(t)
+        ref["gap"] = fs[t]
+        ref["cost"] = np.array([ref["cost"]])
+        got = blocks(tape[t])
+        for key in got:
+            if t == T and key in ("Fx", "Fu", "Lxu", "Luu", "Lu"):
+                continue
+            assert rel(np.asarray(got[key]).ravel(), np.asarray(ref[key]).ravel()) < 1e-10, (t, key)
+    ok, Ko, ko, Vxo, _, dgo = o.phase_backward(1e-9)
+    K = np.zeros((T, m, n))
+    k = np.zeros((T, m))
+    Vx = np.zeros((T + 1, n))
+    dg = np.zeros(2)
+    oke = np.zeros(1, dtype=np.int32)
+    fe = np.zeros(1, dtype=np.int32)
+    ce = np.zeros(1)
+    emu.emu_phase_backward(e, ob.P(K), ob.P(k), ob.P(Vx), ob.P(dg), oke.ctypes.data_as(_ip), fe.ctypes.data_as(_ip), ob.P(ce))
+    assert ok and oke[0] == 1
+    # the RK4 cost Hessians of this candidate reach 1e9: the LLT of Quu at xreg = 1e-9 amplifies the 1e-10 tape differences
+    assert rel(K, Ko) < 1e-3 and rel(k, ko) < 1e-3 and rel(Vx, Vxo) < 1e-5
+    for ai in (2, 4):
+        oko, xo, uo, co, d01 = o.phase_forward(2.0 ** -ai)
+        xt = np.zeros((T + 1, nx))
+        ut = np.zeros((T, nu))
+        ct = np.zeros(1)
+        dv = np.zeros(1)
+        okr = np.zeros(1, dtype=np.int32)
+        emu.emu_phase_rollout(e, ai, ob.P(xt), ob.P(ut), ob.P(ct), ob.P(dv), okr.ctypes.data_as(_ip))
+        assert bool(okr[0]) == oko
+        if oko and abs(co) < 1e12:
+            assert rel(xt, xo) < 1e-5 and rel(ut, uo) < 1e-4 and abs(ct[0] - co) < 1e-5 * (1 + abs(co))
+    if name == "eagle_catch":
+        emu.emu_destroy(e)
+        return
+    emu.emu_set_warmstart(e, None, None)
+    emu.emu_solve_c(e, 100, 0)
+    xs_e = np.zeros((T + 1, nx))
+    us_e = np.zeros((T, nu))
+    ul = np.zeros((T, nu))
+    it = np.zeros(1, dtype=np.int32)
+    st = np.zeros(1, dtype=np.int32)
+    emu.emu_get(e, ob.P(xs_e), ob.P(us_e), ob.P(ul), ob.P(ce), it.ctypes.data_as(_ip), st.ctypes.data_as(_ip))
+    o.solve(None, None, 100)
+    r = o.result()
+    assert it[0] == r["iter"] and st[0] == r["status"]
+    assert np.abs(xs_e - r["xs"]).max() < 1e-6 and np.abs(us_e - r["us"]).max() < 1e-4  # north-star bound on the controls
     emu.emu_destroy(e)

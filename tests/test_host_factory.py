@@ -222,11 +222,23 @@ def test_every_shipped_trajectory_builds_and_has_a_kernel(empc):
         assert empc.solver_supported(p), (f, empc.last_error())
         classes.add((d.model.nbodies, d.n_rotors, bool(d.has_contact)))
     assert classes == {(1, 4, False), (1, 6, False), (3, 6, False), (4, 6, False), (4, 6, True), (6, 6, False)}
-    # the options the factory accepts but the device does not implement are refused with a reason, not silently
+    # both integrators of the factory (src/factory/int-action.cpp:24-31) have kernels
     t = empc.Trajectory()
     t.autoSetup(empc.yaml_path("hexacopter370/trajectories/hover.yaml"))
-    assert not empc.solver_supported(t.createProblem(40, True, "IntegratedActionModelRK4"))
-    assert "IntegratedActionModelEuler" in empc.last_error()
+    assert empc.solver_supported(t.createProblem(40, True, "IntegratedActionModelRK4"))
+    # what the device does not implement is refused with a reason, not silently: a 6D contact
+    t = empc.Trajectory()
+    t.autoSetup(empc.yaml_path("hexacopter370_flying_arm_3/trajectories/eagle_catch.yaml"))
+    p = t.createProblem(32, True, "IntegratedActionModelEuler")
+    d = p.desc
+    patched = [(k, d.sets[k].contacts[0].type) for k in range(d.n_sets) if d.sets[k].ncontacts]
+    try:
+        for k, _ in patched:
+            d.sets[k].contacts[0].type = 1
+        assert not empc.solver_supported(p) and "ContactModel3D" in empc.last_error()
+    finally:
+        for k, ty in patched:
+            d.sets[k].contacts[0].type = ty
 
 
 def test_robot_models(problems):
