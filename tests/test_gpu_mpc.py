@@ -160,3 +160,17 @@ def test_weighted_closed_loop_matches_oracle(empc):
     traj, xs_ref, us_ref = planned_trajectory(empc)
     mpc = empc.WeightedMpc(traj, 80, empc.yaml_path(ARM3_MPC), batch=4)
     closed_loop(empc, mpc, xs_ref, us_ref, nq=traj.nx - traj.ndx // 2)
+
+
+def test_carrot_closed_loop_with_rk4_nodes(empc, tmp_path):
+    """`integration_method: IntegratedActionModelRK4` in the controller YAML (src/mpc-base.cpp:41-43,
+    src/mpc-controllers/carrot-mpc.cpp:216-217): the receding-horizon problem is built from RK4 nodes; closed loop on the
+    GPU against the oracle."""
+    src = open(empc.yaml_path(ARM3_MPC)).read()
+    assert "IntegratedActionModelEuler" in src
+    f = tmp_path / "mpc_rk4.yaml"
+    f.write_text(src.replace("IntegratedActionModelEuler", "IntegratedActionModelRK4"))
+    traj, xs_ref, us_ref = planned_trajectory(empc)
+    mpc = empc.CarrotMpc(traj, xs_ref, 80, str(f), batch=2)
+    assert mpc.problem.desc.integrator == 1
+    closed_loop(empc, mpc, xs_ref, us_ref, nq=traj.nx - traj.ndx // 2, B=2, n_steps=4, tol=1e-5)
