@@ -353,6 +353,12 @@ void empc_solver_params_default(EmpcSolverParams* p) {
   p->gap_norm = EMPC_GAP_L1;
   p->terminal_dt_scaling = 1;
   p->smoothsat_power = 2;
+  p->solver_type = EMPC_SOLVER_SBFDDP;
+  p->box_th_stop = 5e-5;  // crocoddyl SolverBox{DDP,FDDP} constructors (~1.8)
+  p->boxqp_th_acceptstep = 0.1;
+  p->boxqp_th_grad = 1e-5;
+  p->boxqp_reg = 0.0;
+  p->boxqp_maxiter = 100;
 }
 
 }  // extern "C"

@@ -90,7 +90,9 @@ class SolverParams(C.Structure):
         ("reg_incfactor", d), ("reg_decfactor", d), ("reg_min", d), ("reg_max", d),
         ("th_gaptol", d),
         ("n_alphas", i32), ("stop_criteria", i32), ("gap_norm", i32), ("terminal_dt_scaling", i32),
-        ("smoothsat_power", i32), ("reserved", i32),
+        ("smoothsat_power", i32), ("solver_type", i32),
+        ("box_th_stop", d), ("boxqp_th_acceptstep", d), ("boxqp_th_grad", d), ("boxqp_reg", d),
+        ("boxqp_maxiter", i32), ("reserved", i32),
     ]
 
 
@@ -111,6 +113,7 @@ class TapeLayout(C.Structure):
                  "ld_fx", "ld_fu", "ld_lxx", "ld_lxu", "ld_luu")]
 
 
+SOLVER_SBFDDP, SOLVER_BOXFDDP, SOLVER_BOXDDP = 0, 1, 2
 STATUS_CONVERGED = 1
 STATUS_REG_MAX = 2
 STATUS_MAXITER = 4

@@ -146,6 +146,10 @@ typedef struct EmpcProblemDesc {
  * block selects among the behaviours that the un-vendored Crocoddyl fork leaves unpinned (A.8). */
 enum EmpcStopCriteria { EMPC_STOP_COST_REDUCTION = 0, EMPC_STOP_EXPECTED_REDUCTION = 1, EMPC_STOP_QU_NORM = 2 };
 enum EmpcGapNorm { EMPC_GAP_L1 = 0, EMPC_GAP_LINF = 1 };
+/* Which solver the handle is: the fork's SolverSbFDDP (src/sbfddp.cpp) or crocoddyl's SolverBoxFDDP / SolverBoxDDP, the
+ * other two back ends MpcAbstract accepts (include/eagle_mpc/mpc-base.hpp:36-47, src/mpc-controllers/carrot-mpc.cpp:232-242)
+ * and the `useSquash = False` branch of the reference's examples (examples/python/trajectory.py:20-23). */
+enum EmpcSolverType { EMPC_SOLVER_SBFDDP = 0, EMPC_SOLVER_BOXFDDP = 1, EMPC_SOLVER_BOXDDP = 2 };
 
 typedef struct EmpcSolverParams {
   double smooth_init, smooth_mult;             /* 0.1, 0.5  (sbfddp.cpp:9-10)   */
@@ -162,6 +166,12 @@ typedef struct EmpcSolverParams {
   int32_t gap_norm;                            /* U1: EmpcGapNorm               */
   int32_t terminal_dt_scaling;                 /* U2: 1 = terminal node is IAM.calc(x,u=0), scaled by dt */
   int32_t smoothsat_power;                     /* U3: 2 (d^2) or 4 (d^4)        */
+  int32_t solver_type;                         /* EmpcSolverType                */
+  /* crocoddyl SolverBoxFDDP / SolverBoxDDP (~1.8; SURVEY A.8 register, unpinned like the rest of A.1): convergence
+   * threshold of the box solvers and the BoxQP(nu, maxiter, th_acceptstep, th_grad, reg) they construct */
+  double box_th_stop;                          /* 5e-5                          */
+  double boxqp_th_acceptstep, boxqp_th_grad, boxqp_reg; /* 0.1, 1e-5, 0        */
+  int32_t boxqp_maxiter;                       /* 100                           */
   int32_t reserved;
 } EmpcSolverParams;
 

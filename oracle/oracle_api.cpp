@@ -40,6 +40,12 @@ void oracle_solver_params_default(EmpcSolverParams* p) {
   p->gap_norm = EMPC_GAP_L1;
   p->terminal_dt_scaling = 1;
   p->smoothsat_power = 2;
+  p->solver_type = EMPC_SOLVER_SBFDDP;
+  p->box_th_stop = 5e-5;  // crocoddyl SolverBox{DDP,FDDP} constructors (~1.8)
+  p->boxqp_th_acceptstep = 0.1;
+  p->boxqp_th_grad = 1e-5;
+  p->boxqp_reg = 0.0;
+  p->boxqp_maxiter = 100;
 }
 
 void* oracle_solver_create(const EmpcProblemDesc* d, const EmpcSolverParams* p) {
@@ -188,6 +194,11 @@ int oracle_phase_forward(void* h, double alpha, int ddp, double* xs_try, double*
     d01[1] = s->d[1];
   }
   return ok ? 1 : 0;
+}
+// crocoddyl::BoxQP::solve restated (oracle/solver.hpp box_qp), for the known-answer test: returns 1 on success
+int oracle_box_qp(void* h, int m, const double* H, const double* q, const double* lb, const double* ub, const double* xinit,
+                  double* x, int* free_mask, double* Hinv) {
+  return static_cast<Solver*>(h)->box_qp(H, q, lb, ub, xinit, m, x, free_mask, Hinv) ? 1 : 0;
 }
 // expectedImprovementDDP (src/sbfddp.cpp:395-408) after oracle_phase_backward: d0 = sum Qu.k, d1 = -sum k.Quu k
 void oracle_phase_expected_ddp(void* h, double* d01) {

@@ -51,7 +51,7 @@ struct Solver {
     ndx = d_.ndx;
     nu = d_.nu;
     x0.assign(d_.x0, d_.x0 + nx);
-    barrier_init();
+    if (prm.solver_type == EMPC_SOLVER_SBFDDP) barrier_init();  // SolverSbFDDP's own cost; the crocoddyl solvers add nothing
     auto mk = [&](std::vector<std::vector<double>>& v, int n, int sz) { v.assign(n, std::vector<double>(sz, 0.0)); };
     mk(xs, T + 1, nx);
     mk(xs_try, T + 1, nx);
@@ -196,6 +196,95 @@ struct Solver {
     }
   }
 
+  // crocoddyl::BoxQP::solve (core/solvers/box-qp.cpp, ~1.8): projected Newton on min 1/2 x'Hx + q'x, lb <= x <= ub, warm
+  // started at xinit.  Outputs x, the free set (mask) and the inverse of the free block of H (embedded in an m x m matrix
+  // with zero clamped rows / columns).  Returns false when a factorisation fails.
+  bool box_qp(const double* H, const double* q, const double* lb, const double* ub, const double* xinit, int m, double* x,
+              int* free_mask, double* Hinv) {
+    double g[NU], xnew[NU], dx[NU];
+    int prev_mask[NU];
+    bool have_inv = false;
+    for (int i = 0; i < m; ++i) {
+      x[i] = std::max(std::min(xinit[i], ub[i]), lb[i]);
+      prev_mask[i] = -1;
+    }
+    auto factor_free = [&](const int* mask) {
+      // LLT of the free block, as an m x m problem with the clamped dimensions decoupled (unit pivots): same arithmetic
+      // on the free entries as factoring Hff alone
+      double Hm[NU * NU];
+      for (int i = 0; i < m; ++i)
+        for (int j = 0; j < m; ++j)
+          Hm[i * m + j] = (mask[i] && mask[j]) ? H[i * m + j] + ((i == j) ? P.prm.boxqp_reg : 0.0) : ((i == j) ? 1.0 : 0.0);
+      if (!cholesky(Hm, m)) return false;
+      for (int c = 0; c < m; ++c) {
+        double col[NU];
+        for (int i = 0; i < m; ++i) col[i] = (i == c) ? 1.0 : 0.0;
+        cholesky_solve(Hm, m, col);
+        for (int i = 0; i < m; ++i) Hinv[i * m + c] = (mask[i] && mask[c]) ? col[i] : 0.0;
+      }
+      for (int i = 0; i < m; ++i) prev_mask[i] = mask[i];
+      have_inv = true;
+      return true;
+    };
+    for (int k = 0; k < P.prm.boxqp_maxiter; ++k) {
+      double gmax = 0;
+      int nf = 0;
+      for (int i = 0; i < m; ++i) {
+        double a = q[i];
+        for (int j = 0; j < m; ++j) a += H[i * m + j] * x[j];
+        g[i] = a;
+        gmax = std::max(gmax, std::fabs(a));
+      }
+      for (int j = 0; j < m; ++j) {
+        const bool clamped = (x[j] == lb[j] && g[j] > 0.0) || (x[j] == ub[j] && g[j] < 0.0);
+        free_mask[j] = clamped ? 0 : 1;
+        nf += free_mask[j];
+      }
+      if (gmax <= P.prm.boxqp_th_grad || nf == 0) {
+        bool same = have_inv;
+        for (int i = 0; i < m; ++i) same = same && prev_mask[i] == free_mask[i];
+        if (!same && !factor_free(free_mask)) return false;  // (the reference factors at k == 0; later it keeps the last one)
+        return true;
+      }
+      if (!factor_free(free_mask)) return false;
+      // Newton step on the free space: dxf = -Hff^-1 (qf + Hfc xc) - xf
+      for (int i = 0; i < m; ++i) {
+        dx[i] = 0;
+        if (!free_mask[i]) continue;
+        double a = 0;
+        for (int j = 0; j < m; ++j) {
+          if (!free_mask[j]) continue;
+          double r = -q[j];
+          for (int c = 0; c < m; ++c)
+            if (!free_mask[c]) r -= H[j * m + c] * x[c];
+          a += Hinv[i * m + j] * r;
+        }
+        dx[i] = a - x[i];
+      }
+      auto fval = [&](const double* z) {
+        double f = 0;
+        for (int i = 0; i < m; ++i) {
+          double a = 0;
+          for (int j = 0; j < m; ++j) a += H[i * m + j] * z[j];
+          f += 0.5 * z[i] * a + q[i] * z[i];
+        }
+        return f;
+      };
+      const double fold = fval(x);
+      for (double alpha : alphas) {
+        for (int i = 0; i < m; ++i) xnew[i] = std::max(std::min(x[i] + alpha * dx[i], ub[i]), lb[i]);
+        const double fnew = fval(xnew);
+        double gd = 0;
+        for (int i = 0; i < m; ++i) gd += g[i] * (x[i] - xnew[i]);
+        if (fold - fnew > P.prm.boxqp_th_acceptstep * gd) {
+          for (int i = 0; i < m; ++i) x[i] = xnew[i];
+          break;
+        }
+      }
+    }
+    return true;
+  }
+
   // SolverDDP::backwardPass + computeGains (A.2). Returns false on "backward_error".
   bool backward_pass() {
     const int n = ndx, m = nu;
@@ -253,17 +342,39 @@ struct Solver {
       }
       if (!std::isnan(ureg))
         for (int i = 0; i < m; ++i) Quu[t][i * m + i] += ureg;
-      // computeGains
-      L = Quu[t];
-      if (!cholesky(L.data(), m)) return false;
-      for (int j = 0; j < n; ++j) {
-        double col[NU];
-        for (int i = 0; i < m; ++i) col[i] = Qxu[t][j * m + i];
-        cholesky_solve(L.data(), m, col);
-        for (int i = 0; i < m; ++i) K[t][i * n + j] = col[i];
+      // computeGains.  SolverBoxDDP::computeGains always, SolverBoxFDDP::computeGains once the trajectory is feasible:
+      // k from the box QP over [u_lb - us, u_ub - us], K on the free controls only, Qu zeroed on the clamped ones
+      const bool box_gains = P.prm.solver_type == EMPC_SOLVER_BOXDDP || (P.prm.solver_type == EMPC_SOLVER_BOXFDDP && is_feasible);
+      if (box_gains) {
+        double lb[NU], ub[NU], xq[NU], Hinv[NU * NU];
+        int fm[NU];
+        for (int i = 0; i < m; ++i) {
+          lb[i] = P.d.u_lb[i] - us[t][i];
+          ub[i] = P.d.u_ub[i] - us[t][i];
+        }
+        if (!box_qp(Quu[t].data(), Qu[t].data(), lb, ub, k[t].data(), m, xq, fm, Hinv)) return false;
+        for (int i = 0; i < m; ++i)
+          for (int j = 0; j < n; ++j) {
+            double acc = 0;
+            for (int l = 0; l < m; ++l) acc += Hinv[i * m + l] * Qxu[t][j * m + l];
+            K[t][i * n + j] = acc;
+          }
+        for (int i = 0; i < m; ++i) {
+          k[t][i] = -xq[i];
+          if (!fm[i]) Qu[t][i] = 0.0;
+        }
+      } else {
+        L = Quu[t];
+        if (!cholesky(L.data(), m)) return false;
+        for (int j = 0; j < n; ++j) {
+          double col[NU];
+          for (int i = 0; i < m; ++i) col[i] = Qxu[t][j * m + i];
+          cholesky_solve(L.data(), m, col);
+          for (int i = 0; i < m; ++i) K[t][i * n + j] = col[i];
+        }
+        k[t] = Qu[t];
+        cholesky_solve(L.data(), m, k[t].data());
       }
-      k[t] = Qu[t];
-      cholesky_solve(L.data(), m, k[t].data());
       // value function
       for (int i = 0; i < m; ++i) {
         double acc = 0;
@@ -401,6 +512,8 @@ struct Solver {
         for (int j = 0; j < ndx; ++j) acc -= K[t][i * ndx + j] * dx[t][j];
         us_try[t][i] = acc;
       }
+      if (P.prm.solver_type != EMPC_SOLVER_SBFDDP)  // SolverBox{DDP,FDDP}::forwardPass: clamp to the control limits
+        for (int i = 0; i < nu; ++i) us_try[t][i] = std::min(std::max(us_try[t][i], P.d.u_lb[i]), P.d.u_ub[i]);
       calc_node(t, xs_try[t].data(), us_try[t].data(), false, D);
       xnext.assign(D.xnext, D.xnext + nx);
       if (ddp) xs_try[t + 1] = xnext;
@@ -444,7 +557,8 @@ struct Solver {
   }
   // fork-only stoppingCriteria() (U1)
   void stopping_criteria() {
-    switch (P.prm.stop_criteria) {
+    // the crocoddyl solvers use SolverDDP::stoppingCriteria (sum |Qu|^2), whatever the fork-only option says
+    switch (P.prm.solver_type != EMPC_SOLVER_SBFDDP ? (int)EMPC_STOP_QU_NORM : P.prm.stop_criteria) {
       case EMPC_STOP_COST_REDUCTION:
         stop = std::fabs(cost_prev - cost);
         break;
@@ -475,8 +589,9 @@ struct Solver {
     trace.push_back(r);
   }
 
-  // sbfddp.cpp:228-315
-  bool solve_fddp(int maxiter, bool feasible, double reginit) {
+  // sbfddp.cpp:228-315; upstream = crocoddyl::SolverFDDP::solve's own test (was_feasible_ && stop_ < th_stop_), used by
+  // SolverBoxFDDP
+  bool solve_fddp(int maxiter, bool feasible, double reginit, bool upstream = false) {
     is_feasible = feasible;
     xreg = ureg = std::isnan(reginit) ? P.prm.reg_min : reginit;
     was_feasible = false;
@@ -518,7 +633,7 @@ struct Solver {
       }
       stopping_criteria();
       record();
-      if (stopping_test_gaps()) return true;
+      if (upstream ? stopping_test_feasible() : stopping_test_gaps()) return true;
     }
     iter = iter >= maxiter ? maxiter - 1 : iter;
     status |= EMPC_STATUS_MAXITER;
@@ -578,6 +693,23 @@ struct Solver {
     trace.clear();
     phase = 0;
     bool last = false;
+    if (P.prm.solver_type != EMPC_SOLVER_SBFDDP) {
+      // crocoddyl::SolverBoxFDDP / SolverBoxDDP::solve(init_xs, init_us, maxiter, is_feasible): one loop, th_stop_ = 5e-5.
+      // The BoxQP of knot t is warm-started at k_[t]: zeros for a fresh solver.  Every solve starts from zeros here (a
+      // solver object serves many rollouts of a batch; the warm start moves the QP's path, not its optimum).
+      for (auto& kt : k) std::fill(kt.begin(), kt.end(), 0.0);
+      th_stop = P.prm.box_th_stop;
+      if (P.prm.solver_type == EMPC_SOLVER_BOXFDDP) {
+        last = solve_fddp(maxiter, feasible_arg, P.prm.reg_init, true);
+      } else {
+        phase = 100;
+        last = solve_ddp(maxiter, P.prm.reg_init);
+      }
+      total_iters = iter + 1;
+      iter = total_iters - 1;
+      if (last) status |= EMPC_STATUS_CONVERGED;
+      return true;
+    }
     while (convergence >= P.prm.convergence_stop) {
       P.smooth = smooth;       // squashingUpdate
       barrier_update(smooth);  // barrierUpdate

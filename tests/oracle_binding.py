@@ -48,6 +48,7 @@ def orc():
         L.oracle_phase_forward.argtypes = [C.c_void_p, C.c_double, C.c_int, _dp, _dp, _dp, _dp]
         L.oracle_phase_tape.argtypes = [C.c_void_p, C.c_int] + [_dp] * 9
         L.oracle_phase_expected_ddp.argtypes = [C.c_void_p, _dp]
+        L.oracle_box_qp.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp, _ip, _dp]
         L.oracle_solve_batch.restype = C.c_double
         L.oracle_solve_batch.argtypes = [C.POINTER(T.ProblemDesc), C.POINTER(T.SolverParams), C.c_int, _dp, C.c_int, C.c_int,
                                          _dp, _dp, _dp, _dp, _ip, _ip]
@@ -172,6 +173,14 @@ class OracleSolver:
         dgdq = np.zeros(2)
         ok = orc().oracle_phase_backward(self.h, float(xreg), P(K), P(k), P(Vx), P(Vxx), P(dgdq))
         return bool(ok), K, k, Vx, Vxx, dgdq
+
+    def box_qp(self, H, q, lb, ub, xinit):
+        m = len(q)
+        H, q, lb, ub, xinit = [np.ascontiguousarray(a, dtype=np.float64) for a in (H, q, lb, ub, xinit)]
+        x, Hinv = np.zeros(m), np.zeros((m, m))
+        fm = np.zeros(m, dtype=np.int32)
+        ok = orc().oracle_box_qp(self.h, m, P(H), P(q), P(lb), P(ub), P(xinit), P(x), fm.ctypes.data_as(_ip), P(Hinv))
+        return bool(ok), x, fm.astype(bool), Hinv
 
     def phase_expected_ddp(self):
         d01 = np.zeros(2)

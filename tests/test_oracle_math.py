@@ -258,3 +258,36 @@ def test_ddp_invariants(problems):
         feas = tr[tr[:, 0] == ph][:, 6]
         cc = c[feas > 0]
         assert np.all(np.diff(cc) <= 1e-9)
+
+
+def test_box_qp_known_answers(problems):
+    """The BoxQP of SolverBoxFDDP / SolverBoxDDP (crocoddyl core/solvers/box-qp): unconstrained optimum when the box is
+    wide, KKT conditions of the box-constrained optimum otherwise (zero gradient on the free set, sign conditions on the
+    clamped set), inverse of the free Hessian block embedded with zero clamped rows / columns."""
+    o = ob.OracleSolver(problems["hover"][1].desc)
+    rng = np.random.default_rng(8)
+    for trial in range(40):
+        m = 6
+        A = rng.normal(size=(m, m))
+        H = A @ A.T + 0.5 * np.eye(m)
+        q = rng.normal(size=m) * 3
+        wide = trial % 4 == 0
+        lb = -np.full(m, 1e3) if wide else -rng.uniform(0.05, 1.0, size=m)
+        ub = np.full(m, 1e3) if wide else rng.uniform(0.05, 1.0, size=m)
+        ok, x, free, Hinv = o.box_qp(H, q, lb, ub, np.zeros(m))
+        assert ok and (x >= lb).all() and (x <= ub).all()
+        g = q + H @ x
+        if wide:
+            assert free.all() and np.abs(x + np.linalg.solve(H, q)).max() < 1e-8
+        assert np.abs(g[free]).max(initial=0.0) < 1e-4  # th_grad = 1e-5 on the whole gradient at the accepted iterate
+        at_lb, at_ub = ~free & (x == lb), ~free & (x == ub)
+        assert (at_lb | at_ub)[~free].all() and (g[at_lb] > 0).all() and (g[at_ub] < 0).all()
+        if free.any():
+            idx = np.flatnonzero(free)
+            assert np.abs(Hinv[np.ix_(idx, idx)] - np.linalg.inv(H[np.ix_(idx, idx)])).max() < 1e-9
+        assert np.abs(Hinv[~free]).max(initial=0.0) == 0.0 and np.abs(Hinv[:, ~free]).max(initial=0.0) == 0.0
+        # the box optimum is no worse than projected random feasible points
+        f = lambda z: 0.5 * z @ H @ z + q @ z
+        for _ in range(20):
+            z = rng.uniform(lb if not wide else -3, ub if not wide else 3, size=m)
+            assert f(x) <= f(z) + 1e-6
