@@ -71,6 +71,7 @@ def lib():
     L.empc_solver_create.restype = C.c_void_p
     L.empc_solver_create.argtypes = [C.POINTER(T.ProblemDesc), C.POINTER(T.SolverParams), C.c_int, C.c_int]
     L.empc_solver_destroy.argtypes = [C.c_void_p]
+    L.empc_mpc_solver_type.argtypes = [C.c_void_p, C.c_void_p]
     L.empc_solver_supported.argtypes = [C.POINTER(T.ProblemDesc), C.POINTER(T.SolverParams)]
     L.empc_solver_update_problem.argtypes = [C.c_void_p, C.POINTER(T.ProblemDesc)]
     L.empc_solver_set_x0.argtypes = [C.c_void_p, _dp]
@@ -269,10 +270,13 @@ class SolverSbFDDP:
     trajectory 0, under the reference's property names (``xs``, ``us``, ``us_squash``, ``iter``, ``cost``).
     """
 
+    SOLVER_TYPE = T.SOLVER_SBFDDP
+
     def __init__(self, problem, batch=1, device=0, params=None):
         self.problem = problem
         self.batch = int(batch)
-        prm = params if params is not None else default_params()
+        prm = T.SolverParams.from_buffer_copy(params) if params is not None else default_params()
+        prm.solver_type = self.SOLVER_TYPE
         h = lib().empc_solver_create(C.byref(problem.desc), C.byref(prm), self.batch, int(device))
         if not h:
             raise EmpcError(lib().empc_last_error().decode())
@@ -490,6 +494,25 @@ class SolverSbFDDP:
             pass
 
 
+class SolverBoxFDDP(SolverSbFDDP):
+    """crocoddyl.SolverBoxFDDP on the same kernels (crocoddyl 1.8 core/solvers/box-fddp.cpp): the backward pass solves one
+    box QP per knot for the feed-forward term, the gains live on the free subspace, the forward pass clamps the controls.
+    Build the problem without squashing (``trajectory.createProblem(dt, False, ...)``), as
+    src/mpc-controllers/carrot-mpc.cpp:188-193 does for this solver.  ``us_squash`` equals ``us``."""
+
+    SOLVER_TYPE = T.SOLVER_BOXFDDP
+
+
+class SolverBoxDDP(SolverSbFDDP):
+    """crocoddyl.SolverBoxDDP (core/solvers/box-ddp.cpp): the box-QP backward pass with DDP's gap-free rollout."""
+
+    SOLVER_TYPE = T.SOLVER_BOXDDP
+
+
+_SOLVER_CLASSES = {T.SOLVER_SBFDDP: SolverSbFDDP, T.SOLVER_BOXFDDP: SolverBoxFDDP, T.SOLVER_BOXDDP: SolverBoxDDP}
+SOLVER_NAMES = {T.SOLVER_SBFDDP: "SolverSbFDDP", T.SOLVER_BOXFDDP: "SolverBoxFDDP", T.SOLVER_BOXDDP: "SolverBoxDDP"}
+
+
 class MpcProblem:
     """The controller's ShootingProblem (get_problem()); owned by the controller."""
 
@@ -545,11 +568,13 @@ class CarrotMpc:
         self.problem = MpcProblem(self)
         self._batch, self._device, self._params = int(batch), int(device), params
         self._solver = None
+        self.solver_type = SOLVER_NAMES[lib().empc_mpc_solver_type(self._h, None)]  # get_solver_type(), the YAML's `solver:`
 
     @property
     def solver(self):
         if self._solver is None:
-            self._solver = SolverSbFDDP(self.problem, batch=self._batch, device=self._device, params=self._params)
+            cls = _SOLVER_CLASSES[lib().empc_mpc_solver_type(self._h, None)]
+            self._solver = cls(self.problem, batch=self._batch, device=self._device, params=self._params)
         return self._solver
 
     def updateProblem(self, current_time):
@@ -582,11 +607,13 @@ class _Mpc:
         self.problem = MpcProblem(self, prefix="empc_mpc")
         self._batch, self._device, self._params = int(batch), int(device), params
         self._solver = None
+        self.solver_type = SOLVER_NAMES[lib().empc_mpc_solver_type(None, self._h)]
 
     @property
     def solver(self):
         if self._solver is None:
-            self._solver = SolverSbFDDP(self.problem, batch=self._batch, device=self._device, params=self._params)
+            cls = _SOLVER_CLASSES[lib().empc_mpc_solver_type(None, self._h)]
+            self._solver = cls(self.problem, batch=self._batch, device=self._device, params=self._params)
         return self._solver
 
     def updateProblem(self, current_time):

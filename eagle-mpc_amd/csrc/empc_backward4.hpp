@@ -16,6 +16,7 @@
 //     -K (B operand of the Vxx update) and used for Vx without a round trip.
 #pragma once
 #include "empc_backward3.hpp"
+#include "empc_boxqp.hpp"
 
 namespace empc {
 
@@ -38,11 +39,14 @@ struct Bwd4Smem {
   static constexpr int OFF_RED = OFF_KF + 2 * m;                      // 3 x 32 partial sums
   static constexpr int OFF_FLAG = OFF_RED + 96;
   static constexpr int OFF_ZERO = OFF_FLAG + 2;                       // a word that holds 0.0 (H entries outside the matrix)
-  static constexpr int OFF_PRO = OFF_ZERO + 2;                        // prologue reductions: 3 x 64
+  static constexpr int OFF_HINV = OFF_ZERO + 2;                       // m x m: inverse of the free block of Quu (box solvers)
+  static constexpr int OFF_PRO = OFF_HINV + m * m;                    // prologue reductions: 3 x 64
   static constexpr int SIZE = (OFF_PRO + 3 * 64 + 1) / 2 * 2;
 };
 
-template <class DM, class Exec>
+// BOX: the instantiation for crocoddyl's SolverBoxFDDP / SolverBoxDDP (box-QP gains); the squash-box solver's instantiation
+// carries none of that code, so its register allocation is that of the plain pass
+template <class DM, bool BOX, class Exec>
 EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) {
   typedef Bwd4Smem<DM> SM;
   constexpr int NL = 64;
@@ -65,6 +69,7 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
   double* red = smem + SM::OFF_RED;
   double* flag = smem + SM::OFF_FLAG;
   double* pro = smem + SM::OFF_PRO;
+  double* Hinv = smem + SM::OFF_HINV;
   const double* tape = D.tape + (size_t)b * (T + 1) * REC;
 
   // ---- prologue: cost, gap norms, feasibility (as backward3) ---------------------------------------------------------
@@ -282,6 +287,51 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
       BWD_STAMP(2);
       // computeGains: LLT(Quu + ureg I) in every lane; lane j < n solves column j of K = Quu^-1 Qxu^T, lane n solves k and
       // forms Quu k.  The columns stay in registers.
+      // SolverBoxDDP::computeGains always, SolverBoxFDDP::computeGains once the trajectory is feasible: k from the box QP over
+      // [u_lb - us, u_ub - us] (one lane), K = (free block of Quu)^-1 Qux on the free controls and zero on the clamped ones, Qu
+      // zeroed on the clamped ones (it enters the stopping criterion, the expected improvement and Vx below)
+      const bool box_gains = BOX && (P.prm.solver_type == EMPC_SOLVER_BOXDDP || (P.prm.solver_type == EMPC_SOLVER_BOXFDDP && is_feasible));
+      if (box_gains) {
+        ex.each([&](int lane, int sl) {
+          if (lane != n) return;
+          double Hq[m * m], qq[m], lbq[m], ubq[m], xq[m], hinv[m * m];
+          int fm[m];
+          const double* usg = D.us + ((size_t)b * T + t) * m;
+          const double* kprev = D.kff + ((size_t)b * T + t) * m;  // k_[t] of the previous iteration: the QP's warm start
+#pragma unroll
+          for (int i = 0; i < m; ++i) {
+#pragma unroll
+            for (int j = 0; j < m; ++j) Hq[i * m + j] = Q[(n + (i > j ? i : j)) * QS + n + (i > j ? j : i)] + ((i == j) ? ureg : 0.0);
+            qq[i] = Q[(n + i) * QS + nm];
+            lbq[i] = P.u_lb[i] - usg[i];
+            ubq[i] = P.u_ub[i] - usg[i];
+            xq[i] = kprev[i];
+          }
+          const bool okq = box_qp_lane<m>(Hq, qq, lbq, ubq, xq, fm, hinv, P.prm.boxqp_maxiter, P.prm.boxqp_th_acceptstep,
+                                          P.prm.boxqp_th_grad, P.prm.boxqp_reg, D.NA);
+          flag[0] = okq ? 0.0 : 1.0;
+#pragma unroll
+          for (int i = 0; i < m * m; ++i) Hinv[i] = hinv[i];
+#pragma unroll
+          for (int i = 0; i < m; ++i) {
+            kf[i] = -xq[i];
+            Kc[sl][i] = -xq[i];
+            if (!fm[i]) Q[(n + i) * QS + nm] = 0.0;
+          }
+        });
+        ex.sync();
+        ex.each([&](int lane, int sl) {
+          if (lane >= n) return;
+#pragma unroll
+          for (int i = 0; i < m; ++i) {
+            double a_ = 0;
+#pragma unroll
+            for (int l = 0; l < m; ++l) a_ += Hinv[i * m + l] * Q[lane * QS + n + l];
+            Kc[sl][i] = a_;
+            Kn[i * KS + lane] = -a_;
+          }
+        });
+      } else
       ex.each([&](int lane, int sl) {
         double Lq[m * (m + 1) / 2];
 #pragma unroll

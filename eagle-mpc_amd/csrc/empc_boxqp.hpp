@@ -1,0 +1,113 @@
+// empc_boxqp.hpp -- crocoddyl::BoxQP::solve (core/solvers/box-qp.cpp, ~1.8) for one lane: the box-constrained QP behind
+// SolverBoxDDP::computeGains / SolverBoxFDDP::computeGains, i.e. the `SolverBoxFDDP` / `SolverBoxDDP` back ends MpcAbstract
+// accepts (include/eagle_mpc/mpc-base.hpp:36-47) and the reference's examples fall back to with useSquash = False.
+//   min 1/2 x'Hx + q'x  s.t. lb <= x <= ub : projected Newton, active set from the sign of the gradient at the bounds,
+//   Armijo backtracking over alpha = 2^-n.  Oracle: oracle/solver.hpp box_qp (same structure, same constants).
+// The free block of H is factored as an M x M problem with the clamped dimensions decoupled (unit pivots), so that nothing
+// is indexed through a run-time list.
+#pragma once
+#include "empc_dev_model.hpp"
+
+namespace empc {
+
+// H: full M x M (row-major), symmetric positive definite on the free block.  x: in = warm start, out = solution.
+// free_mask[i] = 1 for free components; Hinv: inverse of the free block, zero rows / columns for clamped components.
+// Returns false when a factorisation fails (crocoddyl throws "backward_error").
+template <int M>
+EMPC_HD bool box_qp_lane(const double* H, const double* q, const double* lb, const double* ub, double* x, int* free_mask, double* Hinv,
+                         int maxiter, double th_acceptstep, double th_grad, double reg, int n_alphas) {
+  double g[M], xnew[M], dx[M];
+  int prev_mask[M];
+  bool have_inv = false, ok = true;
+#pragma unroll
+  for (int i = 0; i < M; ++i) {
+    x[i] = fmax(fmin(x[i], ub[i]), lb[i]);
+    prev_mask[i] = -1;
+  }
+  auto factor_free = [&](const int* mask) {
+    double L[M * (M + 1) / 2];
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+      for (int j = 0; j <= i; ++j)
+        L[i * (i + 1) / 2 + j] = (mask[i] && mask[j]) ? H[i * M + j] + ((i == j) ? reg : 0.0) : ((i == j) ? 1.0 : 0.0);
+    if (!chol_packed<M>(L)) return false;
+    for (int c = 0; c < M; ++c) {
+      double col[M];
+#pragma unroll
+      for (int i = 0; i < M; ++i) col[i] = (i == c) ? 1.0 : 0.0;
+      chol_solve_packed<M>(L, col);
+#pragma unroll
+      for (int i = 0; i < M; ++i) Hinv[i * M + c] = (mask[i] && mask[c]) ? col[i] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < M; ++i) prev_mask[i] = mask[i];
+    have_inv = true;
+    return true;
+  };
+  auto fval = [&](const double* z) {
+    double f = 0;
+    for (int i = 0; i < M; ++i) {
+      double a = 0;
+#pragma unroll
+      for (int j = 0; j < M; ++j) a += H[i * M + j] * z[j];
+      f += 0.5 * z[i] * a + q[i] * z[i];
+    }
+    return f;
+  };
+  for (int k = 0; k < maxiter; ++k) {
+    double gmax = 0;
+    int nf = 0;
+    for (int i = 0; i < M; ++i) {
+      double a = q[i];
+#pragma unroll
+      for (int j = 0; j < M; ++j) a += H[i * M + j] * x[j];
+      g[i] = a;
+      gmax = fmax(gmax, fabs(a));
+    }
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+      const bool clamped = (x[j] == lb[j] && g[j] > 0.0) || (x[j] == ub[j] && g[j] < 0.0);
+      free_mask[j] = clamped ? 0 : 1;
+      nf += free_mask[j];
+    }
+    if (gmax <= th_grad || nf == 0) {
+      bool same = have_inv;
+#pragma unroll
+      for (int i = 0; i < M; ++i) same = same && prev_mask[i] == free_mask[i];
+      if (!same) ok = factor_free(free_mask);
+      return ok;
+    }
+    if (!factor_free(free_mask)) return false;
+    // Newton step on the free space: dxf = -Hff^-1 (qf + Hfc xc) - xf
+    for (int i = 0; i < M; ++i) {
+      double a = 0;
+      for (int j = 0; j < M; ++j) {
+        if (!free_mask[j]) continue;
+        double r = -q[j];
+        for (int c = 0; c < M; ++c)
+          if (!free_mask[c]) r -= H[j * M + c] * x[c];
+        a += Hinv[i * M + j] * r;
+      }
+      dx[i] = free_mask[i] ? a - x[i] : 0.0;
+    }
+    const double fold = fval(x);
+    for (int ia = 0; ia < n_alphas; ++ia) {
+      const double alpha = ldexp(1.0, -ia);
+#pragma unroll
+      for (int i = 0; i < M; ++i) xnew[i] = fmax(fmin(x[i] + alpha * dx[i], ub[i]), lb[i]);
+      const double fnew = fval(xnew);
+      double gd = 0;
+#pragma unroll
+      for (int i = 0; i < M; ++i) gd += g[i] * (x[i] - xnew[i]);
+      if (fold - fnew > th_acceptstep * gd) {
+#pragma unroll
+        for (int i = 0; i < M; ++i) x[i] = xnew[i];
+        break;
+      }
+    }
+  }
+  return true;
+}
+
+}  // namespace empc

@@ -285,6 +285,20 @@ int empc_mpc_params(const EmpcMpc* m, int* knots, int* iters, int* dt_ms, int* n
   return EMPC_OK;
   EMPC_CATCH(EMPC_ERR_INVALID)
 }
+/* EmpcSolverType named by the controller's YAML (`solver:`), for either controller handle (NULL for the other) */
+int empc_mpc_solver_type(const EmpcCarrotMpc* carrot, const EmpcMpc* other) {
+  const eagle_mpc::MpcAbstract* a = carrot ? static_cast<const eagle_mpc::MpcAbstract*>(carrot->m.get())
+                                           : (other ? static_cast<const eagle_mpc::MpcAbstract*>(other->m.get()) : nullptr);
+  if (!a) return -1;
+  switch (a->get_solver_type()) {
+    case eagle_mpc::SolverTypes::SolverSbFDDP:
+      return EMPC_SOLVER_SBFDDP;
+    case eagle_mpc::SolverTypes::SolverBoxFDDP:
+      return EMPC_SOLVER_BOXFDDP;
+    default:
+      return EMPC_SOLVER_BOXDDP;
+  }
+}
 int empc_mpc_update_problem(EmpcMpc* m, long long current_time_ms) {
   EMPC_TRY
   if (!m) throw std::invalid_argument("controller is NULL");

@@ -97,6 +97,7 @@ struct DevBuffers {
   int trace_cap = 0;
   int B, T, NA;
   int integrator = 0;  // EmpcIntegrator of the problem (host copy: selects the kernel forms that support it)
+  int solver_type = 0; // EmpcSolverType (host copy): the box solvers need the kernel forms that implement them
   int raw = 0;         // linearize: write the differential model's derivatives (da/dx, da/du, unscaled costs) instead of the
                        // Euler node's -- the stage records of IntegratedActionModelRK4 (empc_rk4.hpp)
   double gaptol;    // feasibility tolerance actually used: max(th_gaptol, 1e-13)
@@ -193,7 +194,8 @@ EMPC_HD bool rollout_knot(const EMPC_K DevProblem& P, const SetT& set, RollLane<
       double a_ = uc[i] - kk[i] * alpha;
 #pragma unroll
       for (int j = 0; j < NDX; ++j) a_ -= KK[i * NDX + j] * dx[j];
-      utry[i] = a_;
+      // SolverBox{DDP,FDDP}::forwardPass clamp the trial control to the limits of the model
+      utry[i] = (P.prm.solver_type != EMPC_SOLVER_SBFDDP) ? fmin(fmax(a_, P.u_lb[i]), P.u_ub[i]) : a_;
     }
     EMPC_STAMP(0);  // x_try, state difference, feedback
     node_nominal<DM, CT>(P, set, smooth, xtry, utry, false, L.xnext, acc, cost, usq, lam, stp);
@@ -549,8 +551,11 @@ EMPC_HD void select_decide(const DevBuffers& D, int b, int& accepted_ai, int& la
       st.status |= EMPC_STATUS_REG_MAX;
       phase_end = true;
     } else {
-      // stoppingCriteria (fork, U1)
-      if (prm.stop_criteria == EMPC_STOP_COST_REDUCTION)
+      // stoppingCriteria (fork, U1); the crocoddyl box solvers use SolverDDP::stoppingCriteria = sum |Qu|^2
+      const bool box = prm.solver_type != EMPC_SOLVER_SBFDDP;
+      if (box)
+        st.stop = st.qu2;
+      else if (prm.stop_criteria == EMPC_STOP_COST_REDUCTION)
         st.stop = fabs(st.cost_prev - st.cost);
       else if (prm.stop_criteria == EMPC_STOP_EXPECTED_REDUCTION)
         st.stop = fabs(st.d0 + 0.5 * st.d1);
@@ -573,8 +578,10 @@ EMPC_HD void select_decide(const DevBuffers& D, int b, int& accepted_ai, int& la
         r[11] = st.d1;
         st.trace_count += 1;
       }
-      const bool stop_now = ddp ? (st.was_feasible && st.stop < st.th_stop)
-                                : (st.stop < st.th_stop && st.gapnorm < prm.th_stop_gaps);
+      // SolverDDP / SolverFDDP::solve (and the fork's solveDDP) stop on was_feasible_ && stop_ < th_stop_; the fork's solveFDDP
+      // on its gap test
+      const bool stop_now = (ddp || box) ? (st.was_feasible && st.stop < st.th_stop)
+                                         : (st.stop < st.th_stop && st.gapnorm < prm.th_stop_gaps);
       if (stop_now) {
         phase_end = true;
         returned = true;
@@ -592,6 +599,14 @@ EMPC_HD void select_decide(const DevBuffers& D, int b, int& accepted_ai, int& la
   if (phase_end) {
     st.total_iters += st.iter + 1;
     bool next_fddp = false;
+    if (prm.solver_type != EMPC_SOLVER_SBFDDP) {
+      // SolverBoxFDDP / SolverBoxDDP: a single loop, no continuation and no clean-up pass
+      st.phase = PHASE_DONE;
+      st.iter = st.total_iters - 1;
+      if (st.last_ok) st.status |= EMPC_STATUS_CONVERGED;
+      st.bwd_failed = 0;
+      return;
+    }
     if (!ddp) {
       st.smooth_next *= prm.smooth_mult;
       st.convergence *= prm.convergence_mult;

@@ -201,11 +201,11 @@ __global__ void __launch_bounds__(64) k_backward3(DevBuffers D) {
 }
 
 // the shipped backward pass: matrix cores, zero-padded LDS tiles (empc_backward4.hpp)
-template <class DM>
+template <class DM, bool BOX>
 __global__ void __launch_bounds__(64) k_backward4(DevBuffers D) {
   extern __shared__ double smem_bwd4[];
   BlockExec ex{(int)threadIdx.x};
-  backward_traj4<DM>(ex, D, blockIdx.x, smem_bwd4);
+  backward_traj4<DM, BOX>(ex, D, blockIdx.x, smem_bwd4);
 }
 
 template <class DM>
@@ -391,10 +391,12 @@ static void launch_backward(DevBuffers D, hipStream_t s) {
     const char* e = getenv("EMPC_BACKWARD");  // 2 = vector form, 3 = matrix-core form, 4 = matrix cores + padded tiles (default)
     return e ? atoi(e) : 4;
   }();
-  if (version == 2)
+  if (version == 2 && D.solver_type == EMPC_SOLVER_SBFDDP)
     hipLaunchKernelGGL(k_backward<DM>, dim3(D.B), dim3(EMPC_BWD_NL), sizeof(double) * Bwd2Smem<DM>::SIZE, s, D);
+  else if (D.solver_type != EMPC_SOLVER_SBFDDP)  // the BoxQP gains exist in this form only
+    hipLaunchKernelGGL((k_backward4<DM, true>), dim3(D.B), dim3(64), sizeof(double) * Bwd4Smem<DM>::SIZE, s, D);
   else if (version == 4)
-    hipLaunchKernelGGL(k_backward4<DM>, dim3(D.B), dim3(64), sizeof(double) * Bwd4Smem<DM>::SIZE, s, D);
+    hipLaunchKernelGGL((k_backward4<DM, false>), dim3(D.B), dim3(64), sizeof(double) * Bwd4Smem<DM>::SIZE, s, D);
   else
     hipLaunchKernelGGL(k_backward3<DM>, dim3(D.B), dim3(64), sizeof(double) * Bwd3Smem<DM>::SIZE, s, D);
 }
@@ -407,7 +409,7 @@ static void launch_rollout(DevBuffers D, hipStream_t s) {
   }();
   if (version == 1 || D.NA > MAX_ALPHAS || D.integrator != EMPC_INTEGRATOR_EULER) {  // RK4 nodes: the per-lane form
     hipLaunchKernelGGL((k_rollout<DM, CT>), dim3((n + 63) / 64), dim3(64), 0, s, D);
-  } else if (version == 6) {
+  } else if (version == 6 || D.solver_type != EMPC_SOLVER_SBFDDP) {  // (the clamp of the box solvers: forms 6 and 1)
     const size_t smem = sizeof(double) * Roll6Smem<DM>::SIZE;
     static const bool once = [&] {  // more than 64 KB of dynamic LDS needs the opt-in
       (void)hipFuncSetAttribute((const void*)k_rollout6<DM, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);

@@ -80,8 +80,8 @@ inline void prepare_problem(const EmpcProblemDesc& d, const EmpcSolverParams& pr
   H.x0.assign(d.x0, d.x0 + d.nx);
   for (int t = 0; t <= d.T; ++t)
     if (H.knot_set[t] < 0 || H.knot_set[t] >= d.n_sets) throw std::invalid_argument("knot table references a missing cost set");
-  // barrierInit: once per distinct running model
-  {
+  // barrierInit: once per distinct running model -- SolverSbFDDP's own cost; the crocoddyl box solvers add nothing
+  if (prm.solver_type == EMPC_SOLVER_SBFDDP) {
     std::vector<char> done(H.sets.size(), 0);
     for (int t = 0; t < d.T; ++t) {
       const int si = H.knot_set[t];
@@ -221,6 +221,14 @@ inline void init_traj_state(TrajState& s, const EmpcSolverParams& prm, int maxit
   z.steplength = 1.0;
   z.need_calc = 1;
   z.need_lin = 1;
+  if (prm.solver_type != EMPC_SOLVER_SBFDDP) {
+    // crocoddyl::SolverBoxFDDP / SolverBoxDDP::solve: one loop from the candidate's feasibility flag, th_stop_ = 5e-5
+    z.phase = (prm.solver_type == EMPC_SOLVER_BOXDDP) ? PHASE_DDP : 0;
+    z.is_feasible = is_feasible_arg ? 1 : 0;
+    z.th_stop = prm.box_th_stop;
+    s = z;
+    return;
+  }
   if (prm.convergence_init >= prm.convergence_stop) {
     z.phase = 0;
     z.is_feasible = 0;  // solveFDDP(maxiter, false, reg_init_)

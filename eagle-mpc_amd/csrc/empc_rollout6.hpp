@@ -393,7 +393,8 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
           double a_ = n_us[i] - n_kf[i] * L.alpha;
 #pragma unroll
           for (int j = 0; j < NDX; ++j) a_ -= n_K[i * NDX + j] * dx[j];
-          s[i] = a_;
+          // SolverBox{DDP,FDDP}::forwardPass clamp the trial control to the limits of the model
+          s[i] = (P.prm.solver_type != EMPC_SOLVER_SBFDDP) ? fmin(fmax(a_, P.u_lb[i]), P.u_ub[i]) : a_;
         }
       } else {
 #pragma unroll

@@ -269,6 +269,10 @@ EmpcSolver* empc_solver_create(const EmpcProblemDesc* problem, const EmpcSolverP
   D.NA = s->NA;
   D.gaptol = std::max(prm.th_gaptol, 1e-13);
   D.integrator = problem->integrator;
+  D.solver_type = prm.solver_type;
+  if (prm.solver_type < EMPC_SOLVER_SBFDDP || prm.solver_type > EMPC_SOLVER_BOXDDP) throw std::invalid_argument("unknown solver_type");
+  HIP_CHECK(hipMemsetAsync(D.kff, 0, sizeof(double) * B * T * k.nu, s->stream));
+  HIP_CHECK(hipMemsetAsync(D.K, 0, sizeof(double) * B * T * k.nu * k.ndx, s->stream));
   if (problem->integrator == EMPC_INTEGRATOR_RK4) {
     s->R4.ys = s->dalloc<double>(4 * B * (T + 1) * k.nx);
     s->R4.accs = s->dalloc<double>(4 * B * (T + 1) * k.nacc);
@@ -506,6 +510,8 @@ int empc_solver_solve(EmpcSolver* s, int maxiter, int is_feasible) {
     init_traj_state(s->h_st[b], s->H.P.prm, maxiter, is_feasible != 0, s->have_state ? &prev : nullptr);
   }
   upload_states(s);
+  if (s->D.solver_type != EMPC_SOLVER_SBFDDP)  // the BoxQP of knot t is warm-started at k_[t]: zeros at the start of a solve
+    HIP_CHECK(hipMemsetAsync(s->D.kff, 0, sizeof(double) * s->B * s->T * s->kt.nu, s->stream));
   HIP_CHECK(hipStreamSynchronize(s->stream));
   EmpcSolveStats& S = s->stats;
   std::memset(&S, 0, sizeof(S));

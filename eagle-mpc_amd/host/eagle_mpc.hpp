@@ -253,7 +253,10 @@ class Trajectory : public std::enable_shared_from_this<Trajectory> {
 class SolverSbFDDP {
  public:
   // squashing model == the problem's (u_lb, u_ub) smooth saturation; batch_size trajectories on HIP device `device`
-  explicit SolverSbFDDP(const std::shared_ptr<ShootingProblem>& problem, std::size_t batch_size = 1, int device = 0);
+  // solver_type: EMPC_SOLVER_SBFDDP (the fork's solver, default) or the crocoddyl back ends MpcAbstract also accepts --
+  // EMPC_SOLVER_BOXFDDP / EMPC_SOLVER_BOXDDP (include/eagle_mpc/mpc-base.hpp:36-47); same handle type, same getters
+  explicit SolverSbFDDP(const std::shared_ptr<ShootingProblem>& problem, std::size_t batch_size = 1, int device = 0,
+                        int solver_type = EMPC_SOLVER_SBFDDP);
   ~SolverSbFDDP();
   SolverSbFDDP(const SolverSbFDDP&) = delete;
   SolverSbFDDP& operator=(const SolverSbFDDP&) = delete;

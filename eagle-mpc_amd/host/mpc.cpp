@@ -67,10 +67,11 @@ VectorXd MpcAbstract::zero_state() const {
 
 const std::shared_ptr<SolverSbFDDP>& MpcAbstract::get_solver(std::size_t batch_size, int device) {
   if (!solver_) {
-    // only the squash-box solver is built here (SolverBoxFDDP / SolverBoxDDP are out of scope)
-    if (params_.solver_type != SolverTypes::SolverSbFDDP)
-      throw std::runtime_error("MpcAbstract: only solver 'SolverSbFDDP' is available in this build");
-    solver_ = std::make_shared<SolverSbFDDP>(problem_, batch_size, device);
+    // src/mpc-controllers/carrot-mpc.cpp:232-242: eagle_mpc::SolverSbFDDP, crocoddyl::SolverBoxFDDP or crocoddyl::SolverBoxDDP
+    const int st = params_.solver_type == SolverTypes::SolverSbFDDP    ? EMPC_SOLVER_SBFDDP
+                   : params_.solver_type == SolverTypes::SolverBoxFDDP ? EMPC_SOLVER_BOXFDDP
+                                                                       : EMPC_SOLVER_BOXDDP;
+    solver_ = std::make_shared<SolverSbFDDP>(problem_, batch_size, device, st);
   } else if (solver_->get_batch_size() != batch_size) {
     throw std::invalid_argument("MpcAbstract: the solver already exists with a different batch size");
   }

@@ -7,11 +7,12 @@
 
 namespace eagle_mpc {
 
-SolverSbFDDP::SolverSbFDDP(const std::shared_ptr<ShootingProblem>& problem, std::size_t batch_size, int device)
+SolverSbFDDP::SolverSbFDDP(const std::shared_ptr<ShootingProblem>& problem, std::size_t batch_size, int device, int solver_type)
     : problem_(problem), batch_(batch_size) {
   if (!problem) throw std::invalid_argument("SolverSbFDDP: problem is null");
   EmpcSolverParams prm;
   empc_solver_params_default(&prm);
+  prm.solver_type = solver_type;
   handle_ = empc_solver_create(&problem_->desc(), &prm, (int)batch_size, device);
   if (!handle_) throw std::runtime_error(std::string("SolverSbFDDP: ") + empc_last_error());
   const std::size_t T = problem_->get_T();

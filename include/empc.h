@@ -203,6 +203,10 @@ EmpcMpc* empc_weighted_mpc_create(EmpcTrajectory* t, int dt_ref_ms, const char* 
 void empc_mpc_destroy(EmpcMpc* m);
 /* get_knots / get_iters / get_dt (src/mpc-base.cpp:81-85) and the problem's dimensions */
 int empc_mpc_params(const EmpcMpc* m, int* knots, int* iters, int* dt_ms, int* nx, int* ndx, int* nu);
+/* get_solver_type() (src/mpc-base.cpp:85): the EmpcSolverType the controller's YAML names (`solver: SolverSbFDDP |
+ * SolverBoxFDDP | SolverBoxDDP`); pass the handle you have and NULL for the other.  Create the solver with that
+ * EmpcSolverParams.solver_type (src/mpc-controllers/carrot-mpc.cpp:232-242). */
+int empc_mpc_solver_type(const EmpcCarrotMpc* carrot, const EmpcMpc* other);
 /* updateProblem(current_time)   rail-mpc.cpp:151-161, weighted-mpc.cpp:170-185 */
 int empc_mpc_update_problem(EmpcMpc* m, long long current_time_ms);
 /* problem.x0 = x0 */

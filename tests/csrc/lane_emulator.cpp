@@ -231,9 +231,12 @@ static void emu_backward(Emu& e) {
   std::vector<double> smem3(Bwd3Smem<DM>::SIZE);
   std::vector<double> smem4(Bwd4Smem<DM>::SIZE);
   for (int b = 0; b < e.B; ++b) {
-    if (g_bwd_version == 4) {
+    if (g_bwd_version == 4 || e.H.P.prm.solver_type != EMPC_SOLVER_SBFDDP) {
       CpuExec<64> ex{64};
-      backward_traj4<DM>(ex, e.D, b, smem4.data());  // the shipped form: matrix cores, zero-padded tiles
+      if (e.H.P.prm.solver_type != EMPC_SOLVER_SBFDDP)
+        backward_traj4<DM, true>(ex, e.D, b, smem4.data());
+      else
+        backward_traj4<DM, false>(ex, e.D, b, smem4.data());  // the shipped form: matrix cores, zero-padded tiles
       continue;
     }
     if (g_bwd_version == 3) {
@@ -254,7 +257,8 @@ static int g_roll_version = 6;
 template <class DM>
 static void emu_rollout(Emu& e) {
   const bool ct = e.H.P.has_contact != 0;
-  if (g_roll_version == 6 && e.NA <= MAX_ALPHAS && e.H.P.integrator == EMPC_INTEGRATOR_EULER) {  // the shipped form: packed trajectories, role wavefronts (Euler nodes)
+  if ((g_roll_version == 6 || (g_roll_version == 5 && e.H.P.prm.solver_type != EMPC_SOLVER_SBFDDP)) && e.NA <= MAX_ALPHAS &&
+      e.H.P.integrator == EMPC_INTEGRATOR_EULER) {  // the shipped form: packed trajectories, role wavefronts (Euler nodes)
     const int G = roll6_group_size(e.NA);
     std::vector<double> smem6(Roll6Smem<DM>::SIZE);
     for (int grp = 0; grp * G < e.B; ++grp) {
@@ -308,6 +312,7 @@ static void emu_solve(Emu& e, int maxiter, int is_feasible) {
     TrajState prev = e.st[b];
     init_traj_state(e.st[b], e.H.P.prm, maxiter, is_feasible != 0, &prev);
   }
+  if (e.H.P.prm.solver_type != EMPC_SOLVER_SBFDDP) std::fill(e.kff.begin(), e.kff.end(), 0.0);
   e.sweeps = 0;
   while (true) {
     emu_calc<DM>(e);

@@ -291,3 +291,49 @@ def test_rk4_kernel_bodies_vs_oracle(empc, emu, name, dt):
     assert it[0] == r["iter"] and st[0] == r["status"]
     assert np.abs(xs_e - r["xs"]).max() < 1e-6 and np.abs(us_e - r["us"]).max() < 1e-4  # north-star bound on the controls
     emu.emu_destroy(e)
+
+
+@pytest.mark.parametrize("solver_type", [1, 2])
+@pytest.mark.parametrize("name,dt,warm", [("hover", 40, False), ("displacement", 80, False), ("displacement", 80, True)])
+def test_box_solvers_vs_oracle(empc, emu, name, dt, warm, solver_type):
+    """crocoddyl SolverBoxFDDP (1) / SolverBoxDDP (2) through the device code on the CPU lane emulator -- BoxQP gains with
+    clamped Qu in the backward pass, clamped trial controls in the rollout, the upstream solve loop in select -- against
+    the oracle: iteration count, status, controls inside their limits, same trajectory.  `warm`: from the SbFDDP solution
+    (feasible start: the BoxQP path from the first iteration, also for BoxFDDP)."""
+    from conftest import CONFIGS
+    tr = empc.Trajectory()
+    tr.autoSetup(empc.yaml_path(CONFIGS[name][0]))
+    problem = tr.createProblem(dt, False, "IntegratedActionModelEuler")  # useSquash = False (examples/python/trajectory.py:11,20-23)
+    d = problem.desc
+    prm = ob.default_params()
+    prm.solver_type = solver_type
+    maxiter = 30
+    xs0 = us0 = None
+    if warm:
+        sq = tr.createProblem(dt, True, "IntegratedActionModelEuler")
+        o0 = ob.OracleSolver(sq.desc)
+        o0.solve(None, None, 100)
+        r0 = o0.result()
+        xs0, us0 = r0["xs"], np.ascontiguousarray(r0["us_squash"])  # squashed controls: inside the limits
+    emu.emu_set_linearize_version(2)
+    emu.emu_set_backward_version(4)
+    emu.emu_set_rollout_version(6)
+    e = C.c_void_p(emu.emu_create(C.byref(d), C.byref(prm), 1))
+    assert e.value
+    emu.emu_set_warmstart(e, None if xs0 is None else ob.P(xs0), None if us0 is None else ob.P(us0))
+    emu.emu_solve_c(e, maxiter, 1 if warm else 0)
+    T, nx, nu = d.T, d.nx, d.nu
+    xs_e, us_e, ul, ce = np.zeros((T + 1, nx)), np.zeros((T, nu)), np.zeros((T, nu)), np.zeros(1)
+    it, st = np.zeros(1, dtype=np.int32), np.zeros(1, dtype=np.int32)
+    emu.emu_get(e, ob.P(xs_e), ob.P(us_e), ob.P(ul), ob.P(ce), it.ctypes.data_as(_ip), st.ctypes.data_as(_ip))
+    o = ob.OracleSolver(d, prm)
+    o.solve(xs0, us0, maxiter, is_feasible=warm)
+    r = o.result()
+    assert it[0] == r["iter"] and st[0] == r["status"], (it, r["iter"], st, r["status"])
+    lb = np.array([d.u_lb[i] for i in range(nu)])
+    ub = np.array([d.u_ub[i] for i in range(nu)])
+    assert (us_e >= lb - 1e-12).all() and (us_e <= ub + 1e-12).all()
+    if abs(r["cost"]) < 1e6:
+        assert np.abs(xs_e - r["xs"]).max() < 1e-5 and np.abs(us_e - r["us"]).max() < 1e-4
+        assert abs(ce[0] - r["cost"]) < 1e-7 * (1 + abs(r["cost"]))
+    emu.emu_destroy(e)

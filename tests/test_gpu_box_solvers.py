@@ -1,0 +1,85 @@
+"""crocoddyl's SolverBoxFDDP / SolverBoxDDP on the GPU against the CPU oracle (the two other
+back ends MpcAbstract accepts, include/eagle_mpc/mpc-base.hpp:36-47, src/mpc-controllers/carrot-mpc.cpp:232-242).
+
+Problems are built without squashing (`createProblem(dt, False, ...)`, examples/python/trajectory.py:11,20-23): the controls
+are the rotor thrusts themselves, kept inside [u_lb, u_ub] by the box QP in the backward pass and the clamp in the rollout.
+"""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from conftest import CONFIGS
+
+pytestmark = pytest.mark.gpu
+
+CLASSES = {1: "SolverBoxFDDP", 2: "SolverBoxDDP"}
+
+
+def box_problem(empc, name, dt):
+    tr = empc.Trajectory()
+    tr.autoSetup(empc.yaml_path(CONFIGS[name][0]))
+    return tr, tr.createProblem(dt, False, "IntegratedActionModelEuler")
+
+
+@pytest.mark.parametrize("solver_type", [1, 2])
+@pytest.mark.parametrize("name,dt", [("hover", 40), ("displacement", 80), ("eagle_catch", 32), ("push_slide", 13)])
+def test_box_solve_matches_oracle(empc, name, dt, solver_type):
+    """Cold start on a batch of perturbed initial states: same iteration counts and status as the oracle, controls inside
+    their limits, trajectories within the north-star bound (1e-4 on the controls) wherever the solve stayed bounded."""
+    tr, problem = box_problem(empc, name, dt)
+    d = problem.desc
+    B, maxiter = 8, 30
+    x0s = empc.perturbed_x0s(problem.x0, B, nq=d.model.nq)
+    solver = getattr(empc, CLASSES[solver_type])(problem, batch=B)
+    solver.enable_trace(64)
+    solver.solve([], [], maxiter, x0s=x0s)
+    prm = ob.default_params()
+    prm.solver_type = solver_type
+    ref = ob.solve_batch(d, x0s, maxiter, nthreads=4, params=prm)
+    assert np.array_equal(solver.iter_batch, ref["iter"]), (solver.iter_batch, ref["iter"])
+    assert np.array_equal(solver.status_batch, ref["status"]), (solver.status_batch, ref["status"])
+    lb = np.array([d.u_lb[i] for i in range(d.nu)])
+    ub = np.array([d.u_ub[i] for i in range(d.nu)])
+    us = solver.us_batch
+    assert (us >= lb - 1e-12).all() and (us <= ub + 1e-12).all()
+    assert np.array_equal(solver.us_squash_batch, us)  # no squashing: us_squash is us
+    bounded = np.abs(ref["cost"]) < 1e6
+    assert bounded.sum() >= B // 2
+    assert np.abs(solver.xs_batch[bounded] - ref["xs"][bounded]).max() < 1e-5
+    assert np.abs(us[bounded] - ref["us"][bounded]).max() < 1e-4
+    assert np.allclose(solver.cost_batch[bounded], ref["cost"][bounded], rtol=1e-7, atol=1e-9)
+
+
+@pytest.mark.parametrize("solver_type", [1, 2])
+def test_box_solve_from_feasible_warm_start(empc, solver_type):
+    """Warm start from the squash-box solution (feasible: the BoxQP gains run from the first iteration for both solvers;
+    several rotor thrusts start on their bounds, so clamped directions, zeroed Qu entries and free-subspace gains are live)."""
+    tr, problem = box_problem(empc, "displacement", 80)
+    d = problem.desc
+    sq = tr.createProblem(80, True, "IntegratedActionModelEuler")
+    s0 = empc.SolverSbFDDP(sq, batch=1)
+    s0.solve([], [], 100)
+    xs0, us0 = np.array(s0.xs), np.array(s0.us_squash)
+    solver = getattr(empc, CLASSES[solver_type])(problem, batch=1)
+    solver.solve(xs0, us0, 30, is_feasible=True)
+    prm = ob.default_params()
+    prm.solver_type = solver_type
+    o = ob.OracleSolver(d, prm)
+    o.solve(xs0, us0, 30, is_feasible=True)
+    r = o.result()
+    assert solver.iter == r["iter"] and solver.status_batch[0] == r["status"]
+    assert np.abs(np.array(solver.xs) - r["xs"]).max() < 1e-5 and np.abs(np.array(solver.us) - r["us"]).max() < 1e-4
+    assert abs(solver.cost - r["cost"]) < 1e-7 * (1 + abs(r["cost"]))
+
+
+def test_box_solver_is_independent_of_batch_neighbours(empc):
+    """The same initial state solved alone and inside a batch gives bitwise the same result."""
+    tr, problem = box_problem(empc, "displacement", 80)
+    d = problem.desc
+    x0s = empc.perturbed_x0s(problem.x0, 6, nq=d.model.nq)
+    a = empc.SolverBoxFDDP(problem, batch=6)
+    a.solve([], [], 20, x0s=x0s)
+    b = empc.SolverBoxFDDP(problem, batch=1)
+    b.solve([], [], 20, x0s=x0s[3:4])
+    assert np.array_equal(a.xs_batch[3], b.xs_batch[0]) and np.array_equal(a.us_batch[3], b.us_batch[0])
+    assert a.iter_batch[3] == b.iter_batch[0]

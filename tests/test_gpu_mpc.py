@@ -49,32 +49,35 @@ def test_plant_rk4_parity(empc, problems, name):
         s2.plant_step(2)
 
 
-def planned_trajectory(empc, dt_traj=80):
+def planned_trajectory(empc, dt_traj=80, squashed=False):
     traj = empc.Trajectory()
     traj.autoSetup(empc.yaml_path(ARM3_TRAJ))
     prob = traj.createProblem(dt_traj, True, "IntegratedActionModelEuler")
     tsolver = empc.SolverSbFDDP(prob, batch=1)
     tsolver.solve([], [], 100)
-    return traj, np.array(tsolver.xs), np.array(tsolver.us)
+    return traj, np.array(tsolver.xs), np.array(tsolver.us_squash if squashed else tsolver.us)
 
 
-def closed_loop(empc, mpc, xs_ref, us_ref, nq, B=4, n_steps=6, dt_sim=2, tol=1e-6, sample=None):
+def closed_loop(empc, mpc, xs_ref, us_ref, nq, B=4, n_steps=6, dt_sim=2, tol=1e-6, sample=None, solver_type=0):
     """examples/python/mpc.py:30-62 on the GPU (B plants at once) and on the oracle (one plant at a time; `sample` =
     the plants the oracle follows, default all of them)."""
     sample = list(range(B)) if sample is None else list(sample)
     T_ = mpc.problem.T
     x_plants = empc.perturbed_x0s(xs_ref[0], B, nq=nq, amplitude=0.02)
     d = mpc.problem.desc
+    oprm = ob.default_params()
+    oprm.solver_type = solver_type
 
     mpc.updateProblem(0)
     solver = mpc.solver
+    assert solver.SOLVER_TYPE == solver_type
     solver.plant_states = x_plants
     # first solve: warm start = the head of the planned trajectory (mpc.py:38)
     solver.solve(xs_ref[:T_ + 1], us_ref[:T_], 100, x0s="plant")
     solver.convergence_init = 1e-3                                   # mpc.py:39
     o_xs, o_us, o_x = {}, {}, x_plants.copy()
     for b in sample:
-        s = ob.OracleSolver(d)
+        s = ob.OracleSolver(d, oprm)
         s.set_x0(o_x[b])
         s.solve(xs_ref[:T_ + 1], us_ref[:T_], 100)
         r = s.result()
@@ -92,7 +95,7 @@ def closed_loop(empc, mpc, xs_ref, us_ref, nq, B=4, n_steps=6, dt_sim=2, tol=1e-
         solver.plant_step(dt_sim)
         gx = solver.plant_states
         for b in sample:
-            s = ob.OracleSolver(d)
+            s = ob.OracleSolver(d, oprm)
             ob.orc().oracle_solver_set_convergence_init(s.h, C.c_double(1e-3))
             s.set_x0(o_x[b])
             s.solve(o_xs[b], o_us[b], mpc.iters)
@@ -174,3 +177,18 @@ def test_carrot_closed_loop_with_rk4_nodes(empc, tmp_path):
     mpc = empc.CarrotMpc(traj, xs_ref, 80, str(f), batch=2)
     assert mpc.problem.desc.integrator == 1
     closed_loop(empc, mpc, xs_ref, us_ref, nq=traj.nx - traj.ndx // 2, B=2, n_steps=4, tol=1e-5)
+
+
+@pytest.mark.parametrize("solver_name,solver_type", [("SolverBoxFDDP", 1), ("SolverBoxDDP", 2)])
+def test_carrot_closed_loop_with_box_solver(empc, tmp_path, solver_name, solver_type):
+    """`solver: SolverBoxFDDP | SolverBoxDDP` in the controller YAML (src/mpc-base.cpp:50,
+    src/mpc-controllers/carrot-mpc.cpp:188-193,232-242): the controller builds its nodes on the plain actuation and hands
+    them to crocoddyl's box solver; here the same kernels with the box-QP backward pass, closed loop against the oracle."""
+    src = open(empc.yaml_path(ARM3_MPC)).read()
+    assert "SolverSbFDDP" in src
+    f = tmp_path / "mpc_box.yaml"
+    f.write_text(src.replace("SolverSbFDDP", solver_name))
+    traj, xs_ref, us_ref = planned_trajectory(empc, squashed=True)  # rotor thrusts inside their limits
+    mpc = empc.CarrotMpc(traj, xs_ref, 80, str(f), batch=2)
+    assert mpc.solver_type == solver_name and not mpc.problem.desc.use_squash
+    closed_loop(empc, mpc, xs_ref, us_ref, nq=traj.nx - traj.ndx // 2, B=2, n_steps=4, tol=1e-5, solver_type=solver_type)
