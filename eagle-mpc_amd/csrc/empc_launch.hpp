@@ -247,7 +247,8 @@ __global__ void k_squash_out(DevBuffers D, double* out) {
   if (idx >= n) return;
   const int b = idx / (D.T * DM::NU), i = idx % DM::NU;
   const EMPC_K DevProblem& P = EMPC_KREF(DevProblem, D.P);
-  double u = D.us_last[idx], du;
+  // without squashing (the box solvers' problems) there is no squashing data to report: us_squash is the accepted us
+  double u = D.us[idx], du;
   if (P.use_squash) squash1(D.us_last[idx], P.u_lb[i], P.u_ub[i], D.st[b].smooth, P.prm.smoothsat_power, u, du);
   out[idx] = u;
 }
@@ -269,7 +270,7 @@ __global__ void k_pack_rows(DevBuffers D, double* out) {
     const size_t k = j - nxs;
     const int i = (int)(k % DM::NU);
     double du;
-    v = D.us_last[(size_t)b * nus + k];
+    v = D.us[(size_t)b * nus + k];
     if (P.use_squash) squash1(D.us_last[(size_t)b * nus + k], P.u_lb[i], P.u_ub[i], D.st[b].smooth, P.prm.smoothsat_power, v, du);
   } else {
     v = (j == nxs + nus) ? D.st[b].cost : (double)D.st[b].iter;
@@ -292,7 +293,7 @@ __global__ void __launch_bounds__(64) k_plant_rk4(DevBuffers D, double* x, const
     } else {
       const double s = D.us_last[(size_t)b * D.T * DM::NU + i];
       double du;
-      uu[i] = s;
+      uu[i] = D.us[(size_t)b * D.T * DM::NU + i];
       if (P.use_squash) squash1(s, P.u_lb[i], P.u_ub[i], D.st[b].smooth, P.prm.smoothsat_power, uu[i], du);
     }
   }

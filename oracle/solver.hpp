@@ -740,7 +740,7 @@ struct Solver {
       if (P.d.use_squash)
         squash(P, us_lastcalc[t].data(), u, nullptr);
       else
-        for (int i = 0; i < nu; ++i) u[i] = us_lastcalc[t][i];
+        for (int i = 0; i < nu; ++i) u[i] = us[t][i];  // no squashing data: the accepted controls
       for (int i = 0; i < nu; ++i) out[t * nu + i] = u[i];
     }
   }
