@@ -591,31 +591,49 @@ EMPC_HD void cone_rows(const double* nsurf, double mu, double AR[5][3]) {
     for (int j = 0; j < 3; ++j) AR[i][j] = A[i][0] * Rn[3 * j] + A[i][1] * Rn[3 * j + 1] + A[i][2] * Rn[3 * j + 2];
 }
 
-// ContactModel3D forward dynamics on top of the free solution: [M Jc^T; Jc 0][a; -lam] = [tau - h; -a0].
+// ContactModel3D / ContactModel6D forward dynamics on top of the free solution:
+// [M Jc^T; Jc 0][a; -lam] = [tau - h; -a0].
 // In: the Cholesky factor L of M (reciprocal diagonal), a = M^-1 (tau - h), the contact frame's capture ck (from the bias
 // pass: placement, LOCAL velocity, LOCAL acceleration at qdd = 0 with the gravity offset).  Out: a corrected in place,
-// lam[0..2] = contact force (LOCAL frame).  Three constraint rows, fixed at compile time (6D contacts are refused by
-// prepare_problem): every loop unrolls and Jc / M^-1 Jc^T stay in registers.
-template <class DM, class ContactT>
+// lam[0..NC-1] = contact force (NC = 3: LOCAL linear force; NC = 6: LOCAL wrench [f; n]).  The number of constraint rows is
+// fixed at compile time (one kernel instantiation per contact type): every loop unrolls and Jc / M^-1 Jc^T stay in registers.
+//   3D: a0 = a_lin + w x v_lin + g0 (p_f - xref) + g1 v_lin          (classical acceleration of the contact point)
+//   6D: a0 = a (spatial, LOCAL) + g0 log6(Mref^-1 oMf) + g1 v
+template <class DM, int NC, class ContactT>
 EMPC_HD void contact_forward(const EMPC_K EmpcModelDesc& m, const ContactT& ct, const FrameCap<double>& ck, const double* R0,
                              const double* q, const double* cs, const double* sn, const double* L, double* a, double* lam) {
   constexpr int NV = DM::NV;
-  constexpr int nc = 3;
+  constexpr int nc = NC;
+  static_assert(NC == 3 || NC == 6, "ContactModel3D or ContactModel6D");
   // drift (frame acceleration at qdd = 0, no gravity): the bias pass carries gravity as a base acceleration -g, which
   // reaches every frame as the pure translation R_f^T (-g); take it out again
   double ng[3] = {-m.gravity[0], -m.gravity[1], -m.gravity[2]}, gf[3], a0[6];
   matTvec3<double>(ck.R, ng, gf);
-  {
+  if constexpr (NC == 3) {
     double wxv[3];
     cross3<double>(ck.v + 3, ck.v, wxv);  // classical acceleration of the contact point
 #pragma unroll
     for (int r = 0; r < 3; ++r) a0[r] = (ck.a[r] - gf[r]) + wxv[r];
-  }
-  if (ct.gains[0] != 0.0) {
-    double dp[3], dpl[3];
-    for (int r = 0; r < 3; ++r) dp[r] = ck.p[r] - ct.ref_p[r];
-    matTvec3<double>(ck.R, dp, dpl);
-    for (int r = 0; r < 3; ++r) a0[r] += ct.gains[0] * dpl[r];
+    if (ct.gains[0] != 0.0)
+#pragma unroll
+      for (int r = 0; r < 3; ++r) a0[r] += ct.gains[0] * (ck.p[r] - ct.ref_p[r]);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      a0[r] = ck.a[r] - gf[r];
+      a0[3 + r] = ck.a[3 + r];
+    }
+    if (ct.gains[0] != 0.0) {
+      double rR[9], dp[3], rp[3], qq[4], xi[6];
+      matTmul3<double>(ct.ref_R, ck.R, rR);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) dp[r] = ck.p[r] - ct.ref_p[r];
+      matTvec3<double>(ct.ref_R, dp, rp);
+      R_to_quat(rR, qq);
+      log6_quat(qq, rp, xi);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) a0[r] += ct.gains[0] * xi[r];
+    }
   }
   if (ct.gains[1] != 0.0)
 #pragma unroll
@@ -631,6 +649,7 @@ EMPC_HD void contact_forward(const EMPC_K EmpcModelDesc& m, const ContactT& ct, 
       matTvec3<double>(ck.R, w, lin);
 #pragma unroll
       for (int r = 0; r < 3; ++r) Jc[r][j] = lin[r];
+      if constexpr (NC == 6) Jc[3][j] = Jc[4][j] = Jc[5][j] = 0.0;
     }
     double Rw[9], pw[3];
 #pragma unroll
@@ -665,6 +684,12 @@ EMPC_HD void contact_forward(const EMPC_K EmpcModelDesc& m, const ContactT& ct, 
       matTvec3<double>(ck.R, zxd, lin);
 #pragma unroll
       for (int r = 0; r < 3; ++r) Jc[r][j] = on_path ? lin[r] : 0.0;
+      if constexpr (NC == 6) {
+        double ang[3];
+        matTvec3<double>(ck.R, z, ang);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) Jc[3 + r][j] = on_path ? ang[r] : 0.0;
+      }
     }
   }
   double G[nc * (nc + 1) / 2];  // packed nc x nc
@@ -726,7 +751,7 @@ EMPC_HD void contact_forward(const EMPC_K EmpcModelDesc& m, const ContactT& ct, 
 // dam_nominal: ell_out is the UNSCALED cost sum; with `euler_xnext` != nullptr the semi-implicit Euler step is taken in the
 // middle of the function, where the r01 kernels had it (the compiler's schedule -- and with it the last bits of the
 // iteration path of ill-conditioned problems -- stays what the golden vectors were recorded with)
-template <class DM, bool CT, class SetT>
+template <class DM, int CT, class SetT>
 EMPC_HD void dam_nominal(const EMPC_K DevProblem& P, const SetT& set, double smooth, const double* x, const double* s_in,
                          bool terminal, double* euler_xnext, double* acc, double& ell_out, double* usq, double* lam_out,
                          unsigned long long* stp = nullptr) {
@@ -899,7 +924,7 @@ EMPC_HD void dam_nominal(const EMPC_K DevProblem& P, const SetT& set, double smo
 #pragma unroll
     for (int kk = 1; kk < NCAP; ++kk)
       if (kk == ccap) ck = caps[kk];
-    contact_forward<DM>(m, set.contacts[0], ck, R0, q, cs, sn, L, a, lam);
+    contact_forward<DM, CT>(m, set.contacts[0], ck, R0, q, cs, sn, L, a, lam);
   }
 #pragma unroll
   for (int i = 0; i < NV; ++i) acc[i] = a[i];
@@ -937,7 +962,7 @@ EMPC_HD void dam_nominal(const EMPC_K DevProblem& P, const SetT& set, double smo
 // IntegratedActionModelRK4::calc (src/factory/int-action.cpp:29-31; oracle/action.hpp node_calc_rk4): four evaluations
 // of the differential model at y_i = x (+) c_i dt k_{i-1}, k_i = [v(y_i); a(y_i, s)]; the acceleration / squashing /
 // contact outputs are those of stage 0 (src/sbfddp.cpp:144-145 reads differential[0]).
-template <class DM, bool CT, class SetT>
+template <class DM, int CT, class SetT>
 EMPC_HD void node_nominal_rk4(const EMPC_K DevProblem& P, const SetT& set, double smooth, const double* x, const double* s_in,
                               bool terminal, double* xnext, double* acc, double& cost_out, double* usq, double* lam_out) {
   constexpr int NV = DM::NV, NQ = DM::NQ, NX = DM::NX, NU = DM::NU, NDX = DM::NDX;
@@ -985,7 +1010,7 @@ EMPC_HD void node_nominal_rk4(const EMPC_K DevProblem& P, const SetT& set, doubl
   cost_out = ellsum * cscale;
 }
 
-template <class DM, bool CT, class SetT>
+template <class DM, int CT, class SetT>
 EMPC_HD void node_nominal(const EMPC_K DevProblem& P, const SetT& set, double smooth, const double* x, const double* s_in,
                           bool terminal, double* xnext, double* acc, double& cost_out, double* usq, double* lam_out,
                           unsigned long long* stp = nullptr) {

@@ -1,4 +1,4 @@
 // Kernel instantiation for (bodies, rotors) = Dims<3, 6> -- one translation unit per robot class so the build parallelises.
 #define EMPC_INSTANTIATE
 #include "empc_launch.hpp"
-KernelTable empc_table_3_6() { return make_table<Dims<3, 6>, false>(); }
+KernelTable empc_table_3_6() { return make_table<Dims<3, 6>, 0>(); }

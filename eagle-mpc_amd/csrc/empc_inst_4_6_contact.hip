@@ -1,4 +1,4 @@
 // Kernel instantiation for (bodies, rotors, contact dynamics) = Dims<4, 6> -- one translation unit per robot class so the build parallelises.
 #define EMPC_INSTANTIATE
 #include "empc_launch.hpp"
-KernelTable empc_table_4_6_contact() { return make_table<Dims<4, 6>, true>(); }
+KernelTable empc_table_4_6_contact() { return make_table<Dims<4, 6>, 3>(); }

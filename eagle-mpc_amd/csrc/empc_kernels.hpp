@@ -132,7 +132,7 @@ struct LaneExec {
 // =====================================================================================================================
 // calc: IAM.calc at (xs[t], us[t]) -> acc (and the last-calc control).  One lane per (b, t).
 // =====================================================================================================================
-template <class DM, bool CT>
+template <class DM, int CT>
 EMPC_HD void calc_thread(const DevBuffers& D, int b, int t) {
   const TrajState& st = D.st[b];
   if (st.phase == PHASE_DONE || !st.need_calc) return;
@@ -164,7 +164,7 @@ struct RollLane {
 // One knot of the forward pass for one trial.  The knot's nominal data comes through typed pointers so that the same
 // body serves any placement of that data (k_rollout reads it per lane from global memory).  Returns false when the trial
 // failed (NaN / overflow, crocoddyl's raiseIfNaN) and the caller must stop.
-template <class DM, bool CT, class SetT, class PX, class PU, class PK, class PG>
+template <class DM, int CT, class SetT, class PX, class PU, class PK, class PG>
 EMPC_HD bool rollout_knot(const EMPC_K DevProblem& P, const SetT& set, RollLane<DM>& L, int t, int T, bool plain, bool need_dv,
                           double alpha, double smooth, PX xc, PU uc, PU kk, PK KK, PG gap, PG vf, double* xs_o, double* us_o,
                           double* ac_o, unsigned long long* stp) {
@@ -232,7 +232,7 @@ EMPC_HD bool rollout_knot(const EMPC_K DevProblem& P, const SetT& set, RollLane<
   return true;
 }
 
-template <class DM, bool CT>
+template <class DM, int CT>
 EMPC_HD void rollout_thread(const DevBuffers& D, int b, int ai) {
   const TrajState& st = D.st[b];
   if (st.phase == PHASE_DONE || st.bwd_failed) return;
@@ -306,7 +306,7 @@ struct Roll5Smem {
   static constexpr int SIZE = (OFF_U + MAX_ALPHAS * NU + 1) / 2 * 2;
 };
 
-template <class DM, bool CT, class Exec>
+template <class DM, int CT, class Exec>
 EMPC_HD void rollout_wave5(Exec& ex, const DevBuffers& D, int b, int nl, double* N) {
   typedef Roll5Smem<DM> SM;
   const TrajState& st = D.st[b];

@@ -47,13 +47,14 @@ KernelTable empc_table_1_6();
 KernelTable empc_table_3_6();
 KernelTable empc_table_4_6();
 KernelTable empc_table_4_6_contact();
+KernelTable empc_table_4_6_contact6();
 KernelTable empc_table_6_6();
 
 #ifdef EMPC_INSTANTIATE
 // --------------------------------------------------------------------------------------------------------------------
 // kernels
 // --------------------------------------------------------------------------------------------------------------------
-template <class DM, bool CT>
+template <class DM, int CT>
 __global__ void __launch_bounds__(64) k_calc(DevBuffers D) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = D.B * (D.T + 1);
@@ -63,7 +64,7 @@ __global__ void __launch_bounds__(64) k_calc(DevBuffers D) {
   calc_thread<DM, CT>(D, b, t);
 }
 
-template <class DM, bool CT>
+template <class DM, int CT>
 __global__ void __launch_bounds__(64) k_rollout(DevBuffers D) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= D.B * D.NA) return;
@@ -72,7 +73,7 @@ __global__ void __launch_bounds__(64) k_rollout(DevBuffers D) {
 }
 
 // the shipped rollout: one wavefront per trajectory, lanes = step lengths, feedback product by the whole wave
-template <class DM, bool CT>
+template <class DM, int CT>
 __global__ void __launch_bounds__(64) k_rollout5(DevBuffers D) {
   extern __shared__ double smem_roll5[];
   static_assert(DM::NU <= 64, "feedback rows must fit one wavefront");
@@ -93,7 +94,7 @@ struct RoleExec {
   // drain them (vmcnt(0)) twice per knot.
   __device__ __forceinline__ void sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 };
-template <class DM, bool CT>
+template <class DM, int CT>
 __global__ void __launch_bounds__(64 * R6_WAVES) k_rollout6(DevBuffers D) {
   extern __shared__ double smem_roll6[];
   RoleExec ex{(int)(threadIdx.x & 63)};
@@ -108,7 +109,7 @@ __global__ void __launch_bounds__(64 * R6_WAVES) k_rollout6(DevBuffers D) {
     rollout_group6<DM, CT, R6_D>(ex, D, blockIdx.x, smem_roll6);
 }
 
-template <class DM, bool CT, int LPU, int BLK, bool FR>
+template <class DM, int CT, int LPU, int BLK, bool FR>
 // Two wavefronts per SIMD: at the compiler's own choice (326 registers, one wavefront per SIMD) the kernel sits at
 // ~1 resident wave per SIMD with 37 % of its time in waits; capping the budget at 256 registers costs ~250 spilled
 // values but doubles the resident waves: 2.02 -> 1.42 ms per launch (profiles/README.md).
@@ -308,12 +309,12 @@ __global__ void __launch_bounds__(64) k_plant_rk4(DevBuffers D, double* x, const
   for (int i = 0; i < DM::NX; ++i) x[(size_t)b * DM::NX + i] = xa[i];
 }
 
-template <class DM, bool CT>
+template <class DM, int CT>
 static void launch_calc(DevBuffers D, hipStream_t s) {
   const int n = D.B * (D.T + 1);
   hipLaunchKernelGGL((k_calc<DM, CT>), dim3((n + 63) / 64), dim3(64), 0, s, D);
 }
-template <class DM, bool CT, int BLK>
+template <class DM, int CT, int BLK>
 static void launch_linearize_blk(DevBuffers D, hipStream_t s) {
   constexpr int LPU = (3 * DM::NV <= 32) ? 32 : 64;
   constexpr int UPB = BLK / LPU;
@@ -338,7 +339,7 @@ static void launch_linearize_blk(DevBuffers D, hipStream_t s) {
   if (n_lean > 0) hipLaunchKernelGGL((k_linearize<DM, CT, LPU, BLK, false>), dim3(n_lean), dim3(BLK), smem, s, D);
   if (n_full > 0) hipLaunchKernelGGL((k_linearize<DM, CT, LPU, BLK, true>), dim3(n_full), dim3(BLK), smem, s, D);
 }
-template <class DM, bool CT>
+template <class DM, int CT>
 static void launch_linearize(DevBuffers D, hipStream_t s) {
   static const int blk = [] {
     const char* e = getenv("EMPC_LIN_BLOCK");
@@ -353,7 +354,7 @@ static void launch_linearize(DevBuffers D, hipStream_t s) {
 }
 // IntegratedActionModelRK4: stage states -> differential-model records of the 4 B stage trajectories (the linearize kernel
 // in RAW mode) -> chain rule per node (empc_rk4.hpp)
-template <class DM, bool CT>
+template <class DM, int CT>
 __global__ void __launch_bounds__(64) k_rk4_stages(DevBuffers D, Rk4Buffers R) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= D.B * (D.T + 1)) return;
@@ -367,7 +368,7 @@ __global__ void __launch_bounds__(64) k_rk4_assemble(DevBuffers D, Rk4Buffers R)
   const int u = blockIdx.x;
   rk4_assemble_unit<DM>(ex, D, R, u % D.B, u / D.B, 64, smem_rk4);
 }
-template <class DM, bool CT>
+template <class DM, int CT>
 static void launch_rk4_linearize(DevBuffers D, Rk4Buffers R, hipStream_t s) {
   const int n = D.B * (D.T + 1);
   hipLaunchKernelGGL((k_rk4_stages<DM, CT>), dim3((n + 63) / 64), dim3(64), 0, s, D, R);
@@ -401,7 +402,7 @@ static void launch_backward(DevBuffers D, hipStream_t s) {
   else
     hipLaunchKernelGGL(k_backward3<DM>, dim3(D.B), dim3(64), sizeof(double) * Bwd3Smem<DM>::SIZE, s, D);
 }
-template <class DM, bool CT>
+template <class DM, int CT>
 static void launch_rollout(DevBuffers D, hipStream_t s) {
   const int n = D.B * D.NA;
   static const int version = [] {
@@ -441,7 +442,7 @@ template <class DM>
 static void launch_plant(DevBuffers D, double* x, const double* u, double dt, int nsub, hipStream_t s) {
   hipLaunchKernelGGL(k_plant_rk4<DM>, dim3((D.B + 63) / 64), dim3(64), 0, s, D, x, u, dt, nsub);
 }
-template <class DM, bool CT>
+template <class DM, int CT>
 static KernelTable make_table() {
   KernelTable k;
   k.calc = launch_calc<DM, CT>;

@@ -43,13 +43,14 @@ struct Lin2Smem {
   static constexpr int SLOT = 3 * NDX + 36 + 4;       // r | Ar | Arr | J6 | value
   static constexpr int OFF_RSH = OFF_CST + NSLOT * SLOT;  // residual-Jacobian exchange 6 x (NDX + NU)
   static constexpr int OFF_RED = OFF_RSH + 6 * (NDX + NU);  // small reduction area (cost partial sums) 64
-  // contact block (ContactModel3D): lambda 6 | fext 6 | Jc 3 x NV | M^-1 Jc^T NV x 3 | G 9 | cone rows 15 + Ar 5 + Arr 5
+  // contact block (ContactModel3D: nc = 3 rows, ContactModel6D: nc = 6; sized for 6): lambda 6 | fext 6 | Jc nc x NV |
+  // M^-1 Jc^T NV x nc | packed G nc (nc + 1) / 2 | cone rows 15 + Ar 5 + Arr 5
   static constexpr int OFF_LAM = OFF_RED + 64;
   static constexpr int OFF_FEXT = OFF_LAM + 6;
   static constexpr int OFF_JC = OFF_FEXT + 6;
-  static constexpr int OFF_MIJ = OFF_JC + 3 * NV;
-  static constexpr int OFF_G = OFF_MIJ + 3 * NV;
-  static constexpr int OFF_CONE = OFF_G + 9;
+  static constexpr int OFF_MIJ = OFF_JC + 6 * NV;
+  static constexpr int OFF_G = OFF_MIJ + 6 * NV;
+  static constexpr int OFF_CONE = OFF_G + 22;
   static constexpr int SIZE = (OFF_CONE + 25 + 1) / 2 * 2;
   static constexpr int SIZE_NC = (OFF_LAM + 1) / 2 * 2;  // problems without contacts never touch the contact block
 };
@@ -440,7 +441,7 @@ struct LinRole {
   double* base;  // LDS of unit 0
   bool active;   // this thread's unit has work (the threads of idle units still serve as role lanes)
 };
-template <class DM, bool CT, bool FR, class Exec, int RW = 0>
+template <class DM, int CT, bool FR, class Exec, int RW = 0>
 EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lpu, double* N, const LinRole* RL = nullptr) {
   typedef Lin2Smem<DM> SM;
   constexpr int NB = DM::NB, NV = DM::NV, NQ = DM::NQ, NX = DM::NX, NDX = DM::NDX, NU = DM::NU, NROT = DM::NROT;
@@ -476,7 +477,8 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
     }
   }
 
-  // contact of this node (ContactModel3D only on the device)
+  // contact of this node: CT = 3 (ContactModel3D) or 6 (ContactModel6D) constraint rows, fixed per kernel instantiation
+  constexpr int NCR = CT ? CT : 3;
   const bool use_contact = FR && CT && P.has_contact && set.ncontacts > 0;
   int cframe = -1, cbody = -1, ccap = 0;
   if (use_contact) {
@@ -665,11 +667,17 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
       N[SM::OFF_CS + j] = c_;
       N[SM::OFF_SN + j] = s_;
     } else if (CT && lane == lpu - 2) {
-      // contact force as a spatial force on the contact body (body coordinates): X_f^* [lambda; 0]
+      // contact force as a spatial force on the contact body (body coordinates): X_f^* [f; n]  (n = 0 for the 3D contact)
       if (use_contact) {
         double fl[3] = {N[SM::OFF_LAM], N[SM::OFF_LAM + 1], N[SM::OFF_LAM + 2]}, fb[3], rxf[3];
         matvec3<double>(m.frame_R[cframe], fl, fb);
         cross3<double>(m.frame_p[cframe], fb, rxf);
+        if constexpr (CT == 6) {
+          double nl[3] = {N[SM::OFF_LAM + 3], N[SM::OFF_LAM + 4], N[SM::OFF_LAM + 5]}, nb[3];
+          matvec3<double>(m.frame_R[cframe], nl, nb);
+#pragma unroll
+          for (int i = 0; i < 3; ++i) rxf[i] += nb[i];
+        }
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
           N[SM::OFF_FEXT + i] = fb[i];
@@ -706,7 +714,7 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
   // ---- S3: tangent recursion; inertia columns to LDS ---------------------------------------------------------
   double dtau_l[Exec::SLOTS][NV];
   double jc_l[Exec::SLOTS][NCAP][6], dvc_l[Exec::SLOTS][NCAP][6];
-  double dcon_l[Exec::SLOTS][3], dlam_l[Exec::SLOTS][3];
+  double dcon_l[Exec::SLOTS][NCR], dlam_l[Exec::SLOTS][NCR];
   ex.each([&](int lane, int sl) {
     double capdv[NCAP][6], capda[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -733,11 +741,14 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
       matTvec3<double>(m.frame_R[f], capdv[c] + 3, dvc_l[sl][c] + 3);
     }
     if constexpr (CT) {
-      dcon_l[sl][0] = dcon_l[sl][1] = dcon_l[sl][2] = 0.0;
-      dlam_l[sl][0] = dlam_l[sl][1] = dlam_l[sl][2] = 0.0;
+#pragma unroll
+      for (int r = 0; r < NCR; ++r) dcon_l[sl][r] = dlam_l[sl][r] = 0.0;
       if (use_contact) {
-        // d(classical acceleration of the contact frame origin, LOCAL), at fixed generalized acceleration:
-        //   d a_f.lin + dphi x (Rf^T (-g)) + d w_f x v_f.lin + w_f x d v_f.lin
+        // derivative of the contact drift at fixed generalized acceleration.  3D: d(classical acceleration of the contact
+        // frame origin, LOCAL) = d a_f.lin + dphi x (Rf^T (-g)) + d w_f x v_f.lin + w_f x d v_f.lin;
+        // 6D: d(spatial acceleration, LOCAL) = [d a_f.lin + dphi x (Rf^T (-g)); d a_f.ang].  Baumgarte terms
+        // (ContactModel3D/6D::calcDiff): 3D g0 oRf fJf.lin, 6D g0 Jlog6(Mref^-1 oMf) fJf, both g1 d(v_f)
+        const EmpcContact& ctc = set.contacts[0];
         const double* F = N + SM::OFF_FR + ccap * 18;
         double daf[3], wxr[3], tmp[3], gf[3], c1[3], c2[3], c3[3];
         cross3<double>(capda + 3, m.frame_p[cframe], wxr);
@@ -762,14 +773,50 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
             }
           }
         cross3<double>(jcc + 3, gf, c1);
-        cross3<double>(dvcc + 3, F + 12, c2);
-        cross3<double>(F + 15, dvcc, c3);
+        if constexpr (CT == 6) {
+          double dang[3];
+          matTvec3<double>(m.frame_R[cframe], capda + 3, dang);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) dcon_l[sl][i] = daf[i] + c1[i] + c2[i] + c3[i];
+          for (int i = 0; i < 3; ++i) {
+            dcon_l[sl][i] = daf[i] + c1[i];
+            dcon_l[sl][3 + i] = dang[i];
+          }
+          if (ctc.gains[0] != 0.0) {
+            double rR[9], dp[3], rp[3], qq[4], xi[6], J6[36];
+            matTmul3<double>(ctc.ref_R, F, rR);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) dp[i] = F[9 + i] - ctc.ref_p[i];
+            matTvec3<double>(ctc.ref_R, dp, rp);
+            R_to_quat(rR, qq);
+            log6_quat(qq, rp, xi);
+            Jlog6(xi, rp, J6);
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+              double a_ = 0;
+#pragma unroll
+              for (int l = 0; l < 6; ++l) a_ += J6[r * 6 + l] * jcc[l];
+              dcon_l[sl][r] += ctc.gains[0] * a_;
+            }
+          }
+        } else {
+          cross3<double>(dvcc + 3, F + 12, c2);
+          cross3<double>(F + 15, dvcc, c3);
+#pragma unroll
+          for (int i = 0; i < 3; ++i) dcon_l[sl][i] = daf[i] + c1[i] + c2[i] + c3[i];
+          if (ctc.gains[0] != 0.0) {
+            double wl[3];
+            matvec3<double>(F, jcc, wl);  // oRf * (LOCAL linear Jacobian column)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) dcon_l[sl][i] += ctc.gains[0] * wl[i];
+          }
+        }
+        if (ctc.gains[1] != 0.0)
+#pragma unroll
+          for (int r = 0; r < NCR; ++r) dcon_l[sl][r] += ctc.gains[1] * dvcc[r];
         if (lane >= 2 * NV && lane < 3 * NV) {
           // direction da_j: d(con)/d(a_j) is column j of the contact Jacobian
 #pragma unroll
-          for (int r = 0; r < 3; ++r) N[SM::OFF_JC + r * NV + (lane - 2 * NV)] = dcon_l[sl][r];
+          for (int r = 0; r < NCR; ++r) N[SM::OFF_JC + r * NV + (lane - 2 * NV)] = dcon_l[sl][r];
         }
       }
     }
@@ -795,9 +842,9 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
   ex.sync();
   if constexpr (CT) {
     if (use_contact) {
-      // M^-1 Jc^T (lanes 0..2), then G = Jc M^-1 Jc^T and its Cholesky factor (lane 0)
+      // M^-1 Jc^T (lanes 0..nc-1), then G = Jc M^-1 Jc^T and its Cholesky factor (lane 0)
       ex.each([&](int lane, int sl) {
-        if (lane >= 3) return;
+        if (lane >= NCR) return;
         const double* Lm = N + SM::OFF_M;
         double y[NV];
 #pragma unroll
@@ -817,21 +864,22 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
           y[i] = s_ * Lm[i * NV + i];
         }
 #pragma unroll
-        for (int i = 0; i < NV; ++i) N[SM::OFF_MIJ + i * 3 + lane] = y[i];
+        for (int i = 0; i < NV; ++i) N[SM::OFF_MIJ + i * NCR + lane] = y[i];
       });
       ex.sync();
       ex.each([&](int lane, int sl) {
         if (lane != 0) return;
-        double G[6];
-        for (int r = 0; r < 3; ++r)
+        constexpr int NG = NCR * (NCR + 1) / 2;
+        double G[NG];
+        for (int r = 0; r < NCR; ++r)
           for (int c = 0; c <= r; ++c) {
             double g = 0;
-            for (int i = 0; i < NV; ++i) g += N[SM::OFF_JC + r * NV + i] * N[SM::OFF_MIJ + i * 3 + c];
+            for (int i = 0; i < NV; ++i) g += N[SM::OFF_JC + r * NV + i] * N[SM::OFF_MIJ + i * NCR + c];
             G[r * (r + 1) / 2 + c] = g;
           }
-        chol_packed<3>(G);
+        chol_packed<NCR>(G);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) N[SM::OFF_G + i] = G[i];
+        for (int i = 0; i < NG; ++i) N[SM::OFF_G + i] = G[i];
       });
       ex.sync();
     }
@@ -877,22 +925,28 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
     if constexpr (CT) {
       if (use_contact) {
         // [M Jc^T; Jc 0][da; -dlam] = [rhs; -dcon]:  dlam = -(Jc M^-1 Jc^T)^-1 (Jc M^-1 rhs + dcon), da += M^-1 Jc^T dlam
-        double z[3];
+        constexpr int NG = NCR * (NCR + 1) / 2;
+        double z[NCR];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
+        for (int r = 0; r < NCR; ++r) {
           double a_ = xlane ? dcon_l[sl][r] : 0.0;
 #pragma unroll
           for (int i = 0; i < NV; ++i) a_ += N[SM::OFF_JC + r * NV + i] * da[i];
           z[r] = -a_;
         }
-        double Gf[6];
+        double Gf[NG];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) Gf[i] = N[SM::OFF_G + i];
-        chol_solve_packed<3>(Gf, z);
+        for (int i = 0; i < NG; ++i) Gf[i] = N[SM::OFF_G + i];
+        chol_solve_packed<NCR>(Gf, z);
 #pragma unroll
-        for (int r = 0; r < 3; ++r) dlam_l[sl][r] = z[r];
+        for (int r = 0; r < NCR; ++r) dlam_l[sl][r] = z[r];
 #pragma unroll
-        for (int i = 0; i < NV; ++i) da[i] += N[SM::OFF_MIJ + i * 3] * z[0] + N[SM::OFF_MIJ + i * 3 + 1] * z[1] + N[SM::OFF_MIJ + i * 3 + 2] * z[2];
+        for (int i = 0; i < NV; ++i) {
+          double a_ = N[SM::OFF_MIJ + i * NCR] * z[0] + N[SM::OFF_MIJ + i * NCR + 1] * z[1] + N[SM::OFF_MIJ + i * NCR + 2] * z[2];
+          if constexpr (CT == 6)
+            a_ += N[SM::OFF_MIJ + i * NCR + 3] * z[3] + N[SM::OFF_MIJ + i * NCR + 4] * z[4] + N[SM::OFF_MIJ + i * NCR + 5] * z[5];
+          da[i] += a_;
+        }
       }
     }
     if (raw) {

@@ -19,6 +19,7 @@ struct HostProblem {
   std::vector<SetInfo> set_info;
   std::vector<int> knot_set;
   std::vector<double> x0;
+  int contact_rows = 0;  // 0: no contact stage; 3: ContactModel3D; 6: ContactModel6D (selects the kernel instantiation)
 };
 
 inline void insert_barrier(EmpcCostSet& s, const DevProblem& P) {
@@ -136,8 +137,14 @@ inline void prepare_problem(const EmpcProblemDesc& d, const EmpcSolverParams& pr
     }
     if (nf > NCAP) throw std::runtime_error("a cost set references more distinct frames than the kernels capture");
     if (s.ncontacts > 1) throw std::runtime_error("more than one contact per stage is not supported by the kernels");
-    if (s.ncontacts == 1 && s.contacts[0].type != EMPC_CONTACT_3D)
-      throw std::runtime_error("only ContactModel3D is implemented in the linearize kernel (ContactModel6D is not)");
+    if (s.ncontacts == 1) {
+      // the number of constraint rows is a compile-time constant of the kernels (3: ContactModel3D, 6: ContactModel6D)
+      const int rows = s.contacts[0].type == EMPC_CONTACT_3D ? 3 : (s.contacts[0].type == EMPC_CONTACT_6D ? 6 : -1);
+      if (rows < 0) throw std::runtime_error("unknown contact type in a cost set");
+      if (H.contact_rows != 0 && H.contact_rows != rows)
+        throw std::runtime_error("ContactModel3D and ContactModel6D stages in one problem are not supported by the kernels");
+      H.contact_rows = rows;
+    }
   }
   // work lists per cost set (SetInfo); the capture order is the one node_nominal derives by scanning the table
   H.set_info.assign(H.sets.size(), SetInfo());

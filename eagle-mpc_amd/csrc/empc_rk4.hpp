@@ -25,7 +25,7 @@ struct Rk4Buffers {
 };
 
 // ---- step 1 -----------------------------------------------------------------------------------------------------------
-template <class DM, bool CT>
+template <class DM, int CT>
 EMPC_HD void rk4_stage_thread(const DevBuffers& D, const Rk4Buffers& R, int b, int t) {
   constexpr int NX = DM::NX, NU = DM::NU, NV = DM::NV, NQ = DM::NQ, NDX = DM::NDX;
   const TrajState& st = D.st[b];

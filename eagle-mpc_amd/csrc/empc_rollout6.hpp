@@ -116,7 +116,7 @@ EMPC_HD Roll6Lane roll6_lane(const DevBuffers& D, const int* TB, int lane, int G
 // One instantiation per role: a wavefront runs the whole rollout of ITS role (warp specialisation), so the registers of a
 // role hold that role's state only; the four instantiations execute the same sequence of workgroup barriers.
 // Exec concept: ex.each(f) runs f(lane, slot) on the lanes of the calling wavefront; ex.sync() is the workgroup barrier.
-template <class DM, bool CT, int ROLE, class Exec>
+template <class DM, int CT, int ROLE, class Exec>
 EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N) {
   typedef Roll6Smem<DM> SM;
   constexpr int NX = DM::NX, NU = DM::NU, NV = DM::NV, NQ = DM::NQ, NDX = DM::NDX, REC = DM::REC, NB = DM::NB, NROT = DM::NROT;
@@ -589,7 +589,7 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
           quat_to_R(x + 3, R0);
 #pragma unroll
           for (int b = 1; b < NB; ++b) fsincos(x[7 + b - 1], &sn[b - 1], &cs[b - 1]);
-          contact_forward<DM>(m, set.contacts[0], ck, R0, x, cs, sn, Lc[sl], a, lam);
+          contact_forward<DM, CT>(m, set.contacts[0], ck, R0, x, cs, sn, Lc[sl], a, lam);
         }
       }
 #pragma unroll

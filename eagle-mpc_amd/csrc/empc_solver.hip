@@ -31,12 +31,15 @@ using namespace empc;
 // --------------------------------------------------------------------------------------------------------------------
 // solver object
 // --------------------------------------------------------------------------------------------------------------------
-static bool find_table(int nb, int nrot, bool contact, KernelTable& k) {
+// contact_rows: 0 for problems built on the free dynamics; 3 / 6 for Contact dynamics (DifferentialActionModelContactFwdDynamics
+// on every node) whose contact stages hold a ContactModel3D / ContactModel6D
+static bool find_table(int nb, int nrot, bool contact, int contact_rows, KernelTable& k) {
   if (nb == 1 && nrot == 4 && !contact) k = empc_table_1_4();
   else if (nb == 1 && nrot == 6 && !contact) k = empc_table_1_6();
   else if (nb == 3 && nrot == 6 && !contact) k = empc_table_3_6();
   else if (nb == 4 && nrot == 6 && !contact) k = empc_table_4_6();
-  else if (nb == 4 && nrot == 6 && contact) k = empc_table_4_6_contact();
+  else if (nb == 4 && nrot == 6 && contact && contact_rows != 6) k = empc_table_4_6_contact();
+  else if (nb == 4 && nrot == 6 && contact && contact_rows == 6) k = empc_table_4_6_contact6();
   else if (nb == 6 && nrot == 6 && !contact) k = empc_table_6_6();
   else return false;
   return true;
@@ -166,7 +169,7 @@ int empc_solver_supported(const EmpcProblemDesc* problem, const EmpcSolverParams
     prepare_problem(*problem, prm, H);  // dimension / chain / integrator / contact-type limits of the kernels
     check_device_support(*problem);
     KernelTable kt;
-    if (!find_table(problem->model.nbodies, problem->n_rotors, problem->has_contact != 0, kt))
+    if (!find_table(problem->model.nbodies, problem->n_rotors, problem->has_contact != 0, H.contact_rows, kt))
       throw std::runtime_error("no kernel instantiation for this (bodies, rotors, contact) combination");
     return 1;
   } catch (const std::exception& e) {
@@ -193,12 +196,7 @@ EmpcSolver* empc_solver_create(const EmpcProblemDesc* problem, const EmpcSolverP
   s->device = device;
   prepare_problem(*problem, prm, s->H);
   check_device_support(*problem);
-  if (problem->has_contact)
-    for (const auto& cs : s->H.sets)
-      for (int i = 0; i < cs.ncontacts; ++i)
-        if (cs.contacts[i].type != EMPC_CONTACT_3D)
-          throw std::runtime_error("only ContactModel3D is implemented on the device");
-  if (!find_table(problem->model.nbodies, problem->n_rotors, problem->has_contact != 0, s->kt)) {
+  if (!find_table(problem->model.nbodies, problem->n_rotors, problem->has_contact != 0, s->H.contact_rows, s->kt)) {
     delete s;
     empc::set_last_error("no kernel instantiation for this (bodies, rotors, contact) combination");
     return nullptr;

@@ -225,10 +225,8 @@ inline void dam_eval(const Problem& P, int t, const double* x, const double* u_i
     }
     if (ct.gains[0] != 0.0) {
       if (nc == 3) {
-        double dp[3], dpl[3];
-        for (int r = 0; r < 3; ++r) dp[r] = cfk.p[r] - ct.ref_p[r];
-        matTvec3<double>(cfk.R, dp, dpl);
-        for (int r = 0; r < 3; ++r) a0[r] += ct.gains[0] * dpl[r];
+        // crocoddyl 1.8 ContactModel3D::calc: a0 += gains[0] * (oMf.translation() - xref)   (world-frame error)
+        for (int r = 0; r < 3; ++r) a0[r] += ct.gains[0] * (cfk.p[r] - ct.ref_p[r]);
       } else {
         double rR[9], dp[3], rp[3], xi[6];
         matTmul3<double>(ct.ref_R, cfk.R, rR);
@@ -338,15 +336,25 @@ inline void dam_eval(const Problem& P, int t, const double* x, const double* u_i
       }
       if (ct.gains[1] != 0.0)
         for (int r = 0; r < nc; ++r) con[r] += ct.gains[1] * fk.v[r];
-      if (ct.gains[0] != 0.0 && nc == 3) {
-        Dual dp[3], dpl[3];
-        for (int r = 0; r < 3; ++r) dp[r] = fk.p[r] - ct.ref_p[r];
-        matTvec3<Dual>(fk.R, dp, dpl);
-        for (int r = 0; r < 3; ++r) con[r] += ct.gains[0] * dpl[r];
-      }
-      // (6D position gain derivative uses Jlog6; all shipped problems have zero gains)
+      if (ct.gains[0] != 0.0 && nc == 3)  // derivative: gains[0] * oRf * fJf.topRows<3>() (ContactModel3D::calcDiff)
+        for (int r = 0; r < 3; ++r) con[r] += ct.gains[0] * (fk.p[r] - ct.ref_p[r]);
       for (int r = 0; r < nc; ++r)
         for (int c = 0; c < ndx; ++c) dcon_dx[r * ndx + c] = con[r].d[c];
+      if (ct.gains[0] != 0.0 && nc == 6) {
+        // ContactModel6D::calcDiff: da0_dq += gains[0] * Jlog6(rMf) * fJf, rMf = Mref^-1 oMf, fJf the LOCAL frame Jacobian
+        double rR[9], dp[3], rp[3], xi[6], J6[36];
+        matTmul3<double>(ct.ref_R, cfk.R, rR);
+        for (int r = 0; r < 3; ++r) dp[r] = cfk.p[r] - ct.ref_p[r];
+        matTvec3<double>(ct.ref_R, dp, rp);
+        log6(rR, rp, xi);
+        Jlog6(xi, J6);
+        for (int r = 0; r < 6; ++r)
+          for (int c = 0; c < nv; ++c) {
+            double acc = 0;
+            for (int l = 0; l < 6; ++l) acc += J6[r * 6 + l] * Jc[l * nv + c];
+            dcon_dx[r * ndx + c] += ct.gains[0] * acc;
+          }
+      }
     }
   }
 

@@ -40,3 +40,22 @@ def problems(empc):
         t.autoSetup(empc.yaml_path(rel))
         out[name] = (t, t.createProblem(dt, True, "IntegratedActionModelEuler"))
     return out
+
+
+def contact_variant(empc, tmp_path, contact="ContactModel3D", gains=(0.0, 0.0), dt=32, integrator="IntegratedActionModelEuler",
+                    squash=True):
+    """eagle_catch with its grasp-stage contact swapped for `contact` (ContactModel3D | ContactModel6D) and Baumgarte
+    `gains` -- the two factory options of src/factory/contacts.cpp:26-79 that no shipped YAML exercises.  Returns
+    (trajectory, problem)."""
+    src = open(empc.yaml_path(CONFIGS["eagle_catch"][0])).read()
+    old = '          type: "ContactModel3D"\n          link_name: "flying_arm_3__gripper"\n          position: [0, 0, 0]\n          gains: [0, 0]\n'
+    assert src.count(old) == 1
+    new = '          type: "%s"\n          link_name: "flying_arm_3__gripper"\n          position: [0, 0, 0]\n' % contact
+    if contact == "ContactModel6D":
+        new += '          orientation: [0, 0, 0, 1]\n'
+    new += '          gains: [%r, %r]\n' % (float(gains[0]), float(gains[1]))
+    f = tmp_path / ("eagle_catch_%s_%g_%g.yaml" % (contact, gains[0], gains[1]))
+    f.write_text(src.replace(old, new))
+    tr = empc.Trajectory()
+    tr.autoSetup(str(f))
+    return tr, tr.createProblem(dt, squash, integrator)

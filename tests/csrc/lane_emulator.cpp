@@ -60,7 +60,7 @@ struct CpuRoleExec {
   }
   void sync() { bar->arrive_and_wait(); }
 };
-template <class DM, bool CT>
+template <class DM, int CT>
 static void emu_rollout_group6(const DevBuffers& D, int grp, double* smem) {
   std::barrier<> bar(R6_WAVES);
   std::thread th[R6_WAVES];
@@ -150,11 +150,15 @@ static void emu_calc(Emu& e) {
     for (int t = 0; t <= e.T; ++t) {
       if constexpr (DM::NB == 4) {
         if (ct) {
-          calc_thread<DM, true>(e.D, b, t);
+          if (e.H.contact_rows == 6) {
+            calc_thread<DM, 6>(e.D, b, t);
+          } else {
+            calc_thread<DM, 3>(e.D, b, t);
+          }
           continue;
         }
       }
-      calc_thread<DM, false>(e.D, b, t);
+      calc_thread<DM, 0>(e.D, b, t);
     }
 }
 static int g_lin_version = 2;
@@ -173,11 +177,15 @@ static void emu_linearize_rk4(Emu& e) {
     for (int b = 0; b < e.B; ++b) {
       if constexpr (DM::NB == 4) {
         if (ct) {
-          rk4_stage_thread<DM, true>(e.D, R, b, t);
+          if (e.H.contact_rows == 6) {
+            rk4_stage_thread<DM, 6>(e.D, R, b, t);
+          } else {
+            rk4_stage_thread<DM, 3>(e.D, R, b, t);
+          }
           continue;
         }
       }
-      rk4_stage_thread<DM, false>(e.D, R, b, t);
+      rk4_stage_thread<DM, 0>(e.D, R, b, t);
     }
   DevBuffers Dv = e.D;
   Dv.B = 4 * e.B;
@@ -215,13 +223,21 @@ static void emu_linearize_view(Emu& e, const DevBuffers& Dl) {
       CpuExec<64> ex{LPU};
       if constexpr (DM::NB == 4) {
         if (e.H.P.has_contact) {
-          linearize_unit2<DM, true, false>(ex, Dl, b, t, LPU, smem.data());
-          linearize_unit2<DM, true, true>(ex, Dl, b, t, LPU, smem.data());
+          if (e.H.contact_rows == 6) {
+            linearize_unit2<DM, 6, false>(ex, Dl, b, t, LPU, smem.data());
+          } else {
+            linearize_unit2<DM, 3, false>(ex, Dl, b, t, LPU, smem.data());
+          }
+          if (e.H.contact_rows == 6) {
+            linearize_unit2<DM, 6, true>(ex, Dl, b, t, LPU, smem.data());
+          } else {
+            linearize_unit2<DM, 3, true>(ex, Dl, b, t, LPU, smem.data());
+          }
           continue;
         }
       }
-      linearize_unit2<DM, false, false>(ex, Dl, b, t, LPU, smem.data());
-      linearize_unit2<DM, false, true>(ex, Dl, b, t, LPU, smem.data());
+      linearize_unit2<DM, 0, false>(ex, Dl, b, t, LPU, smem.data());
+      linearize_unit2<DM, 0, true>(ex, Dl, b, t, LPU, smem.data());
     }
 }
 static int g_bwd_version = 2;
@@ -264,11 +280,15 @@ static void emu_rollout(Emu& e) {
     for (int grp = 0; grp * G < e.B; ++grp) {
       if constexpr (DM::NB == 4) {
         if (ct) {
-          emu_rollout_group6<DM, true>(e.D, grp, smem6.data());
+          if (e.H.contact_rows == 6) {
+            emu_rollout_group6<DM, 6>(e.D, grp, smem6.data());
+          } else {
+            emu_rollout_group6<DM, 3>(e.D, grp, smem6.data());
+          }
           continue;
         }
       }
-      emu_rollout_group6<DM, false>(e.D, grp, smem6.data());
+      emu_rollout_group6<DM, 0>(e.D, grp, smem6.data());
     }
     return;
   }
@@ -280,20 +300,28 @@ static void emu_rollout(Emu& e) {
         CpuExec<64> ex{64};
         if constexpr (DM::NB == 4) {
           if (ct) {
-            rollout_wave5<DM, true>(ex, e.D, b, 64, smem5.data());
+            if (e.H.contact_rows == 6) {
+              rollout_wave5<DM, 6>(ex, e.D, b, 64, smem5.data());
+            } else {
+              rollout_wave5<DM, 3>(ex, e.D, b, 64, smem5.data());
+            }
             continue;
           }
         }
-        rollout_wave5<DM, false>(ex, e.D, b, 64, smem5.data());
+        rollout_wave5<DM, 0>(ex, e.D, b, 64, smem5.data());
         continue;
       }
       if constexpr (DM::NB == 4) {
         if (ct) {
-          rollout_thread<DM, true>(e.D, b, ai);
+          if (e.H.contact_rows == 6) {
+            rollout_thread<DM, 6>(e.D, b, ai);
+          } else {
+            rollout_thread<DM, 3>(e.D, b, ai);
+          }
           continue;
         }
       }
-      rollout_thread<DM, false>(e.D, b, ai);
+      rollout_thread<DM, 0>(e.D, b, ai);
     }
 }
 template <class DM>
@@ -342,12 +370,16 @@ static void emu_node(Emu& e, int t, const double* x, const double* u, double smo
   double c = 0;
   if constexpr (DM::NB == 4) {
     if (e.H.P.has_contact) {
-      node_nominal<DM, true>(e.H.P, set, smooth, x, u, u == nullptr, xnext, acc, c, usq, lam);
+      if (e.H.contact_rows == 6) {
+        node_nominal<DM, 6>(e.H.P, set, smooth, x, u, u == nullptr, xnext, acc, c, usq, lam);
+      } else {
+        node_nominal<DM, 3>(e.H.P, set, smooth, x, u, u == nullptr, xnext, acc, c, usq, lam);
+      }
       *cost = c;
       return;
     }
   }
-  node_nominal<DM, false>(e.H.P, set, smooth, x, u, u == nullptr, xnext, acc, c, usq, lam);
+  node_nominal<DM, 0>(e.H.P, set, smooth, x, u, u == nullptr, xnext, acc, c, usq, lam);
   *cost = c;
 }
 

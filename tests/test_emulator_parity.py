@@ -64,6 +64,19 @@ def candidate(d, seed, scale=1.0):
 @pytest.mark.parametrize("name", ["hover", "displacement", "push_slide", "eagle_catch"])
 def test_kernel_bodies_vs_oracle(empc, problems, emu, name, lin, bwd, roll):
     _, problem = problems[name]
+    kernel_bodies(emu, problem, name, lin, bwd, roll)
+
+
+@pytest.mark.parametrize("contact,gains", [("ContactModel3D", (9.0, 4.0)), ("ContactModel6D", (0.0, 0.0)), ("ContactModel6D", (11.0, 5.0))])
+def test_contact_options_kernel_bodies_vs_oracle(empc, emu, tmp_path, contact, gains):
+    """The contact factory's other options (src/factory/contacts.cpp:26-79) through the device code: ContactModel6D (six
+    constraint rows: its own kernel instantiation) and Baumgarte gains, tape / gains / rollouts against the oracle."""
+    from conftest import contact_variant
+    _, problem = contact_variant(empc, tmp_path, contact, gains)
+    kernel_bodies(emu, problem, "eagle_catch", 2, 4, 6)
+
+
+def kernel_bodies(emu, problem, name, lin, bwd, roll):
     d = problem.desc
     prm = ob.default_params()
     emu.emu_set_linearize_version(lin)

@@ -41,6 +41,10 @@ def test_phase_parity(empc, problems, name):
     """linearize (HOT-A), backward (HOT-B) and rollout (HOT-C) kernels against the oracle's calcDiff / backwardPass /
     forwardPass on random candidates (seeded), one trajectory of the batch at a time."""
     _, problem = problems[name]
+    phase_parity(empc, problem, name)
+
+
+def phase_parity(empc, problem, name):
     d = problem.desc
     B = 3
     xs, us = random_candidate(d, B, seed=11)

@@ -226,7 +226,8 @@ def test_every_shipped_trajectory_builds_and_has_a_kernel(empc):
     t = empc.Trajectory()
     t.autoSetup(empc.yaml_path("hexacopter370/trajectories/hover.yaml"))
     assert empc.solver_supported(t.createProblem(40, True, "IntegratedActionModelRK4"))
-    # what the device does not implement is refused with a reason, not silently: a 6D contact
+    # both contact types of the factory (src/factory/contacts.cpp:26-79) have kernels; anything else is refused with a
+    # reason, not silently
     t = empc.Trajectory()
     t.autoSetup(empc.yaml_path("hexacopter370_flying_arm_3/trajectories/eagle_catch.yaml"))
     p = t.createProblem(32, True, "IntegratedActionModelEuler")
@@ -234,8 +235,11 @@ def test_every_shipped_trajectory_builds_and_has_a_kernel(empc):
     patched = [(k, d.sets[k].contacts[0].type) for k in range(d.n_sets) if d.sets[k].ncontacts]
     try:
         for k, _ in patched:
-            d.sets[k].contacts[0].type = 1
-        assert not empc.solver_supported(p) and "ContactModel3D" in empc.last_error()
+            d.sets[k].contacts[0].type = 1  # EMPC_CONTACT_6D
+        assert empc.solver_supported(p), empc.last_error()
+        for k, _ in patched:
+            d.sets[k].contacts[0].type = 7
+        assert not empc.solver_supported(p) and "contact type" in empc.last_error()
     finally:
         for k, ty in patched:
             d.sets[k].contacts[0].type = ty

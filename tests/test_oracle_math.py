@@ -142,6 +142,52 @@ def test_node_derivatives_fd(problems, name, knots):
             assert np.abs(Lu - r["Lu"]).max() < 1e-6 * (1 + np.abs(r["Lu"]).max())
 
 
+@pytest.mark.parametrize("contact,gains", [("ContactModel3D", (12.0, 0.0)), ("ContactModel3D", (0.0, 7.0)), ("ContactModel3D", (9.0, 4.0)),
+                                           ("ContactModel6D", (0.0, 0.0)), ("ContactModel6D", (0.0, 6.0)), ("ContactModel6D", (11.0, 5.0))])
+def test_contact_options_derivatives_fd(empc, tmp_path, contact, gains):
+    """The contact factory's other options (src/factory/contacts.cpp:26-79): ContactModel6D and Baumgarte gains.  Fx, Fu, Lx,
+    Lu of the grasp-stage node against central differences of calc; the constrained acceleration satisfies
+    Jc a + a0 = 0 (through the force: 6 components for the 6D contact, 3 for the 3D one)."""
+    from conftest import contact_variant
+    _, problem = contact_variant(empc, tmp_path, contact, gains)
+    d = problem.desc
+    o = ob.OracleSolver(d)
+    rng = np.random.default_rng(5)
+    nx, ndx, nu = d.nx, d.ndx, d.nu
+    tk = 45
+    x = np.zeros(nx)
+    x[:3] = rng.normal(size=3) * 0.3
+    q = np.array([0, 0, 0, 1.0]) + rng.normal(size=4) * 0.2
+    x[3:7] = q / np.linalg.norm(q)
+    x[7:] = rng.normal(size=nx - 7) * 0.2
+    u = rng.uniform(1, 8, size=nu)
+    u[d.n_rotors:] = rng.normal(size=nu - d.n_rotors) * 0.3
+    r = o.node_calc(tk, x, u, True)
+    nlam = 6 if contact == "ContactModel6D" else 3
+    assert np.abs(r["lam"][:nlam]).min() > 1e-6 and (nlam == 6 or np.abs(r["lam"][nlam:]).max() == 0.0)
+    h = 1e-6
+    Fx, Lx = np.zeros((ndx, ndx)), np.zeros(ndx)
+    for k in range(ndx):
+        e = np.zeros(ndx)
+        e[k] = h
+        rp = o.node_calc(tk, o.integrate(x, e), u, False)
+        rm = o.node_calc(tk, o.integrate(x, -e), u, False)
+        Fx[:, k] = (o.diff(r["xnext"], rp["xnext"]) - o.diff(r["xnext"], rm["xnext"])) / (2 * h)
+        Lx[k] = (rp["cost"] - rm["cost"]) / (2 * h)
+    assert np.abs(Fx - r["Fx"]).max() < 2e-6 * (1 + np.abs(r["Fx"]).max())
+    assert np.abs(Lx - r["Lx"]).max() < 1e-6 * (1 + np.abs(r["Lx"]).max())
+    Fu, Lu = np.zeros((ndx, nu)), np.zeros(nu)
+    for k in range(nu):
+        e = np.zeros(nu)
+        e[k] = h
+        rp = o.node_calc(tk, x, u + e, False)
+        rm = o.node_calc(tk, x, u - e, False)
+        Fu[:, k] = (o.diff(r["xnext"], rp["xnext"]) - o.diff(r["xnext"], rm["xnext"])) / (2 * h)
+        Lu[k] = (rp["cost"] - rm["cost"]) / (2 * h)
+    assert np.abs(Fu - r["Fu"]).max() < 2e-6 * (1 + np.abs(r["Fu"]).max())
+    assert np.abs(Lu - r["Lu"]).max() < 1e-6 * (1 + np.abs(r["Lu"]).max())
+
+
 @pytest.mark.parametrize("name,dt,knots", [("hover", 40, [0, 50]), ("displacement", 80, [3, 25, 100]), ("eagle_catch", 32, [5, 45, 99])])
 def test_rk4_node_derivatives_fd(empc, name, dt, knots):
     """IntegratedActionModelRK4 (src/factory/int-action.cpp:29-31) in the oracle: Fx, Fu, Lx, Lu of calcDiff against central
