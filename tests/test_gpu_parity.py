@@ -181,16 +181,16 @@ def test_error_paths(empc, problems):
     s = empc.SolverSbFDDP(problem, batch=1)
     with pytest.raises(empc.EmpcError):
         s.solve([], [], 0)
-    # a 6D contact is refused loudly (only ContactModel3D has a linearize tangent on the device)
+    # an unknown contact type is refused loudly
     _, cproblem = problems["eagle_catch"]
     d = cproblem.desc
     patched = []
     for k in range(d.n_sets):
         if d.sets[k].ncontacts:
             patched.append((k, d.sets[k].contacts[0].type))
-            d.sets[k].contacts[0].type = 1
+            d.sets[k].contacts[0].type = 7
     try:
-        with pytest.raises(empc.EmpcError, match="ContactModel3D"):
+        with pytest.raises(empc.EmpcError, match="contact type"):
             empc.SolverSbFDDP(cproblem, batch=1)
     finally:
         for k, t in patched:
