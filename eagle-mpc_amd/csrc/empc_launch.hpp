@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(DM::NV
 k_linearize(DevBuffers D) {
   extern __shared__ double smem_lin[];
   constexpr int UPB = BLK / LPU;  // units per block
-  constexpr int USZ = CT ? Lin2Smem<DM>::SIZE : Lin2Smem<DM>::SIZE_NC;
+  constexpr int USZ = Lin2Smem<DM>::size_for(CT);
 #ifdef EMPC_LIN_NO_ROLES
   constexpr int RW = 0;
 #else
@@ -318,7 +318,7 @@ template <class DM, int CT, int BLK>
 static void launch_linearize_blk(DevBuffers D, hipStream_t s) {
   constexpr int LPU = (3 * DM::NV <= 32) ? 32 : 64;
   constexpr int UPB = BLK / LPU;
-  constexpr int USZ = CT ? Lin2Smem<DM>::SIZE : Lin2Smem<DM>::SIZE_NC;
+  constexpr int USZ = Lin2Smem<DM>::size_for(CT);
   const int n = D.B * (D.T + 1);
   const size_t smem = sizeof(double) * USZ * UPB;
   static const bool once = [&] {

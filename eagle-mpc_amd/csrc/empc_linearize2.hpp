@@ -43,15 +43,17 @@ struct Lin2Smem {
   static constexpr int SLOT = 3 * NDX + 36 + 4;       // r | Ar | Arr | J6 | value
   static constexpr int OFF_RSH = OFF_CST + NSLOT * SLOT;  // residual-Jacobian exchange 6 x (NDX + NU)
   static constexpr int OFF_RED = OFF_RSH + 6 * (NDX + NU);  // small reduction area (cost partial sums) 64
-  // contact block (ContactModel3D: nc = 3 rows, ContactModel6D: nc = 6; sized for 6): lambda 6 | fext 6 | Jc nc x NV |
-  // M^-1 Jc^T NV x nc | packed G nc (nc + 1) / 2 | cone rows 15 + Ar 5 + Arr 5
+  // contact block (nc = 3 rows for ContactModel3D, 6 for ContactModel6D): lambda 6 | fext 6 | cone rows 15 + Ar 5 + Arr 5 |
+  // Jc nc x NV | M^-1 Jc^T NV x nc | packed G nc (nc + 1) / 2.  The nc-dependent part comes last, so a unit of the 3D
+  // instantiation is no larger than it has to be (units per CU are LDS-bound in the contact problem)
   static constexpr int OFF_LAM = OFF_RED + 64;
   static constexpr int OFF_FEXT = OFF_LAM + 6;
-  static constexpr int OFF_JC = OFF_FEXT + 6;
-  static constexpr int OFF_MIJ = OFF_JC + 6 * NV;
-  static constexpr int OFF_G = OFF_MIJ + 6 * NV;
-  static constexpr int OFF_CONE = OFF_G + 22;
-  static constexpr int SIZE = (OFF_CONE + 25 + 1) / 2 * 2;
+  static constexpr int OFF_CONE = OFF_FEXT + 6;
+  static constexpr int OFF_JC = OFF_CONE + 26;
+  static constexpr int off_mij(int nc) { return OFF_JC + nc * NV; }
+  static constexpr int off_g(int nc) { return OFF_JC + 2 * nc * NV; }
+  static constexpr int size_for(int nc) { return nc == 0 ? SIZE_NC : (off_g(nc) + nc * (nc + 1) / 2 + 1) / 2 * 2; }
+  static constexpr int SIZE = (OFF_JC + 12 * NV + 21 + 1) / 2 * 2;  // the largest unit (six rows)
   static constexpr int SIZE_NC = (OFF_LAM + 1) / 2 * 2;  // problems without contacts never touch the contact block
 };
 
@@ -479,6 +481,7 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
 
   // contact of this node: CT = 3 (ContactModel3D) or 6 (ContactModel6D) constraint rows, fixed per kernel instantiation
   constexpr int NCR = CT ? CT : 3;
+  constexpr int OFF_MIJ = SM::off_mij(NCR), OFF_G = SM::off_g(NCR);
   const bool use_contact = FR && CT && P.has_contact && set.ncontacts > 0;
   int cframe = -1, cbody = -1, ccap = 0;
   if (use_contact) {
@@ -864,7 +867,7 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
           y[i] = s_ * Lm[i * NV + i];
         }
 #pragma unroll
-        for (int i = 0; i < NV; ++i) N[SM::OFF_MIJ + i * NCR + lane] = y[i];
+        for (int i = 0; i < NV; ++i) N[OFF_MIJ + i * NCR + lane] = y[i];
       });
       ex.sync();
       ex.each([&](int lane, int sl) {
@@ -874,12 +877,12 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
         for (int r = 0; r < NCR; ++r)
           for (int c = 0; c <= r; ++c) {
             double g = 0;
-            for (int i = 0; i < NV; ++i) g += N[SM::OFF_JC + r * NV + i] * N[SM::OFF_MIJ + i * NCR + c];
+            for (int i = 0; i < NV; ++i) g += N[SM::OFF_JC + r * NV + i] * N[OFF_MIJ + i * NCR + c];
             G[r * (r + 1) / 2 + c] = g;
           }
         chol_packed<NCR>(G);
 #pragma unroll
-        for (int i = 0; i < NG; ++i) N[SM::OFF_G + i] = G[i];
+        for (int i = 0; i < NG; ++i) N[OFF_G + i] = G[i];
       });
       ex.sync();
     }
@@ -936,15 +939,15 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
         }
         double Gf[NG];
 #pragma unroll
-        for (int i = 0; i < NG; ++i) Gf[i] = N[SM::OFF_G + i];
+        for (int i = 0; i < NG; ++i) Gf[i] = N[OFF_G + i];
         chol_solve_packed<NCR>(Gf, z);
 #pragma unroll
         for (int r = 0; r < NCR; ++r) dlam_l[sl][r] = z[r];
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-          double a_ = N[SM::OFF_MIJ + i * NCR] * z[0] + N[SM::OFF_MIJ + i * NCR + 1] * z[1] + N[SM::OFF_MIJ + i * NCR + 2] * z[2];
+          double a_ = N[OFF_MIJ + i * NCR] * z[0] + N[OFF_MIJ + i * NCR + 1] * z[1] + N[OFF_MIJ + i * NCR + 2] * z[2];
           if constexpr (CT == 6)
-            a_ += N[SM::OFF_MIJ + i * NCR + 3] * z[3] + N[SM::OFF_MIJ + i * NCR + 4] * z[4] + N[SM::OFF_MIJ + i * NCR + 5] * z[5];
+            a_ += N[OFF_MIJ + i * NCR + 3] * z[3] + N[OFF_MIJ + i * NCR + 4] * z[4] + N[OFF_MIJ + i * NCR + 5] * z[5];
           da[i] += a_;
         }
       }
