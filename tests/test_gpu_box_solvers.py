@@ -23,7 +23,7 @@ def box_problem(empc, name, dt):
 
 # Cold starts that do not converge within the iteration budget and whose iteration path is rounding-sensitive: the oracle
 # against its own -ffp-contract=fast build differs by 15..50 on xs (hover, BoxFDDP) and up to 5 (eagle_catch), measured with
-# tools/oracle_sensitivity.py's variant libraries on exactly these batches.  They are compared through their iteration
+# `tools/oracle_sensitivity.py --options` on exactly these batches (profiles/r02_oracle_sensitivity_options.json).  They are compared through their iteration
 # records (the first few of every rollout; the number = what the oracle's two builds themselves share: first divergent record
 # 2,4,2,7,2,2,6,6 on hover -- its cold start costs 2.5e9 after the first rollout -- and 12..30 on eagle_catch); the others
 # at the north-star bound.

@@ -32,7 +32,7 @@ def test_contact_options_solve(empc, tmp_path, contact, gains):
     d = problem.desc
     # six constraint rows on this 9-dof arm leave the KKT system (Jc M^-1 Jc^T) poorly conditioned: the oracle against its own
     # -ffp-contract=fast build already differs by 2e-8..9e-8 (relative) in the cost of the FIRST iteration and takes another
-    # path from record 2..7 on (tools/oracle_sensitivity.py's variant libraries on exactly these inputs; the 3D contact:
+    # path from record 2..7 on (`tools/oracle_sensitivity.py --options`, profiles/r02_oracle_sensitivity_options.json, on exactly these inputs; the 3D contact:
     # 1e-9 and record 37..43).  So for the 6D contact only the first record is required to agree (1e-5), next to the
     # phase-level parity above and the same-problem checks below.
     early = 1 if contact == "ContactModel6D" else pc.EARLY_K

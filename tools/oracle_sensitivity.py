@@ -173,8 +173,67 @@ def nudge_ulp(x0s, seed=7):
     return out
 
 
+def options_study(out_path):
+    """The option branches whose GPU tests use a relaxed criterion (tests/test_gpu_box_solvers.py,
+    tests/test_gpu_contact_options.py): the oracle against its -ffp-contract=fast build on exactly the inputs of those tests --
+    first divergent iteration record, relative difference of the FIRST iteration's cost, final xs difference."""
+    import pathlib
+    import tempfile
+    from conftest import contact_variant
+    base = build_variant("base", ["-ffp-contract=off"])
+    fma = build_variant("fma", ["-ffp-contract=fast"])
+    bind_solver_api(base)
+    bind_solver_api(fma)
+
+    def study(d, prm, x0s, maxiter):
+        fd, c0, it_a, it_b = [], [], [], []
+        for b in range(x0s.shape[0]):
+            ta, tb = trace_of(base, d, prm, x0s[b], maxiter), trace_of(fma, d, prm, x0s[b], maxiter)
+            fd.append(first_divergence(ta, tb, rtol=1e-5))
+            c0.append(float(abs(ta[0][2] - tb[0][2]) / (1 + abs(ta[0][2]))))
+            it_a.append(len(ta))
+            it_b.append(len(tb))
+        ra, rb = solve_with(base, d, prm, x0s, maxiter, 4), solve_with(fma, d, prm, x0s, maxiter, 4)
+        ex = np.abs(ra["xs"] - rb["xs"]).reshape(x0s.shape[0], -1).max(axis=1)
+        return {"first_divergent_record": [int(v) for v in fd], "first_iteration_cost_rel_diff": c0,
+                "iteration_records_base": it_a, "iteration_records_fma": it_b, "xs_max_abs_diff": [float(v) for v in ex]}
+
+    res = {"note": "oracle (-ffp-contract=off) vs the same sources with -ffp-contract=fast on the inputs of the GPU tests of the "
+                   "option branches; first_divergent_record uses rtol 1e-5 on the cost like tests/parity_criteria.py"}
+    box = {}
+    for name, dt in [("hover", 40), ("displacement", 80), ("eagle_catch", 32), ("push_slide", 13)]:
+        tr = empc.Trajectory()
+        tr.autoSetup(empc.yaml_path(CONFIGS[name][0]))
+        pb = tr.createProblem(dt, False, "IntegratedActionModelEuler")
+        d = pb.desc
+        x0s = empc.perturbed_x0s(pb.x0, 8, nq=d.model.nq)
+        for st, sname in ((1, "SolverBoxFDDP"), (2, "SolverBoxDDP")):
+            prm = ob.default_params()
+            prm.solver_type = st
+            box["%s/%s" % (name, sname)] = study(d, prm, x0s, 30)
+    res["box_solvers_cold_start_B8_maxiter30"] = box
+    con = {}
+    with tempfile.TemporaryDirectory() as td:
+        for contact, gains in [("ContactModel3D", (0.0, 0.0)), ("ContactModel3D", (9.0, 4.0)), ("ContactModel6D", (0.0, 0.0)),
+                               ("ContactModel6D", (11.0, 5.0))]:
+            _, pb = contact_variant(empc, pathlib.Path(td), contact, gains)
+            d = pb.desc
+            x0s = empc.perturbed_x0s(pb.x0, 4, nq=d.model.nq, amplitude=0.02)
+            x0s[0] = pb.x0
+            con["%s gains %s" % (contact, list(gains))] = study(d, ob.default_params(), x0s, 100)
+    res["eagle_catch_contact_options_B4_maxiter100"] = con
+    with open(out_path, "w") as f:
+        json.dump(res, f, indent=1)
+    for k in ("box_solvers_cold_start_B8_maxiter30", "eagle_catch_contact_options_B4_maxiter100"):
+        for name, v in res[k].items():
+            print(name, "first divergent record", v["first_divergent_record"], "| first-iteration cost diff max %.1e" %
+                  max(v["first_iteration_cost_rel_diff"]), "| xs diff max %.1e" % max(v["xs_max_abs_diff"]))
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--options", action="store_true",
+                    help="study the option branches (box solvers, contact options) instead; writes profiles/r02_oracle_sensitivity_options.json")
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--configs", default="eagle_catch,hover,displacement")
     ap.add_argument("--maxiter", type=int, default=100)
@@ -183,6 +242,9 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02_oracle_sensitivity.json"))
     args = ap.parse_args()
     ob.build_oracle()
+    if args.options:
+        options_study(os.path.join(ROOT, "profiles", "r02_oracle_sensitivity_options.json"))
+        return
     base = build_variant("base", ["-ffp-contract=off"])
     fma = build_variant("fma", ["-ffp-contract=fast"])
     res = {"note": "CPU oracle against rounding-only variants of itself on identical perturbed rollouts "
