@@ -76,6 +76,7 @@ struct DevBuffers {
   // trajectories that linearize in this sweep, written by the previous sweep's select (compact, any order); nullptr =
   // every trajectory.  linearize is the one throughput-bound kernel: with the list its time follows the number of
   // trajectories still iterating instead of the number of workgroups that hold at least one of them.
+  int lin_bound = 0;  // host-side upper bound on the length of lin_list (the active count two sweeps back; 0 = B): sizes the grid
   const int* lin_list = nullptr;
   const int* lin_count = nullptr;
   int* lin_list_out = nullptr;   // the list select builds for the next sweep (nullptr = none)

@@ -128,7 +128,7 @@ k_linearize(DevBuffers D) {
 #endif
   // this body's knots: the lean group or the rest of the sorted knot list; a block holds UPB trajectories of ONE knot
   const int k0 = FR ? D.n_lean : 0, nk = FR ? (D.T + 1 - D.n_lean) : D.n_lean;
-  const int bpk = (D.B + UPB - 1) / UPB;
+  const int bpk = ((D.lin_bound > 0 ? D.lin_bound : D.B) + UPB - 1) / UPB;
   const int kn = blockIdx.x / bpk;
   if (kn >= nk) return;
   const int t = EMPC_KPTR(int, D.lin_knots)[k0 + kn];
@@ -334,7 +334,10 @@ static void launch_linearize_blk(DevBuffers D, hipStream_t s) {
   }();
   (void)once;
   // lean body over the knots without operational frames, full body over the rest; every unit runs in exactly one of them
-  const int bpk = (D.B + UPB - 1) / UPB;  // blocks per knot: a block never straddles two knots
+  // blocks per knot: a block never straddles two knots.  The list of trajectories that linearize is at most lin_bound long
+  // (what the host last saw of the active count), so a sweep with few stragglers launches few workgroups instead of
+  // B / UPB per knot that return at once
+  const int bpk = ((D.lin_bound > 0 ? D.lin_bound : D.B) + UPB - 1) / UPB;
   const int n_lean = bpk * D.n_lean, n_full = bpk * (D.T + 1 - D.n_lean);
   if (n_lean > 0) hipLaunchKernelGGL((k_linearize<DM, CT, LPU, BLK, false>), dim3(n_lean), dim3(BLK), smem, s, D);
   if (n_full > 0) hipLaunchKernelGGL((k_linearize<DM, CT, LPU, BLK, true>), dim3(n_full), dim3(BLK), smem, s, D);
@@ -382,6 +385,7 @@ static void launch_rk4_linearize(DevBuffers D, Rk4Buffers R, hipStream_t s) {
   Dv.x0 = R.ys;  // never read in RAW mode
   Dv.lin_list = nullptr;
   Dv.lin_count = nullptr;
+  Dv.lin_bound = 0;  // the stage batch is not compacted
   Dv.raw = 1;
   launch_linearize<DM, CT>(Dv, s);
   hipLaunchKernelGGL(k_rk4_assemble<DM>, dim3(n), dim3(64), sizeof(double) * Rk4Smem<DM>::SIZE, s, D, R);

@@ -550,6 +550,7 @@ int empc_solver_solve(EmpcSolver* s, int maxiter, int is_feasible) {
       Dq.lin_list = s->dlin_list + (size_t)(1 - q) * s->B + c.b0;
       Dq.act_count = c.D.n_active + 2 * (1 - q);
       Dq.act_list = s->dact_list + (size_t)(1 - q) * s->B + c.b0;
+      Dq.lin_bound = c.active > 0 ? c.active : 1;  // the active set only shrinks: the last count the host saw bounds the list
     }
     Dq.counters_next = c.D.n_active + 2 * (1 - q);  // zeroed by this sweep's select for the next sweep
     Dq.done_ticket = s->dticket + c.idx;
