@@ -73,6 +73,7 @@ def lib():
     L.empc_solver_destroy.argtypes = [C.c_void_p]
     L.empc_mpc_solver_type.argtypes = [C.c_void_p, C.c_void_p]
     L.empc_solver_supported.argtypes = [C.POINTER(T.ProblemDesc), C.POINTER(T.SolverParams)]
+    L.empc_solver_set_cost_refs.argtypes = [C.c_void_p, C.c_int, C.c_char_p, _dp, C.c_int, C.c_int, C.c_double]
     L.empc_solver_update_problem.argtypes = [C.c_void_p, C.POINTER(T.ProblemDesc)]
     L.empc_solver_set_x0.argtypes = [C.c_void_p, _dp]
     L.empc_solver_set_warmstart.argtypes = [C.c_void_p, _dp, _dp]
@@ -333,6 +334,14 @@ class SolverSbFDDP:
 
     def update_problem(self):
         _check(lib().empc_solver_update_problem(self._h, C.byref(self.problem.desc)))
+
+    def set_cost_refs(self, knot, name, ref=None, active=None, weight=None):
+        """Edit one cost entry of node `knot` in place -- residual.reference / cost.active / cost.weight of the reference's
+        crocoddyl models, as MpcAbstract.updateProblem does (src/mpc-controllers/carrot-mpc.cpp:298-359).  None = keep."""
+        r = None if ref is None else np.ascontiguousarray(ref, dtype=np.float64).ravel()
+        _check(lib().empc_solver_set_cost_refs(self._h, int(knot), name.encode(), _ptr(r), 0 if r is None else r.size,
+                                               -1 if active is None else int(bool(active)),
+                                               float("nan") if weight is None else float(weight)))
 
     # -- plant of closed-loop runs (AerialSimulator, bindings/python/eagle_mpc/utils/simulator.py) ------------
     @property

@@ -79,6 +79,12 @@ struct EmpcSolver {
   int* dticket = nullptr;      // [MAX_STREAMS] completion tickets of select
   std::vector<TrajState> h_st;
   bool have_state = false;
+  // the problem as the caller described it (before barrier injection and the other preparations), kept so that single
+  // cost entries can be edited in place (empc_solver_set_cost_refs); re-prepared and uploaded lazily before the next launch
+  EmpcProblemDesc user_desc;
+  std::vector<EmpcCostSet> user_sets;
+  std::vector<int32_t> user_knot_set;
+  bool problem_dirty = false;
   EmpcSolveStats stats;
   std::vector<void*> allocs;
 
@@ -121,6 +127,23 @@ static void upload_problem(EmpcSolver* s) {
     HIP_CHECK(hipStreamSynchronize(s->stream));  // `order` is a local
   }
   HIP_CHECK(hipStreamSynchronize(s->stream));
+}
+
+static void remember_problem(EmpcSolver* s, const EmpcProblemDesc& d) {
+  s->user_desc = d;
+  s->user_sets.assign(d.sets, d.sets + d.n_sets);
+  s->user_knot_set.assign(d.knot_set, d.knot_set + d.T + 1);
+  s->user_desc.sets = s->user_sets.data();
+  s->user_desc.knot_set = s->user_knot_set.data();
+  s->problem_dirty = false;
+}
+// pending edits of empc_solver_set_cost_refs reach the device here: before anything that launches a kernel
+static void flush_problem(EmpcSolver* s) {
+  if (!s->problem_dirty) return;
+  const EmpcSolverParams prm = s->H.P.prm;
+  prepare_problem(s->user_desc, prm, s->H);
+  upload_problem(s);
+  s->problem_dirty = false;
 }
 
 static void upload_states(EmpcSolver* s) {
@@ -195,6 +218,7 @@ EmpcSolver* empc_solver_create(const EmpcProblemDesc* problem, const EmpcSolverP
   s = new EmpcSolver();
   s->device = device;
   prepare_problem(*problem, prm, s->H);
+  remember_problem(s, *problem);
   check_device_support(*problem);
   if (!find_table(problem->model.nbodies, problem->n_rotors, problem->has_contact != 0, s->H.contact_rows, s->kt)) {
     delete s;
@@ -343,7 +367,31 @@ int empc_solver_update_problem(EmpcSolver* s, const EmpcProblemDesc* problem) {
   s->use();
   const EmpcSolverParams prm = s->H.P.prm;
   prepare_problem(*problem, prm, s->H);
+  remember_problem(s, *problem);
   upload_problem(s);
+  return EMPC_OK;
+  EMPC_CATCH(RET_INT)
+}
+
+// One cost entry of the node's model, edited in place: what MpcAbstract::updateProblem does to the crocoddyl models between
+// two solves (src/mpc-controllers/carrot-mpc.cpp:298-359: residual->set_reference, costs->get_costs().at(name)->weight / active).
+// Nodes that share a cost set (all knots of a trajectory stage) see the edit together, like the reference's shared models.
+int empc_solver_set_cost_refs(EmpcSolver* s, int knot, const char* cost_name, const double* ref, int nref, int active, double weight) {
+  EMPC_TRY
+  if (!s || !cost_name) throw std::invalid_argument("NULL argument");
+  if (knot < 0 || knot > s->T) throw std::invalid_argument("set_cost_refs: knot out of range");
+  EmpcCostSet& set = s->user_sets[s->user_knot_set[knot]];
+  EmpcCost* c = nullptr;
+  for (int i = 0; i < set.ncosts; ++i)
+    if (std::strncmp(set.costs[i].name, cost_name, EMPC_NAME_LEN) == 0) c = &set.costs[i];
+  if (!c) throw std::invalid_argument(std::string("set_cost_refs: node has no cost named '") + cost_name + "'");
+  if (ref) {
+    if (nref < 1 || nref > EMPC_MAX_NX) throw std::invalid_argument("set_cost_refs: reference length out of range");
+    std::memcpy(c->ref, ref, sizeof(double) * nref);
+  }
+  if (active >= 0) c->active = active ? 1 : 0;
+  if (weight == weight) c->weight = weight;  // NaN = leave
+  s->problem_dirty = true;
   return EMPC_OK;
   EMPC_CATCH(RET_INT)
 }
@@ -503,6 +551,7 @@ int empc_solver_solve(EmpcSolver* s, int maxiter, int is_feasible) {
   if (!s) throw std::invalid_argument("solver is NULL");
   if (maxiter < 1) throw std::invalid_argument("maxiter must be >= 1");
   s->use();
+  flush_problem(s);
   for (int b = 0; b < s->B; ++b) {
     TrajState prev = s->h_st[b];
     init_traj_state(s->h_st[b], s->H.P.prm, maxiter, is_feasible != 0, s->have_state ? &prev : nullptr);
@@ -782,6 +831,7 @@ int empc_linearize_batch(EmpcSolver* s, const double* xs, const double* us, doub
   if (!s) throw std::invalid_argument("solver is NULL");
   (void)xnext;
   s->use();
+  flush_problem(s);
   if (xs || us) {
     if (empc_solver_set_warmstart(s, xs, us) != EMPC_OK) throw std::runtime_error(empc_last_error());
   }

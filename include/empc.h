@@ -203,6 +203,13 @@ EmpcMpc* empc_weighted_mpc_create(EmpcTrajectory* t, int dt_ref_ms, const char* 
 void empc_mpc_destroy(EmpcMpc* m);
 /* get_knots / get_iters / get_dt (src/mpc-base.cpp:81-85) and the problem's dimensions */
 int empc_mpc_params(const EmpcMpc* m, int* knots, int* iters, int* dt_ms, int* nx, int* ndx, int* nu);
+/* One cost entry of a node's model, edited in place between two solves -- residual->set_reference(...), cost->weight,
+ * cost->active as MpcAbstract::updateProblem applies them to the crocoddyl models (src/mpc-controllers/carrot-mpc.cpp:298-359,
+ * rail-mpc.cpp:151-161, weighted-mpc.cpp:170-243).  `knot` in [0, T]; the cost is named as in the YAML / CostModelSum.
+ * ref: new reference payload (layout of EmpcCost.ref; NULL = keep), active: 0 / 1 (-1 = keep), weight: NaN = keep.  Nodes
+ * that share a cost set (the knots of one trajectory stage) change together, like the reference's shared models.  The edit is
+ * uploaded before the next solve / phase call; empc_solver_update_problem replaces the whole table instead. */
+int empc_solver_set_cost_refs(EmpcSolver* s, int knot, const char* cost_name, const double* ref, int nref, int active, double weight);
 /* get_solver_type() (src/mpc-base.cpp:85): the EmpcSolverType the controller's YAML names (`solver: SolverSbFDDP |
  * SolverBoxFDDP | SolverBoxDDP`); pass the handle you have and NULL for the other.  Create the solver with that
  * EmpcSolverParams.solver_type (src/mpc-controllers/carrot-mpc.cpp:232-242). */

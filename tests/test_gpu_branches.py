@@ -230,3 +230,46 @@ def test_rk4_integrator_on_gpu(empc, name, dt, B):
     # to 1e-3 (measured 1.4e-4 on the GPU, 2e-5 through the CPU emulation of the same kernels)
     assert np.abs(s.xs_batch - r["xs"]).max() < 1e-4 and np.abs(s.us_batch - r["us"]).max() < 1e-3
     assert np.all(np.abs(s.cost_batch - r["cost"]) < 1e-6 * (1 + np.abs(r["cost"])))
+
+
+def test_set_cost_refs_equals_table_update(empc, problems):
+    """empc_solver_set_cost_refs (one cost entry edited in place: reference, weight, active -- what MpcAbstract::updateProblem
+    does to the crocoddyl models, src/mpc-controllers/carrot-mpc.cpp:298-359) gives bitwise the solve of a problem whose
+    table was edited on the host and re-sent whole (empc_solver_update_problem); a wrong name or knot is an error."""
+    tr, _ = problems["displacement"]
+    problem = tr.createProblem(80, True, "IntegratedActionModelEuler")
+    d = problem.desc
+    knot = 60
+    st = d.sets[d.knot_set[knot]]
+    by_name = {st.costs[i].name.decode(): i for i in range(st.ncosts)}
+    state_cost = [n for n, i in by_name.items() if st.costs[i].type == empc.T.COST_STATE][0]
+    other = [n for n in by_name if n != state_cost][0]
+    a = empc.SolverSbFDDP(problem, batch=2)
+    b = empc.SolverSbFDDP(problem, batch=2)
+    a.solve([], [], 100)
+    base_cost = a.cost
+    ref = np.array([st.costs[by_name[state_cost]].ref[i] for i in range(d.nx)])
+    ref[0] += 0.4
+    ref[2] -= 0.2
+    a.set_cost_refs(knot, state_cost, ref=ref, weight=3.0 * st.costs[by_name[state_cost]].weight)
+    a.set_cost_refs(knot, other, active=False)
+    a.solve([], [], 100)
+    try:
+        keep = (list(st.costs[by_name[state_cost]].ref), st.costs[by_name[state_cost]].weight, st.costs[by_name[other]].active)
+        for i in range(d.nx):
+            st.costs[by_name[state_cost]].ref[i] = ref[i]
+        st.costs[by_name[state_cost]].weight *= 3.0
+        st.costs[by_name[other]].active = 0
+        b.update_problem()
+        b.solve([], [], 100)
+    finally:
+        for i in range(len(keep[0])):
+            st.costs[by_name[state_cost]].ref[i] = keep[0][i]
+        st.costs[by_name[state_cost]].weight = keep[1]
+        st.costs[by_name[other]].active = keep[2]
+    assert a.cost != base_cost
+    assert np.array_equal(a.xs_batch, b.xs_batch) and np.array_equal(a.us_batch, b.us_batch) and a.iter == b.iter
+    with pytest.raises(empc.EmpcError, match="no cost named"):
+        a.set_cost_refs(knot, "no_such_cost", weight=1.0)
+    with pytest.raises(empc.EmpcError, match="knot out of range"):
+        a.set_cost_refs(d.T + 1, state_cost, weight=1.0)
