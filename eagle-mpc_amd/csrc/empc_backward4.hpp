@@ -237,41 +237,55 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
 #pragma unroll
             for (int r = 0; r < 4; ++r) accW[sl][mt][nt][r] = 0.0;
       });
+      // (operands of k step ks + 1 are requested from LDS before the matrix-core instructions of step ks are issued: the
+      //  stage fences of `each` would otherwise expose one LDS round trip per k step)
+      {
+        double aopW[2][Exec::SLOTS][MTN], bopW[2][Exec::SLOTS][NTQ];
+        auto loadW = [&](int ks, int buf) {
+          ex.each([&](int lane, int sl) {
+            const int li = lane % 16, lq = lane / 16;
 #pragma unroll
-      for (int ks = 0; ks < KSN; ++ks) {
-        double aop[Exec::SLOTS][MTN], bop[Exec::SLOTS][NTQ];
-        ex.each([&](int lane, int sl) {
-          const int li = lane % 16, lq = lane / 16;
+            for (int mt = 0; mt < MTN; ++mt) aopW[buf][sl][mt] = V[(16 * mt + li) * VS + 4 * ks + lq];
 #pragma unroll
-          for (int mt = 0; mt < MTN; ++mt) aop[sl][mt] = V[(16 * mt + li) * VS + 4 * ks + lq];
+            for (int nt = 0; nt < NTQ; ++nt) bopW[buf][sl][nt] = rec[DM::OFF_A + (4 * ks + lq) * nm + 16 * nt + li];
+          });
+        };
+        loadW(0, 0);
 #pragma unroll
-          for (int nt = 0; nt < NTQ; ++nt) bop[sl][nt] = rec[DM::OFF_A + (4 * ks + lq) * nm + 16 * nt + li];
-        });
+        for (int ks = 0; ks < KSN; ++ks) {
+          if (ks + 1 < KSN) loadW(ks + 1, (ks + 1) & 1);
 #pragma unroll
-        for (int mt = 0; mt < MTN; ++mt)
+          for (int mt = 0; mt < MTN; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < NTQ; ++nt) ex.mfma(aop, mt, bop, nt, accW, mt, nt);
+            for (int nt = 0; nt < NTQ; ++nt) ex.mfma(aopW[ks & 1], mt, bopW[ks & 1], nt, accW, mt, nt);
+        }
       }
       BWD_STAMP(1);
       // Q = H + A^T [W | Vx'].  A^T[i][k] = A[k][i]: same address pattern as the B operand above.  B operand = the W
       // accumulators themselves (register r of tile (mt, nt) holds row 4 mt' + r ... of k step ks = 4 mt + r), with column
       // nm taken from Vx' (zero beyond n).  Rows >= n of W are exact zeros (zero rows of V), so the garbage A^T values of
       // k >= n contribute nothing.
+      {
+        double aopQ[2][Exec::SLOTS][MTQ], bopQ[2][Exec::SLOTS][NTQ];
+        auto loadQ = [&](int ks, int buf) {
+          ex.each([&](int lane, int sl) {
+            const int li = lane % 16, lq = lane / 16;
 #pragma unroll
-      for (int ks = 0; ks < KSN; ++ks) {
-        double aop[Exec::SLOTS][MTQ], bop[Exec::SLOTS][NTQ];
-        ex.each([&](int lane, int sl) {
-          const int li = lane % 16, lq = lane / 16;
+            for (int mt = 0; mt < MTQ; ++mt) aopQ[buf][sl][mt] = rec[DM::OFF_A + (4 * ks + lq) * nm + 16 * mt + li];
+            const double vxk = vx[4 * ks + lq];
 #pragma unroll
-          for (int mt = 0; mt < MTQ; ++mt) aop[sl][mt] = rec[DM::OFF_A + (4 * ks + lq) * nm + 16 * mt + li];
-          const double vxk = vx[4 * ks + lq];
+            for (int nt = 0; nt < NTQ; ++nt) bopQ[buf][sl][nt] = (16 * nt + li == nm) ? vxk : accW[sl][ks / 4][nt][ks % 4];
+          });
+        };
+        loadQ(0, 0);
 #pragma unroll
-          for (int nt = 0; nt < NTQ; ++nt) bop[sl][nt] = (16 * nt + li == nm) ? vxk : accW[sl][ks / 4][nt][ks % 4];
-        });
+        for (int ks = 0; ks < KSN; ++ks) {
+          if (ks + 1 < KSN) loadQ(ks + 1, (ks + 1) & 1);
 #pragma unroll
-        for (int mt = 0; mt < MTQ; ++mt)
+          for (int mt = 0; mt < MTQ; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < NTQ; ++nt) ex.mfma(aop, mt, bop, nt, accQ, mt, nt);
+            for (int nt = 0; nt < NTQ; ++nt) ex.mfma(aopQ[ks & 1], mt, bopQ[ks & 1], nt, accQ, mt, nt);
+        }
       }
       // whole tiles into the padded Q array (column nm = Qx | Qu)
       ex.each([&](int lane, int sl) {
@@ -390,21 +404,27 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
           red[64 + lane] = a_;
         }
       });
+      {
+        double aopV[2][Exec::SLOTS][MTN], bopV[2][Exec::SLOTS][MTN];
+        auto loadV = [&](int ks, int buf) {
+          ex.each([&](int lane, int sl) {
+            const int li = lane % 16, lq = lane / 16;
 #pragma unroll
-      for (int ks = 0; ks < KSM; ++ks) {
-        double aop[Exec::SLOTS][MTN], bop[Exec::SLOTS][MTN];
-        ex.each([&](int lane, int sl) {
-          const int li = lane % 16, lq = lane / 16;
+            for (int mt = 0; mt < MTN; ++mt) {
+              aopV[buf][sl][mt] = Q[(16 * mt + li) * QS + n + 4 * ks + lq];
+              bopV[buf][sl][mt] = Kn[(4 * ks + lq) * KS + 16 * mt + li];
+            }
+          });
+        };
+        loadV(0, 0);
 #pragma unroll
-          for (int mt = 0; mt < MTN; ++mt) {
-            aop[sl][mt] = Q[(16 * mt + li) * QS + n + 4 * ks + lq];
-            bop[sl][mt] = Kn[(4 * ks + lq) * KS + 16 * mt + li];
-          }
-        });
+        for (int ks = 0; ks < KSM; ++ks) {
+          if (ks + 1 < KSM) loadV(ks + 1, (ks + 1) & 1);
 #pragma unroll
-        for (int mt = 0; mt < MTN; ++mt)
+          for (int mt = 0; mt < MTN; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < MTN; ++nt) ex.mfma(aop, mt, bop, nt, accQ, mt, nt);
+            for (int nt = 0; nt < MTN; ++nt) ex.mfma(aopV[ks & 1], mt, bopV[ks & 1], nt, accQ, mt, nt);
+        }
       }
       ex.each([&](int lane, int sl) {
         const int lj = lane % 16, lq = lane / 16;
