@@ -370,7 +370,9 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
           }
         }
       });
+      BWD_STAMP(8);
       ex.sync();
+      BWD_STAMP(9);
       // Quu k, one row per lane (same order of summation as the single-lane form)
       ex.each([&](int lane, int sl) {
         if (lane < m) {
@@ -381,6 +383,7 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
         }
       });
       ex.sync();
+      BWD_STAMP(10);
       if (flag[0] != 0.0) {
         fail = true;
         break;
@@ -404,6 +407,7 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
           red[64 + lane] = a_;
         }
       });
+      BWD_STAMP(11);
       {
         double aopV[2][Exec::SLOTS][MTN], bopV[2][Exec::SLOTS][MTN];
         auto loadV = [&](int ks, int buf) {
@@ -435,6 +439,7 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
 #pragma unroll
             for (int r = 0; r < 4; ++r) W[(16 * mt + 4 * r + lq) * WS + 16 * nt + lj] = accQ[sl][mt][nt][r];
       });
+      BWD_STAMP(12);
       ex.sync();
       BWD_STAMP(4);
       // symmetrise + regularise -> V; NaN / overflow guards of Vxx and Vx are collected per lane and reduced once
@@ -465,7 +470,9 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
         red[32 + lane] = infeas ? rec[DM::OFF_GAP + lane] * a_ : 0.0;
         badl[sl] = badl[sl] || bad_number(nv);  // NaN, inf or >= 1e30 in Vx (crocoddyl's raiseIfNaN on max |Vx|)
       });
+      BWD_STAMP(13);
       const bool badAny = ex.any([&](int lane, int sl) { return badl[sl]; });
+      BWD_STAMP(14);
       if (infeas) {  // same order of summation as backward3; with closed gaps every term would be an exact zero
         for (int i = 0; i < n; ++i) {
           dg_f -= red[i];
@@ -483,7 +490,7 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
     if (b == 0)
       ex.each([&](int lane, int sl) {
         if (lane == 0)
-          for (int i = 0; i < 8; ++i) D.dbg[16 + i] = bst[i];
+          for (int i = 0; i < 15; ++i) D.dbg[16 + i] = bst[i];
       });
 #endif
     ex.sync();

@@ -45,7 +45,8 @@ print('stage cycles (EMPC_STAMPS builds; rollout v1, trajectory 0, alpha 1/2): f
 
 
 print('linearize stage cycles (unit b=0,t=10): S0 load|S1 squash/trig|S2 nominal+Euler|S3 tangent|S4 chol|S5 solves+Fx,Fu|S6 state costs (column sums)|ctrl costs|frame costs|S7 store|S6 staging|S6 nominal parts|S2 nominal chain only|S6 activations', list(cnt)[32:46])
-print('backward stage cycles (trajectory 0, EMPC_STAMPS builds): load|W|Q|gains|Vxx|sym|gap|looptop', list(cnt)[16:24])
+print('backward stage cycles (trajectory 0, EMPC_STAMPS builds): load|W|Q|gains tail (sums)|Vxx tail (sync)|sym|gap tail (sums)|looptop', list(cnt)[16:24])
+print('backward sub-stages: chol+solves|sync|Quu k+sync|Vx partial|Vxx MFMA + W write|gap dot products|any', list(cnt)[24:31])
 print('rollout6 role cycles per rollout (EMPC_STAMPS builds; workgroup 0): role A|B|C|D x {phase I work, wait 1, phase II work, wait 2}',
       [list(cnt)[48 + 4 * r:52 + 4 * r] for r in range(4)])
 print('rollout6 role B sub-stages (cycles per rollout): fetch issue|quat,trig,scan|rnea|H,CAP writes|frame costs|-|outside', list(cnt)[0:7])
