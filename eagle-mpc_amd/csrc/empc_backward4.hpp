@@ -20,6 +20,17 @@
 
 namespace empc {
 
+// Scheduling fence: nothing moves across it.  With 256 registers in use the compiler otherwise turns a short loop over LDS
+// values into load, wait, use, load, wait, use ... -- one exposed LDS round trip (~100 cycles) per element; a block of
+// loads, a fence, then the arithmetic in its original order costs one.
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+#define BWD_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define BWD_FENCE() \
+  do {              \
+  } while (0)
+#endif
+
 template <class DM>
 struct Bwd4Smem {
   static constexpr int n = DM::NDX, m = DM::NU, nm = n + m;
@@ -376,10 +387,18 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
       // Quu k, one row per lane (same order of summation as the single-lane form)
       ex.each([&](int lane, int sl) {
         if (lane < m) {
+          double qrow[m], kv[m];
+#pragma unroll
+          for (int j = 0; j < m; ++j) {
+            qrow[j] = Q[(n + (lane > j ? lane : j)) * QS + n + (lane > j ? j : lane)];
+            kv[j] = kf[j];
+          }
+          const double kl = kf[lane];
+          BWD_FENCE();
           double a_ = 0;
 #pragma unroll
-          for (int j = 0; j < m; ++j) a_ += Q[(n + (lane > j ? lane : j)) * QS + n + (lane > j ? j : lane)] * kf[j];
-          kf[m + lane] = a_ + ureg * kf[lane];
+          for (int j = 0; j < m; ++j) a_ += qrow[j] * kv[j];
+          kf[m + lane] = a_ + ureg * kl;
         }
       });
       ex.sync();
@@ -388,22 +407,39 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
         fail = true;
         break;
       }
-      for (int i = 0; i < m; ++i) {
-        const double qu = Q[(n + i) * QS + nm];
-        dg_u += qu * kf[i];
-        dq_u -= kf[i] * kf[m + i];
-        qu2 += qu * qu;
+      {
+        double quv[m], kv[m], qkv[m];
+#pragma unroll
+        for (int i = 0; i < m; ++i) {
+          quv[i] = Q[(n + i) * QS + nm];
+          kv[i] = kf[i];
+          qkv[i] = kf[m + i];
+        }
+        BWD_FENCE();
+#pragma unroll
+        for (int i = 0; i < m; ++i) {
+          dg_u += quv[i] * kv[i];
+          dq_u -= kv[i] * qkv[i];
+          qu2 += quv[i] * quv[i];
+        }
       }
       BWD_STAMP(3);
       // Vx = Qx + K^T Quuk - 2 K^T Qu from the lane's own column; Vxx = Qxx + (Qxu)(-K) on the matrix cores: the Qxx tiles
       // are still in the accumulators of the Q stage, A operand = Qxu (columns n.. of Q; beyond m they meet zero rows of -K)
       ex.each([&](int lane, int sl) {
         if (lane < n) {
+          double qkv[m], quv[m];
+#pragma unroll
+          for (int l = 0; l < m; ++l) {
+            qkv[l] = kf[m + l];
+            quv[l] = Q[(n + l) * QS + nm];
+          }
           double a_ = Q[lane * QS + nm];
+          BWD_FENCE();
 #pragma unroll
-          for (int l = 0; l < m; ++l) a_ += Kc[sl][l] * kf[m + l];
+          for (int l = 0; l < m; ++l) a_ += Kc[sl][l] * qkv[l];
 #pragma unroll
-          for (int l = 0; l < m; ++l) a_ -= 2.0 * Kc[sl][l] * Q[(n + l) * QS + nm];
+          for (int l = 0; l < m; ++l) a_ -= 2.0 * Kc[sl][l] * quv[l];
           red[64 + lane] = a_;
         }
       });
@@ -446,11 +482,25 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
       bool badl[Exec::SLOTS];
       ex.each([&](int lane, int sl) {
         bool bad = false;
-        for (int i = lane; i < n * n; i += NL) {
-          const int rr = i / n, cc = i % n;
-          const double v_ = 0.5 * (W[rr * WS + cc] + W[cc * WS + rr]) + ((rr == cc) ? xreg : 0.0);
-          V[rr * VS + cc] = v_;
-          bad = bad || bad_number(v_);
+        constexpr int NS = (n * n + NL - 1) / NL;
+        double wa[NS], wb[NS];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+          const int i = lane + q * NL, ic = i < n * n ? i : 0;
+          const int rr = ic / n, cc = ic % n;
+          wa[q] = W[rr * WS + cc];
+          wb[q] = W[cc * WS + rr];
+        }
+        BWD_FENCE();
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+          const int i = lane + q * NL;
+          if (i < n * n) {
+            const int rr = i / n, cc = i % n;
+            const double v_ = 0.5 * (wa[q] + wb[q]) + ((rr == cc) ? xreg : 0.0);
+            V[rr * VS + cc] = v_;
+            bad = bad || bad_number(v_);
+          }
         }
         badl[sl] = bad;
       });
@@ -460,8 +510,25 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
       ex.each([&](int lane, int sl) {
         if (lane >= n) return;
         double a_ = 0;
-        if (infeas)
-          for (int j = 0; j < n; ++j) a_ += V[lane * VS + j] * rec[DM::OFF_GAP + j];
+        if (infeas) {
+          constexpr int CH = 6;
+          static_assert(n % CH == 0 || true, "");
+#pragma unroll
+          for (int j0 = 0; j0 < n; j0 += CH) {
+            double vv[CH], gg[CH];
+#pragma unroll
+            for (int j = 0; j < CH; ++j)
+              if (j0 + j < n) {
+                vv[j] = V[lane * VS + j0 + j];
+                gg[j] = rec[DM::OFF_GAP + j0 + j];
+              }
+            BWD_FENCE();
+#pragma unroll
+            for (int j = 0; j < CH; ++j)
+              if (j0 + j < n) a_ += vv[j] * gg[j];
+            BWD_FENCE();
+          }
+        }
         const double nv = red[64 + lane] + (infeas ? a_ : 0.0);
         vx[lane] = nv;
         vfo[sl] = a_;
@@ -474,9 +541,24 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
       const bool badAny = ex.any([&](int lane, int sl) { return badl[sl]; });
       BWD_STAMP(14);
       if (infeas) {  // same order of summation as backward3; with closed gaps every term would be an exact zero
-        for (int i = 0; i < n; ++i) {
-          dg_f -= red[i];
-          dq_f += red[32 + i];
+        constexpr int CH = 6;
+#pragma unroll
+        for (int i0 = 0; i0 < n; i0 += CH) {
+          double ra[CH], rb[CH];
+#pragma unroll
+          for (int i = 0; i < CH; ++i)
+            if (i0 + i < n) {
+              ra[i] = red[i0 + i];
+              rb[i] = red[32 + i0 + i];
+            }
+          BWD_FENCE();
+#pragma unroll
+          for (int i = 0; i < CH; ++i)
+            if (i0 + i < n) {
+              dg_f -= ra[i];
+              dq_f += rb[i];
+            }
+          BWD_FENCE();
         }
       }
       if (badAny) {
