@@ -358,17 +358,21 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
         });
       } else
       ex.each([&](int lane, int sl) {
-        double Lq[m * (m + 1) / 2];
+        // Quu and the lane's right-hand side: every LDS read issued before the arithmetic starts (BWD_FENCE); the
+        // regularisation touches the diagonal only (an `+ 0.0` on the other entries is a real FP64 instruction)
+        double Lq[m * (m + 1) / 2], rhs[m];
 #pragma unroll
         for (int i = 0; i < m; ++i)
 #pragma unroll
-          for (int j = 0; j <= i; ++j) Lq[i * (i + 1) / 2 + j] = Q[(n + i) * QS + n + j] + ((i == j) ? ureg : 0.0);
+          for (int j = 0; j <= i; ++j) Lq[i * (i + 1) / 2 + j] = Q[(n + i) * QS + n + j];
+#pragma unroll
+        for (int i = 0; i < m; ++i) rhs[i] = Q[((lane < n) ? lane : (n + i)) * QS + ((lane < n) ? (n + i) : nm)];
+        BWD_FENCE();
+#pragma unroll
+        for (int i = 0; i < m; ++i) Lq[i * (i + 1) / 2 + i] += ureg;
         const bool pd = chol_packed<m>(Lq);
         if (lane == 0) flag[0] = pd ? 0.0 : 1.0;
         if (lane <= n) {
-          double rhs[m];
-#pragma unroll
-          for (int i = 0; i < m; ++i) rhs[i] = Q[((lane < n) ? lane : (n + i)) * QS + ((lane < n) ? (n + i) : nm)];
           chol_solve_packed<m>(Lq, rhs);
 #pragma unroll
           for (int i = 0; i < m; ++i) Kc[sl][i] = rhs[i];
