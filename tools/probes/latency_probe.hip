@@ -115,6 +115,36 @@ __global__ void __launch_bounds__(64) probe(double* out, unsigned long long* cyc
   cyc[k++] = t1 - t0;
   out[lane] = x + s + idx;
 }
+// dependent scalar loads (s_load_dword through the constant cache): idx = table[idx], wave-uniform
+typedef const __attribute__((address_space(4))) int* kint_p;
+__global__ void __launch_bounds__(64) probe_sload(const int* table, int* out, unsigned long long* cyc) {
+  kint_p t = (kint_p)(const void*)table;
+  int idx = 0;
+  FENCE(); unsigned long long t0 = CLK(); FENCE();
+#pragma unroll
+  for (int i = 0; i < 64; ++i) idx = t[idx];
+  FENCE(); unsigned long long t1 = CLK(); FENCE();
+  cyc[0] = t1 - t0;
+  // second pass over the same lines (now certainly cached)
+  idx = 0;
+  FENCE(); t0 = CLK(); FENCE();
+#pragma unroll
+  for (int i = 0; i < 64; ++i) idx = t[idx];
+  FENCE(); t1 = CLK(); FENCE();
+  cyc[1] = t1 - t0;
+  // 8 independent scalar loads, one wait
+  int a[8];
+  FENCE(); t0 = CLK(); FENCE();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = t[(i * 37) & 255];
+  FENCE();
+  int sum = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) sum += a[i];
+  FENCE(); t1 = CLK(); FENCE();
+  cyc[2] = t1 - t0;
+  out[threadIdx.x] = idx + sum;
+}
 int main() {
   double* out;
   unsigned long long* cyc;
@@ -129,5 +159,17 @@ int main() {
                         "dependent v_add_f64 (256)", "dependent v_mul_f64 (256)"};
   const int cnt[] = {256, 256, 256, 64, 64, 64, 32, 64, 1, 256, 256};
   for (int i = 0; i < 11; ++i) printf("%-45s %8llu cycles  = %.1f per item\n", name[i], h[i], (double)h[i] / cnt[i]);
+  {
+    int h_t[256], *d_t, *d_o;
+    for (int i = 0; i < 256; ++i) h_t[i] = (i * 67 + 5) & 255;
+    hipMalloc(&d_t, sizeof(h_t));
+    hipMalloc(&d_o, 64 * sizeof(int));
+    hipMemcpy(d_t, h_t, sizeof(h_t), hipMemcpyHostToDevice);
+    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(probe_sload, dim3(1), dim3(64), 0, 0, d_t, d_o, cyc);
+    hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
+    printf("%-45s %8llu cycles  = %.1f per item\n", "dependent s_load_dword chain (64), first pass", h[0], h[0] / 64.0);
+    printf("%-45s %8llu cycles  = %.1f per item\n", "dependent s_load_dword chain (64), cached", h[1], h[1] / 64.0);
+    printf("%-45s %8llu cycles\n", "8 independent s_loads + one wait", h[2]);
+  }
   return 0;
 }
