@@ -306,7 +306,10 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
 #pragma unroll
           for (int nt = 0; nt < NTQ; ++nt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Q[(16 * mt + 4 * r + lq) * QS + 16 * nt + lj] = accQ[sl][mt][nt][r];
+            for (int r = 0; r < 4; ++r)
+              // only what is read back from LDS: rows < nm of the column tiles that reach column n (Qxu | Quu | Qx, Qu);
+              // the Qxx block stays in the accumulators for the Vxx stage
+              if (16 * nt + 15 >= n && 16 * mt + 4 * r < nm) Q[(16 * mt + 4 * r + lq) * QS + 16 * nt + lj] = accQ[sl][mt][nt][r];
       });
       ex.sync();
       BWD_STAMP(2);
@@ -477,7 +480,8 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
 #pragma unroll
           for (int nt = 0; nt < MTN; ++nt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) W[(16 * mt + 4 * r + lq) * WS + 16 * nt + lj] = accQ[sl][mt][nt][r];
+            for (int r = 0; r < 4; ++r)
+              if (16 * mt + 4 * r < n && 16 * nt < n) W[(16 * mt + 4 * r + lq) * WS + 16 * nt + lj] = accQ[sl][mt][nt][r];
       });
       BWD_STAMP(12);
       ex.sync();
