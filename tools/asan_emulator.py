@@ -24,10 +24,28 @@ L.emu_solve_c.argtypes=[C.c_void_p, C.c_int, C.c_int]
 for rel, dt, it in (("hexacopter370/trajectories/hover.yaml",40,100),("hexacopter370_flying_arm_3/trajectories/displacement.yaml",80,3),("hexacopter370_flying_arm_3/trajectories/eagle_catch.yaml",32,3),("hextilt_flying_arm_5/trajectories/push_slide.yaml",13,2)):
     t = empc.Trajectory(); t.autoSetup(empc.yaml_path(rel)); p = t.createProblem(dt, True, "IntegratedActionModelEuler")
     prm = ob.default_params()
-    for bwd in (3, 2):
-        L.emu_set_backward_version(bwd); L.emu_set_rollout_version(5 if bwd==3 else 1); L.emu_set_linearize_version(2)
+    for bwd, roll in ((4, 6), (3, 5), (2, 1)):  # the shipped forms first, then the cross-check forms
+        L.emu_set_backward_version(bwd); L.emu_set_rollout_version(roll); L.emu_set_linearize_version(2)
         e = C.c_void_p(L.emu_create(C.byref(p.desc), C.byref(prm), 2))
         L.emu_set_warmstart(e, None, None)
         L.emu_solve_c(e, it, 0)
         L.emu_destroy(e)
     print("ok", rel, flush=True)
+# option branches of the shipped forms: box solvers (box-QP gains, clamped rollout), RK4 nodes, the 6D contact with gains
+import pathlib, tempfile
+from conftest import contact_variant
+L.emu_set_backward_version(4); L.emu_set_rollout_version(6); L.emu_set_linearize_version(2)
+t = empc.Trajectory(); t.autoSetup(empc.yaml_path("hexacopter370_flying_arm_3/trajectories/displacement.yaml"))
+for st in (1, 2):
+    p = t.createProblem(80, False, "IntegratedActionModelEuler")
+    prm = ob.default_params(); prm.solver_type = st
+    e = C.c_void_p(L.emu_create(C.byref(p.desc), C.byref(prm), 2)); L.emu_set_warmstart(e, None, None); L.emu_solve_c(e, 4, 0); L.emu_destroy(e)
+    print("ok box solver", st, flush=True)
+p = t.createProblem(80, True, "IntegratedActionModelRK4")
+prm = ob.default_params()
+e = C.c_void_p(L.emu_create(C.byref(p.desc), C.byref(prm), 1)); L.emu_set_warmstart(e, None, None); L.emu_solve_c(e, 2, 0); L.emu_destroy(e)
+print("ok rk4", flush=True)
+with tempfile.TemporaryDirectory() as td:
+    _, p = contact_variant(empc, pathlib.Path(td), "ContactModel6D", (11.0, 5.0))
+    e = C.c_void_p(L.emu_create(C.byref(p.desc), C.byref(prm), 1)); L.emu_set_warmstart(e, None, None); L.emu_solve_c(e, 2, 0); L.emu_destroy(e)
+    print("ok 6D contact", flush=True)
