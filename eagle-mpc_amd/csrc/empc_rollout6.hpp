@@ -571,8 +571,19 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
       double x[NX], a[NV], lam[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
       for (int i = 0; i < NX; ++i) x[i] = XT[i * NL + lane];
+      {
+        // both operands of every row requested before the first subtraction (the compiler otherwise pairs each read with
+        // its own wait: one exposed LDS round trip per row on the critical path of the knot)
+        double tv[NV], hv[NV];
 #pragma unroll
-      for (int i = 0; i < NV; ++i) a[i] = TAU[i * NL + lane] - HB[i * NL + lane];
+        for (int i = 0; i < NV; ++i) {
+          tv[i] = TAU[i * NL + lane];
+          hv[i] = HB[i * NL + lane];
+        }
+        R6_SCHED_FENCE();
+#pragma unroll
+        for (int i = 0; i < NV; ++i) a[i] = tv[i] - hv[i];
+      }
       chol_solve_packed<NV>(Lc[sl], a);
       if constexpr (CT) {
         if (use_contact) {
