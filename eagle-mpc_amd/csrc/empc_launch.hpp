@@ -116,7 +116,10 @@ template <class DM, int CT, int LPU, int BLK, bool FR>
 #ifndef EMPC_LIN_WAVES
 #define EMPC_LIN_WAVES 2
 #endif
-__global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(DM::NV > 9 ? 1 : EMPC_LIN_WAVES, DM::NV > 9 ? 1 : EMPC_LIN_WAVES)))
+#ifndef EMPC_LIN_WAVES_BIG
+#define EMPC_LIN_WAVES_BIG 1
+#endif
+__global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(DM::NV > 9 ? EMPC_LIN_WAVES_BIG : EMPC_LIN_WAVES, DM::NV > 9 ? EMPC_LIN_WAVES_BIG : EMPC_LIN_WAVES)))
 k_linearize(DevBuffers D) {
   extern __shared__ double smem_lin[];
   constexpr int UPB = BLK / LPU;  // units per block
