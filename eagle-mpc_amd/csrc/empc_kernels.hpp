@@ -477,15 +477,12 @@ EMPC_HD void rollout_wave5(Exec& ex, const DevBuffers& D, int b, int nl, double*
 // select: one trajectory; the serial decision logic of solveFDDP / solveDDP / solve after the trial rollouts.
 // `tid`/`nthreads` cooperate on the candidate copy; all threads must call it.
 // =====================================================================================================================
-template <class DM>
-EMPC_HD void select_decide(const DevBuffers& D, int b, int& accepted_ai, int& last_ai) {
-  TrajState& st = D.st[b];
+template <int NAMAX>
+EMPC_HD void select_decide_state(const DevBuffers& D, int b, TrajState& st, const int* try_ok_v, const double* try_cost_v,
+                                 const double* try_dv_v, int& accepted_ai, int& last_ai) {
   const EMPC_K DevProblem& P = EMPC_KREF(DevProblem, D.P);
   const EMPC_K EmpcSolverParams& prm = P.prm;
   const int NA = D.NA;
-  accepted_ai = -1;
-  last_ai = -1;
-  if (st.phase == PHASE_DONE) return;
   const bool ddp = (st.phase == PHASE_DDP);
   bool phase_end = false, returned = false;
   if (st.bwd_failed) {
@@ -499,15 +496,16 @@ EMPC_HD void select_decide(const DevBuffers& D, int b, int& accepted_ai, int& la
       st.d0 = st.dg_u;
       st.d1 = st.dq_u;
     }
-    for (int ai = 0; ai < NA; ++ai) {
+#pragma unroll
+    for (int ai = 0; ai < NAMAX; ++ai) {
+      if (ai >= NA) break;
       const double alpha = ldexp(1.0, -ai);
       st.steplength = alpha;
       last_ai = ai;
-      const size_t slot = (size_t)b * NA + ai;
-      if (!D.try_ok[slot]) continue;  // "forward_error"
-      st.dV = st.cost - D.try_cost[slot];
+      if (!try_ok_v[ai]) continue;  // "forward_error"
+      st.dV = st.cost - try_cost_v[ai];
       if (!ddp) {
-        const double dv = st.is_feasible ? 0.0 : D.try_dv[slot];
+        const double dv = st.is_feasible ? 0.0 : try_dv_v[ai];
         const double dg = st.dg_u + (st.is_feasible ? 0.0 : st.dg_f);
         const double dq = st.dq_u + (st.is_feasible ? 0.0 : st.dq_f);
         st.d0 = dg + dv;
@@ -530,7 +528,7 @@ EMPC_HD void select_decide(const DevBuffers& D, int b, int& accepted_ai, int& la
         st.was_feasible = st.is_feasible;
         st.is_feasible = ddp ? 1 : ((st.was_feasible || alpha == 1.0) ? 1 : 0);
         st.cost_prev = st.cost;
-        st.cost = D.try_cost[slot];
+        st.cost = try_cost_v[ai];
         st.need_lin = 1;
         accepted_ai = ai;
         break;
@@ -640,6 +638,31 @@ EMPC_HD void select_decide(const DevBuffers& D, int b, int& accepted_ai, int& la
     }
   }
   st.bwd_failed = 0;
+}
+
+template <class DM>
+EMPC_HD void select_decide(const DevBuffers& D, int b, int& accepted_ai, int& last_ai) {
+  const EMPC_K DevProblem& P = EMPC_KREF(DevProblem, D.P);
+  const EMPC_K EmpcSolverParams& prm = P.prm;
+  const int NA = D.NA;
+  accepted_ai = -1;
+  last_ai = -1;
+  if (D.st[b].phase == PHASE_DONE) return;
+  // The state machine runs on a register copy of the trajectory's state and on the trial results fetched in one batch:
+  // one thread walking `D.st[b].field` and `D.try_*[slot]` in place pays a memory round trip per step of the walk (the
+  // floor of this kernel when few trajectories are left).
+  TrajState st = D.st[b];
+  int try_ok_v[MAX_ALPHAS];
+  double try_cost_v[MAX_ALPHAS], try_dv_v[MAX_ALPHAS];
+#pragma unroll
+  for (int ai = 0; ai < MAX_ALPHAS; ++ai) {
+    const size_t slot = (size_t)b * NA + (ai < NA ? ai : 0);
+    try_ok_v[ai] = D.try_ok[slot];
+    try_cost_v[ai] = D.try_cost[slot];
+    try_dv_v[ai] = D.try_dv[slot];
+  }
+  select_decide_state<MAX_ALPHAS>(D, b, st, try_ok_v, try_cost_v, try_dv_v, accepted_ai, last_ai);
+  D.st[b] = st;
 }
 
 // copy helper used by select: candidate <- trial slot `ai` (xs, us, acc); threads cooperate
