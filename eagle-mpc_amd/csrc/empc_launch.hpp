@@ -119,9 +119,7 @@ template <class DM, int CT, int LPU, int BLK, bool FR>
 #ifndef EMPC_LIN_WAVES_BIG
 #define EMPC_LIN_WAVES_BIG 1
 #endif
-__global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(DM::NV > 9 ? EMPC_LIN_WAVES_BIG : EMPC_LIN_WAVES, DM::NV > 9 ? EMPC_LIN_WAVES_BIG : EMPC_LIN_WAVES)))
-k_linearize(DevBuffers D) {
-  extern __shared__ double smem_lin[];
+__device__ __forceinline__ void lin_block(const DevBuffers& D, const int block, double* smem_lin) {
   constexpr int UPB = BLK / LPU;  // units per block
   constexpr int USZ = Lin2Smem<DM>::size_for(CT);
 #ifdef EMPC_LIN_NO_ROLES
@@ -132,10 +130,10 @@ k_linearize(DevBuffers D) {
   // this body's knots: the lean group or the rest of the sorted knot list; a block holds UPB trajectories of ONE knot
   const int k0 = FR ? D.n_lean : 0, nk = FR ? (D.T + 1 - D.n_lean) : D.n_lean;
   const int bpk = ((D.lin_bound > 0 ? D.lin_bound : D.B) + UPB - 1) / UPB;
-  const int kn = blockIdx.x / bpk;
+  const int kn = block / bpk;
   if (kn >= nk) return;
   const int t = EMPC_KPTR(int, D.lin_knots)[k0 + kn];
-  const int i0 = (blockIdx.x % bpk) * UPB;  // position in the list of trajectories that linearize in this sweep
+  const int i0 = (block % bpk) * UPB;  // position in the list of trajectories that linearize in this sweep
   const int nlist = D.lin_list ? *D.lin_count : D.B;
   if (i0 >= nlist) return;
   const int u = threadIdx.x / LPU, lane = threadIdx.x % LPU;
@@ -154,6 +152,23 @@ k_linearize(DevBuffers D) {
     if (!active) return;
     linearize_unit2<DM, CT, FR>(ex, D, b, t, LPU, smem_lin + (size_t)u * USZ);
   }
+}
+#define EMPC_LIN_ATTR __attribute__((amdgpu_waves_per_eu(DM::NV > 9 ? EMPC_LIN_WAVES_BIG : EMPC_LIN_WAVES, DM::NV > 9 ? EMPC_LIN_WAVES_BIG : EMPC_LIN_WAVES)))
+template <class DM, int CT, int LPU, int BLK, bool FR>
+__global__ void __launch_bounds__(BLK) EMPC_LIN_ATTR k_linearize(DevBuffers D) {
+  extern __shared__ double smem_lin[];
+  lin_block<DM, CT, LPU, BLK, FR>(D, blockIdx.x, smem_lin);
+}
+// Both bodies in one launch: the first `n_lean_blocks` workgroups run the lean body over the knots without operational
+// frames, the rest the full body over the other knots.  One launch instead of two: the short full-body launch no longer
+// waits for the last lean workgroup (straggler sweeps: two unit latencies per sweep become one).
+template <class DM, int CT, int LPU, int BLK>
+__global__ void __launch_bounds__(BLK) EMPC_LIN_ATTR k_linearize_all(DevBuffers D, int n_lean_blocks) {
+  extern __shared__ double smem_lin[];
+  if ((int)blockIdx.x < n_lean_blocks)
+    lin_block<DM, CT, LPU, BLK, false>(D, blockIdx.x, smem_lin);
+  else
+    lin_block<DM, CT, LPU, BLK, true>(D, blockIdx.x - n_lean_blocks, smem_lin);
 }
 
 // workgroup-wide executor: barriers are real workgroup barriers
@@ -342,6 +357,18 @@ static void launch_linearize_blk(DevBuffers D, hipStream_t s) {
   // B / UPB per knot that return at once
   const int bpk = ((D.lin_bound > 0 ? D.lin_bound : D.B) + UPB - 1) / UPB;
   const int n_lean = bpk * D.n_lean, n_full = bpk * (D.T + 1 - D.n_lean);
+  static const bool merged = [] {
+    const char* e = getenv("EMPC_LIN_MERGED");  // 0 = one launch per body (the earlier form)
+    return e ? atoi(e) != 0 : true;
+  }();
+  if constexpr (BLK == 256) {
+    // only when few trajectories are left (a full batch is better served by the two separately compiled bodies:
+    // displacement 0.665 vs 0.690 ms per sweep), where the second launch is mostly latency
+    if (merged && n_lean > 0 && n_full > 0 && D.lin_bound > 0 && 2 * D.lin_bound <= D.B) {
+      hipLaunchKernelGGL((k_linearize_all<DM, CT, LPU, BLK>), dim3(n_lean + n_full), dim3(BLK), smem, s, D, n_lean);
+      return;
+    }
+  }
   if (n_lean > 0) hipLaunchKernelGGL((k_linearize<DM, CT, LPU, BLK, false>), dim3(n_lean), dim3(BLK), smem, s, D);
   if (n_full > 0) hipLaunchKernelGGL((k_linearize<DM, CT, LPU, BLK, true>), dim3(n_full), dim3(BLK), smem, s, D);
 }

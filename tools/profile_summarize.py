@@ -15,11 +15,13 @@ import json
 import os
 import sys
 
-KERNELS = ("k_linearize_full", "k_linearize", "k_backward", "k_rollout", "k_select", "k_calc", "k_squash_out", "k_plant_rk4", "k_pack_rows")
+KERNELS = ("k_linearize_all", "k_linearize_full", "k_linearize", "k_backward", "k_rollout", "k_select", "k_calc", "k_squash_out", "k_plant_rk4", "k_pack_rows")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def short(name):
+    if "k_linearize_all" in name:  # both bodies in one launch (sweeps with less than half of the batch active)
+        return "k_linearize_all"
     if "k_linearize" in name:  # two bodies per sweep: lean (no operational frames) and full
         return "k_linearize_full" if "true>(" in name.replace(" ", "") else "k_linearize"
     for k in KERNELS:
@@ -57,10 +59,13 @@ def counters(src, counter):
 def traffic(fetch_dir, write_dir, tag, config="displacement"):
     fe = counters(fetch_dir, "FETCH_SIZE")
     wr = counters(write_dir, "WRITE_SIZE")
-    if "k_linearize_full" in fe and "k_linearize_full" in wr:  # one linearize step of a sweep = both bodies
-        n = min(len(fe["k_linearize"]), len(fe["k_linearize_full"]), len(wr["k_linearize"]), len(wr["k_linearize_full"]))
-        fe["k_linearize"] = [a + b for a, b in zip(fe["k_linearize"][:n], fe["k_linearize_full"][:n])]
-        wr["k_linearize"] = [a + b for a, b in zip(wr["k_linearize"][:n], wr["k_linearize_full"][:n])]
+    # one linearize step of a sweep = both bodies (two launches, or one k_linearize_all launch): total bytes of all
+    # linearize launches spread over the sweeps of the run (= backward launches)
+    if "k_backward" in fe and "k_backward" in wr:
+        ns = len(fe["k_backward"])
+        for tab in (fe, wr):
+            tot = sum(tab.get("k_linearize", [])) + sum(tab.get("k_linearize_full", [])) + sum(tab.get("k_linearize_all", []))
+            tab["k_linearize"] = [tot / ns] * ns
     for k in ("k_linearize", "k_backward", "k_rollout"):
         if k not in fe or k not in wr:
             continue
