@@ -496,13 +496,15 @@ EMPC_HD void select_decide_state(const DevBuffers& D, int b, TrajState& st, cons
       st.d0 = st.dg_u;
       st.d1 = st.dq_u;
     }
+    // (no break / continue: the loop unrolls, so the register copies of the trial results are indexed at compile time)
+    bool searching = true;
 #pragma unroll
     for (int ai = 0; ai < NAMAX; ++ai) {
-      if (ai >= NA) break;
+      if (!(searching && ai < NA)) continue;
       const double alpha = ldexp(1.0, -ai);
       st.steplength = alpha;
       last_ai = ai;
-      if (!try_ok_v[ai]) continue;  // "forward_error"
+      if (try_ok_v[ai]) {  // else "forward_error": next step length
       st.dV = st.cost - try_cost_v[ai];
       if (!ddp) {
         const double dv = st.is_feasible ? 0.0 : try_dv_v[ai];
@@ -531,7 +533,8 @@ EMPC_HD void select_decide_state(const DevBuffers& D, int b, TrajState& st, cons
         st.cost = try_cost_v[ai];
         st.need_lin = 1;
         accepted_ai = ai;
-        break;
+        searching = false;
+      }
       }
     }
     if (st.steplength > prm.th_stepdec) {
