@@ -12,7 +12,7 @@ import empc_loader, oracle_binding as ob
 empc = empc_loader.load()
 CONFIGS = {"displacement": ("hexacopter370_flying_arm_3/trajectories/displacement.yaml", 80, 1024),
            "push_slide": ("hextilt_flying_arm_5/trajectories/push_slide.yaml", 13, 1024),
-           "eagle_catch": ("hexacopter370_flying_arm_3/trajectories/eagle_catch.yaml", 32, 256),
+           "eagle_catch": ("hexacopter370_flying_arm_3/trajectories/eagle_catch.yaml", 32, 1024),
            "hover": ("hexacopter370/trajectories/hover.yaml", 40, 256)}
 out = {}
 for name, (rel, dt, B) in CONFIGS.items():
@@ -22,7 +22,7 @@ for name, (rel, dt, B) in CONFIGS.items():
     s = empc.SolverSbFDDP(p, batch=B)
     s.solve([], [], 100, x0s=x0s)
     t0 = time.time()
-    r = ob.solve_batch(d, x0s, 100, nthreads=os.cpu_count(), want_traj=True)
+    r = ob.solve_batch(d, x0s, 100, nthreads=min(os.cpu_count(), len(os.sched_getaffinity(0)), 16), want_traj=True)
     same = s.iter_batch == r["iter"]
     ex = np.abs(s.xs_batch - r["xs"]).reshape(B, -1).max(axis=1)
     eu = np.abs(s.us_batch - r["us"]).reshape(B, -1).max(axis=1)
