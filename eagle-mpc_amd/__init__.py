@@ -92,6 +92,17 @@ def lib():
     L.empc_linearize_batch.argtypes = [C.c_void_p, _dp, _dp, C.c_double, C.c_int, _dp, _dp, _dp]
     L.empc_backward_batch.argtypes = [C.c_void_p, C.c_double, C.c_int, _dp, _dp, _dp, _dp, _ip]
     L.empc_rollout_batch.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int, _dp, _dp, _dp, _ip]
+    L.empc_solver_get_states.argtypes = [C.c_void_p, C.POINTER(T.TrajState)]
+    L.empc_solver_set_states.argtypes = [C.c_void_p, C.POINTER(T.TrajState)]
+    L.empc_sweep_batch.argtypes = [C.c_void_p, C.c_int]
+    L.empc_select_batch.argtypes = [C.c_void_p, _ip, _dp, _dp]
+    L.empc_solver_get_trials.argtypes = [C.c_void_p, _dp, _dp, _ip]
+    L.empc_solver_get_tape.argtypes = [C.c_void_p, _dp]
+    L.empc_solver_get_gains.argtypes = [C.c_void_p, _dp, _dp, _dp]
+    L.empc_solver_set_gains.argtypes = [C.c_void_p, _dp, _dp]
+    L.empc_solver_stream_begin.argtypes = [C.c_void_p, C.c_int, _dp]
+    L.empc_solver_stream_run.argtypes = [C.c_void_p, C.c_int]
+    L.empc_solver_stream_results.argtypes = [C.c_void_p, _dp, _ip]
     L.empc_plant_set_state.argtypes = [C.c_void_p, _dp]
     L.empc_plant_get_state.argtypes = [C.c_void_p, _dp]
     L.empc_plant_step.argtypes = [C.c_void_p, C.c_double, _dp, C.c_int]
@@ -495,6 +506,92 @@ class SolverSbFDDP:
         _check(lib().empc_rollout_batch(self._h, float(alpha), int(ddp), int(is_feasible), _ptr(xs), _ptr(us), _ptr(cost),
                                         _ptr(ok, np.int32)))
         return xs, us, cost, ok
+
+    # -- step-wise entry points: one iteration from any iterate (teacher-forced parity) ----------------------
+    def get_states(self):
+        """the solver scalars of every trajectory (array of ctypes_defs.TrajState)"""
+        st = (T.TrajState * self.batch)()
+        _check(lib().empc_solver_get_states(self._h, st))
+        return st
+
+    def set_states(self, states):
+        assert len(states) == self.batch
+        _check(lib().empc_solver_set_states(self._h, states))
+
+    def set_x0s(self, x0s):
+        x0s = np.ascontiguousarray(x0s, dtype=np.float64).reshape(self.batch, self.nx)
+        _check(lib().empc_solver_set_x0(self._h, _ptr(x0s)))
+
+    def set_candidates(self, xs, us):
+        xs = np.ascontiguousarray(xs, dtype=np.float64).reshape(self.batch, self.T + 1, self.nx)
+        us = np.ascontiguousarray(us, dtype=np.float64).reshape(self.batch, self.T, self.nu)
+        _check(lib().empc_solver_set_warmstart(self._h, _ptr(xs), _ptr(us)))
+
+    def sweep(self, stages=T.STAGE_ALL):
+        """run the named stages of ONE iteration (linearize, backward, rollout, select) over the batch from the current
+        candidates and scalars"""
+        _check(lib().empc_sweep_batch(self._h, int(stages)))
+
+    def select(self, try_ok=None, try_cost=None, try_dv=None):
+        """the line-search decision alone, on trial results given here (batch x n_alphas) or left by the last rollout"""
+        def arr(a, dt):
+            return None if a is None else np.ascontiguousarray(a, dtype=dt).reshape(self.batch, self._n_alphas)
+        ok, c, dv = arr(try_ok, np.int32), arr(try_cost, np.float64), arr(try_dv, np.float64)
+        _check(lib().empc_select_batch(self._h, _ptr(ok, np.int32), _ptr(c), _ptr(dv)))
+
+    def trials(self):
+        """(cost_try, dv, ok) of every step length from the last rollout, each batch x n_alphas"""
+        c = np.zeros((self.batch, self._n_alphas))
+        dv = np.zeros((self.batch, self._n_alphas))
+        ok = np.zeros((self.batch, self._n_alphas), dtype=np.int32)
+        _check(lib().empc_solver_get_trials(self._h, _ptr(c), _ptr(dv), _ptr(ok, np.int32)))
+        return c, dv, ok
+
+    def tape(self):
+        t = np.zeros((self.batch, self.T + 1, self.rec))
+        _check(lib().empc_solver_get_tape(self._h, _ptr(t)))
+        return t
+
+    def gains(self):
+        K = np.zeros((self.batch, self.T, self.nu, self.ndx))
+        k = np.zeros((self.batch, self.T, self.nu))
+        Vx = np.zeros((self.batch, self.T + 1, self.ndx))
+        _check(lib().empc_solver_get_gains(self._h, _ptr(K), _ptr(k), _ptr(Vx)))
+        return K, k, Vx
+
+    def set_gains(self, K=None, k=None):
+        K = None if K is None else np.ascontiguousarray(K, dtype=np.float64).reshape(self.batch, self.T, self.nu, self.ndx)
+        k = None if k is None else np.ascontiguousarray(k, dtype=np.float64).reshape(self.batch, self.T, self.nu)
+        _check(lib().empc_solver_set_gains(self._h, _ptr(K), _ptr(k)))
+
+    # -- streamed solves ("continuous batching") ----------------------------------------------------------------
+    def stream_begin(self, x0s):
+        """queue of initial states (n_jobs x nx) for solve_stream: copied to the device, result rows allocated there"""
+        x0s = np.ascontiguousarray(x0s, dtype=np.float64).reshape(-1, self.nx)
+        _check(lib().empc_solver_stream_begin(self._h, x0s.shape[0], _ptr(x0s)))
+        self._stream_jobs = x0s.shape[0]
+
+    def stream_run(self, maxiter=100):
+        """solve([], [], maxiter) for every queued initial state through the solver's `batch` slots: a slot that finishes
+        takes the next job in the same sweep, so the batch stays full until the queue is dry"""
+        _check(lib().empc_solver_stream_run(self._h, int(maxiter)))
+
+    def stream_results(self):
+        """dict of per-job results: xs, us, us_squash, cost, iter, status"""
+        n = C.c_int()
+        _check(lib().empc_solver_stream_results(self._h, None, C.byref(n)))
+        rows = np.zeros((self._stream_jobs, n.value))
+        _check(lib().empc_solver_stream_results(self._h, _ptr(rows), C.byref(n)))
+        T_, nx, nu = self.T, self.nx, self.nu
+        nxs, nus = (T_ + 1) * nx, T_ * nu
+        return dict(xs=rows[:, :nxs].reshape(-1, T_ + 1, nx).copy(), us=rows[:, nxs:nxs + nus].reshape(-1, T_, nu).copy(),
+                    us_squash=rows[:, nxs + nus:nxs + 2 * nus].reshape(-1, T_, nu).copy(), cost=rows[:, nxs + 2 * nus].copy(),
+                    iter=rows[:, nxs + 2 * nus + 1].astype(np.int32), status=rows[:, nxs + 2 * nus + 2].astype(np.int32))
+
+    def solve_stream(self, x0s, maxiter=100):
+        self.stream_begin(x0s)
+        self.stream_run(maxiter)
+        return self.stream_results()
 
     def __del__(self):
         try:

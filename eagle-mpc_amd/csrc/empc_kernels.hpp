@@ -22,18 +22,8 @@ constexpr int PHASE_DDP = 100;
 constexpr int PHASE_DONE = 255;
 constexpr int MAX_ALPHAS = 16;
 
-struct TrajState {
-  int phase;  // 0.. : FDDP pass index; PHASE_DDP; PHASE_DONE
-  int iter, total_iters, status;
-  int is_feasible, was_feasible;
-  int need_calc, need_lin;
-  int maxiter, bwd_failed, trace_count, last_ok;  // trace_count: iteration records written in this solve
-  double smooth, smooth_next, convergence, th_stop;
-  double xreg, ureg, cost, cost_prev, stop, steplength, dV, dVexp, d0, d1;
-  double dg_u, dq_u;      // sum Qu.k , -sum k.Quuk          (control part)
-  double dg_f, dq_f;      // -sum Vx.f , +sum f.Vxx f         (gap part, valid when infeasible)
-  double gapnorm, qu2;
-};
+// the per-trajectory solver scalars are part of the C ABI (step-wise entry points): include/empc_types.h
+typedef EmpcTrajState TrajState;
 
 // Per-cost-set work lists, built once on the host (prepare_problem) so that the kernels walk only the costs a stage needs
 // instead of scanning the whole table with dependent scalar loads: indices into EmpcCostSet::costs, active costs only,
@@ -96,6 +86,13 @@ struct DevBuffers {
   // records of EMPC_TRACE_WORDS doubles per trajectory, written by select; nullptr = off
   double* trace = nullptr;  // [B][trace_cap][EMPC_TRACE_WORDS]
   int trace_cap = 0;
+  // streamed solves (empc_solver_stream_*): queue of initial states and the result rows, both resident on the device; a
+  // trajectory that finishes hands its row over and its slot takes the next job inside select.  nullptr = plain solve.
+  const double* q_x0 = nullptr;            // [q_njobs][NX]
+  double* q_rows = nullptr;                // [q_njobs][(T+1) NX + 2 T NU + 3]: xs | us | us_squash | cost | iters | status
+  int* q_head = nullptr;                   // next job to hand out
+  unsigned long long* q_iters = nullptr;   // DDP iterations of the finished jobs, summed
+  int q_njobs = 0, q_maxiter = 0;
   int B, T, NA;
   int integrator = 0;  // EmpcIntegrator of the problem (host copy: selects the kernel forms that support it)
   int solver_type = 0; // EmpcSolverType (host copy): the box solvers need the kernel forms that implement them
@@ -473,6 +470,48 @@ EMPC_HD void rollout_wave5(Exec& ex, const DevBuffers& D, int b, int nl, double*
   });
 }
 
+// State of one trajectory at the start of SolverSbFDDP::solve (src/sbfddp.cpp:198-210).  `prev` carries the members that
+// the reference keeps across solve() calls on one solver object (cost_, cost_prev_, stop_); nullptr = a fresh solver.
+template <class PrmT>
+EMPC_HD void traj_state_init(TrajState& s, const PrmT& prm, int maxiter, bool is_feasible_arg, const TrajState* prev) {
+  TrajState z;
+  z.phase = z.iter = z.total_iters = z.status = z.is_feasible = z.was_feasible = 0;
+  z.bwd_failed = z.trace_count = z.last_ok = z.reserved = 0;
+  z.accepted_alpha = z.last_alpha = -1;
+  z.job = -1;
+  z.cost = prev ? prev->cost : 0.0;
+  z.cost_prev = prev ? prev->cost_prev : 0.0;
+  z.stop = prev ? prev->stop : 0.0;
+  z.gapnorm = prev ? prev->gapnorm : 0.0;
+  z.dV = z.dVexp = z.d0 = z.d1 = z.dg_u = z.dq_u = z.dg_f = z.dq_f = z.qu2 = 0.0;
+  z.maxiter = maxiter;
+  z.smooth = z.smooth_next = prm.smooth_init;
+  z.convergence = prm.convergence_init;
+  z.th_stop = prm.convergence_init;
+  z.xreg = z.ureg = prm.reg_init;
+  z.steplength = 1.0;
+  z.need_calc = 1;
+  z.need_lin = 1;
+  if (prm.solver_type != EMPC_SOLVER_SBFDDP) {
+    // crocoddyl::SolverBoxFDDP / SolverBoxDDP::solve: one loop from the candidate's feasibility flag, th_stop_ = 5e-5
+    z.phase = (prm.solver_type == EMPC_SOLVER_BOXDDP) ? PHASE_DDP : 0;
+    z.is_feasible = is_feasible_arg ? 1 : 0;
+    z.th_stop = prm.box_th_stop;
+  } else if (prm.convergence_init >= prm.convergence_stop) {
+    z.phase = 0;
+    z.is_feasible = 0;  // solveFDDP(maxiter, false, reg_init_)
+  } else if (!is_feasible_arg) {
+    z.phase = PHASE_DDP;
+    z.is_feasible = 0;
+    z.status |= EMPC_STATUS_DDP_CLEANUP;
+  } else {
+    z.phase = PHASE_DONE;
+    z.is_feasible = 1;
+    z.iter = -1;
+  }
+  s = z;
+}
+
 // =====================================================================================================================
 // select: one trajectory; the serial decision logic of solveFDDP / solveDDP / solve after the trial rollouts.
 // `tid`/`nthreads` cooperate on the candidate copy; all threads must call it.
@@ -665,6 +704,8 @@ EMPC_HD void select_decide(const DevBuffers& D, int b, int& accepted_ai, int& la
     try_dv_v[ai] = D.try_dv[slot];
   }
   select_decide_state<MAX_ALPHAS>(D, b, st, try_ok_v, try_cost_v, try_dv_v, accepted_ai, last_ai);
+  st.accepted_alpha = accepted_ai;
+  st.last_alpha = last_ai;
   D.st[b] = st;
 }
 
@@ -691,6 +732,53 @@ EMPC_HD void select_copy(const DevBuffers& D, int b, int accepted_ai, int last_a
     double* ul = D.us_last + (size_t)b * T * DM::NU;
     for (int i = tid; i < T * DM::NU; i += nthreads) ul[i] = us_i[i];
   }
+}
+
+// ---- streamed solves: hand-over of a finished trajectory's slot (called by select; threads cooperate) -------------------
+template <class DM>
+EMPC_HD size_t stream_row_doubles(int T) {
+  return (size_t)(T + 1) * DM::NX + 2 * (size_t)T * DM::NU + 3;
+}
+// result row of the job in slot b: xs | us | us_squash | cost | iters | status (us_squash: fillSquashedOutputs semantics,
+// the squashed control of the LAST calc at every node, as empc_solver_get_us_squash reports it)
+template <class DM>
+EMPC_HD void stream_write_row(const DevBuffers& D, int b, int tid, int nthreads) {
+  const EMPC_K DevProblem& P = EMPC_KREF(DevProblem, D.P);
+  const TrajState& st = D.st[b];
+  const int T = D.T;
+  const size_t nxs = (size_t)(T + 1) * DM::NX, nus = (size_t)T * DM::NU;
+  double* row = D.q_rows + (size_t)st.job * stream_row_doubles<DM>(T);
+  const double* xs = D.xs + (size_t)b * nxs;
+  const double* us = D.us + (size_t)b * nus;
+  const double* ul = D.us_last + (size_t)b * nus;
+  for (size_t i = tid; i < nxs; i += nthreads) row[i] = xs[i];
+  for (size_t i = tid; i < nus; i += nthreads) {
+    row[nxs + i] = us[i];
+    double u = us[i], du;
+    const int c = (int)(i % DM::NU);
+    if (P.use_squash) squash1(ul[i], P.u_lb[c], P.u_ub[c], st.smooth, P.prm.smoothsat_power, u, du);
+    row[nxs + nus + i] = u;
+  }
+  if (tid == 0) {
+    row[nxs + 2 * nus] = st.cost;
+    row[nxs + 2 * nus + 1] = (double)st.iter;
+    row[nxs + 2 * nus + 2] = (double)st.status;
+  }
+}
+// the slot takes job `job`: setCandidate([], []) (zero state at every node, zero controls), problem.x0 = the job's state
+template <class DM>
+EMPC_HD void stream_refill(const DevBuffers& D, int b, int job, int tid, int nthreads) {
+  const int T = D.T;
+  const size_t nxs = (size_t)(T + 1) * DM::NX, nus = (size_t)T * DM::NU;
+  double* xs = D.xs + (size_t)b * nxs;
+  double* us = D.us + (size_t)b * nus;
+  double* kf = D.kff + (size_t)b * nus;
+  for (size_t i = tid; i < nxs; i += nthreads) xs[i] = ((i % DM::NX) == 6) ? 1.0 : 0.0;
+  for (size_t i = tid; i < nus; i += nthreads) {
+    us[i] = 0.0;
+    kf[i] = 0.0;  // warm start of the box QPs (a fresh solver's k_)
+  }
+  for (int i = tid; i < DM::NX; i += nthreads) D.x0[(size_t)b * DM::NX + i] = D.q_x0[(size_t)job * DM::NX + i];
 }
 
 }  // namespace empc

@@ -229,7 +229,7 @@ __global__ void __launch_bounds__(64) k_backward4(DevBuffers D) {
 
 template <class DM>
 __global__ void __launch_bounds__(64) k_select(DevBuffers D) {
-  __shared__ int sh[2];
+  __shared__ int sh[3];
   const int b = blockIdx.x;
   if (threadIdx.x == 0) {
     if (b == 0 && D.counters_next) {  // every reader of the other slot's counters ran before this kernel
@@ -240,20 +240,43 @@ __global__ void __launch_bounds__(64) k_select(DevBuffers D) {
     select_decide<DM>(D, b, acc_ai, last_ai);
     sh[0] = acc_ai;
     sh[1] = last_ai;
+  }
+  __syncthreads();
+  select_copy<DM>(D, b, sh[0], sh[1], threadIdx.x, blockDim.x);
+  if (D.q_rows) {
+    // streamed solves: a trajectory that has just finished hands its row over and the slot takes the next job of the queue
+    // (the whole workgroup sees the same state: it was written before the barrier above)
+    TrajState& st = D.st[b];
+    if (st.phase == PHASE_DONE && st.job >= 0) {
+      __syncthreads();  // the accepted candidate is complete in global memory
+      stream_write_row<DM>(D, b, threadIdx.x, blockDim.x);
+      if (threadIdx.x == 0) {
+        atomicAdd(D.q_iters, (unsigned long long)st.total_iters);
+        const int j = atomicAdd(D.q_head, 1);
+        sh[2] = j < D.q_njobs ? j : -1;
+      }
+      __syncthreads();  // the row is out; the next job is known to everybody
+      const int job = sh[2];
+      if (job >= 0) stream_refill<DM>(D, b, job, threadIdx.x, blockDim.x);
+      if (threadIdx.x == 0) {
+        if (job >= 0) traj_state_init(st, EMPC_KREF(DevProblem, D.P).prm, D.q_maxiter, false, (const TrajState*)nullptr);
+        st.job = job;
+      }
+    }
+  }
+  if (threadIdx.x == 0) {
     if (D.st[b].phase != PHASE_DONE) {
       const int pos = atomicAdd(D.n_active, 1);
       if (D.act_list_out) D.act_list_out[pos] = b;
       if (D.lin_count_out && D.st[b].need_lin) D.lin_list_out[atomicAdd(D.lin_count_out, 1)] = b;
     }
-  }
-  __syncthreads();
-  select_copy<DM>(D, b, sh[0], sh[1], threadIdx.x, blockDim.x);
-  if (threadIdx.x == 0 && D.host_active) {
-    __threadfence();
-    if (atomicAdd(D.done_ticket, 1) == (int)gridDim.x - 1) {  // last workgroup: all counts are in
-      *D.host_active = atomicAdd(D.n_active, 0);
-      *D.done_ticket = 0;
-      __threadfence_system();
+    if (D.host_active) {
+      __threadfence();
+      if (atomicAdd(D.done_ticket, 1) == (int)gridDim.x - 1) {  // last workgroup: all counts are in
+        *D.host_active = atomicAdd(D.n_active, 0);
+        *D.done_ticket = 0;
+        __threadfence_system();
+      }
     }
   }
 }

@@ -61,6 +61,7 @@ inline void prepare_problem(const EmpcProblemDesc& d, const EmpcSolverParams& pr
   if (d.nu > m.nv) throw std::runtime_error("more controls than velocity dimensions is not supported by the kernels");
   if (prm.n_alphas < 1 || prm.n_alphas > MAX_ALPHAS) throw std::invalid_argument("n_alphas out of range");
   std::memset(&H.P, 0, sizeof(H.P));
+  H.contact_rows = 0;
   H.P.model = m;
   H.P.nx = d.nx;
   H.P.ndx = d.ndx;
@@ -212,42 +213,6 @@ inline int group_linearize_knots(const HostProblem& H, std::vector<int>& order) 
 
 inline void init_traj_state(TrajState& s, const EmpcSolverParams& prm, int maxiter, bool is_feasible_arg,
                             const TrajState* prev) {
-  TrajState z;
-  std::memset(&z, 0, sizeof(z));
-  if (prev) {
-    z.cost = prev->cost;
-    z.cost_prev = prev->cost_prev;
-    z.stop = prev->stop;
-    z.gapnorm = prev->gapnorm;
-  }
-  z.maxiter = maxiter;
-  z.smooth = z.smooth_next = prm.smooth_init;
-  z.convergence = prm.convergence_init;
-  z.th_stop = prm.convergence_init;
-  z.xreg = z.ureg = prm.reg_init;
-  z.steplength = 1.0;
-  z.need_calc = 1;
-  z.need_lin = 1;
-  if (prm.solver_type != EMPC_SOLVER_SBFDDP) {
-    // crocoddyl::SolverBoxFDDP / SolverBoxDDP::solve: one loop from the candidate's feasibility flag, th_stop_ = 5e-5
-    z.phase = (prm.solver_type == EMPC_SOLVER_BOXDDP) ? PHASE_DDP : 0;
-    z.is_feasible = is_feasible_arg ? 1 : 0;
-    z.th_stop = prm.box_th_stop;
-    s = z;
-    return;
-  }
-  if (prm.convergence_init >= prm.convergence_stop) {
-    z.phase = 0;
-    z.is_feasible = 0;  // solveFDDP(maxiter, false, reg_init_)
-  } else if (!is_feasible_arg) {
-    z.phase = PHASE_DDP;
-    z.is_feasible = 0;
-    z.status |= EMPC_STATUS_DDP_CLEANUP;
-  } else {
-    z.phase = PHASE_DONE;
-    z.is_feasible = 1;
-    z.iter = -1;
-  }
-  s = z;
+  traj_state_init(s, prm, maxiter, is_feasible_arg, prev);
 }
 }  // namespace empc

@@ -86,6 +86,12 @@ struct EmpcSolver {
   std::vector<int32_t> user_knot_set;
   bool problem_dirty = false;
   EmpcSolveStats stats;
+  // streamed solves (empc_solver_stream_*): the queue of initial states and the result rows, resident on the device
+  double* dq_x0 = nullptr;
+  double* dq_rows = nullptr;
+  int* dq_head = nullptr;                  // [0] next job; the summed iterations live behind it (8-byte aligned)
+  unsigned long long* dq_iters = nullptr;
+  int q_njobs = 0;
   std::vector<void*> allocs;
 
   template <class Tt>
@@ -101,6 +107,9 @@ struct EmpcSolver {
     for (void* p : allocs) (void)hipFree(p);
     if (h_active) (void)hipHostFree(h_active);
     if (dtrace) (void)hipFree(dtrace);
+    if (dq_x0) (void)hipFree(dq_x0);
+    if (dq_rows) (void)hipFree(dq_rows);
+    if (dq_head) (void)hipFree(dq_head);
     if (t_begin) (void)hipEventDestroy(t_begin);
     if (t_end) (void)hipEventDestroy(t_end);
     for (auto& e : ev)
@@ -141,7 +150,11 @@ static void remember_problem(EmpcSolver* s, const EmpcProblemDesc& d) {
 static void flush_problem(EmpcSolver* s) {
   if (!s->problem_dirty) return;
   const EmpcSolverParams prm = s->H.P.prm;
-  prepare_problem(s->user_desc, prm, s->H);
+  HostProblem N;
+  prepare_problem(s->user_desc, prm, N);
+  if (N.contact_rows != s->H.contact_rows || N.sets.size() != s->H.sets.size())
+    throw std::invalid_argument("set_cost_refs: the edited problem no longer matches the solver's kernel class");
+  s->H = std::move(N);
   upload_problem(s);
   s->problem_dirty = false;
 }
@@ -225,6 +238,10 @@ EmpcSolver* empc_solver_create(const EmpcProblemDesc* problem, const EmpcSolverP
     empc::set_last_error("no kernel instantiation for this (bodies, rotors, contact) combination");
     return nullptr;
   }
+  // the packed rollout stages its nominal data through 32-bit element offsets (empc_rollout6.hpp): the largest array it
+  // indexes is the tape
+  if ((long long)batch * (problem->T + 1) * s->kt.rec >= (1LL << 31))
+    throw std::invalid_argument("batch x (T + 1) x record length exceeds 2^31 elements: split the batch over several solvers");
   s->use();
   s->B = batch;
   s->T = problem->T;
@@ -359,14 +376,30 @@ int empc_tape_layout(const EmpcSolver* s, EmpcTapeLayout* l) {
   return EMPC_OK;
 }
 
+// The kernel table, the buffers and the host copies of integrator / solver type are fixed when the solver is created: a new
+// problem image may change cost tables, references, weights, x0 and dt, not the class of the problem.
+static void check_same_class(const EmpcSolver* s, const HostProblem& N) {
+  const HostProblem& O = s->H;
+  auto fail = [](const char* what) {
+    throw std::invalid_argument(std::string("update_problem: the new problem differs from the one the solver was created with in ") + what);
+  };
+  if (N.P.T != s->T || N.P.nx != s->kt.nx || N.P.nu != s->kt.nu || N.sets.size() != O.sets.size()) fail("its shapes (T, nx, nu, number of cost sets)");
+  if (N.P.integrator != O.P.integrator) fail("its integrator (Euler / RK4)");
+  if ((N.P.has_contact != 0) != (O.P.has_contact != 0)) fail("its dynamics (free / contact)");
+  if (N.contact_rows != O.contact_rows) fail("its contact type (ContactModel3D / ContactModel6D)");
+  if ((N.P.use_squash != 0) != (O.P.use_squash != 0)) fail("use_squash");
+  if (N.P.model.nbodies != O.P.model.nbodies || N.P.n_rotors != O.P.n_rotors) fail("its robot class (bodies, rotors)");
+}
+
 int empc_solver_update_problem(EmpcSolver* s, const EmpcProblemDesc* problem) {
   EMPC_TRY
   if (!s || !problem) throw std::invalid_argument("NULL argument");
-  if (problem->T != s->T || problem->nx != s->kt.nx || problem->nu != s->kt.nu || problem->n_sets != (int)s->H.sets.size())
-    throw std::invalid_argument("update_problem: shapes differ from the problem the solver was created with");
   s->use();
   const EmpcSolverParams prm = s->H.P.prm;
-  prepare_problem(*problem, prm, s->H);
+  HostProblem N;  // prepared aside: s->H keeps matching the device image if anything below throws
+  prepare_problem(*problem, prm, N);
+  check_same_class(s, N);
+  s->H = std::move(N);
   remember_problem(s, *problem);
   upload_problem(s);
   return EMPC_OK;
@@ -380,7 +413,10 @@ int empc_solver_set_cost_refs(EmpcSolver* s, int knot, const char* cost_name, co
   EMPC_TRY
   if (!s || !cost_name) throw std::invalid_argument("NULL argument");
   if (knot < 0 || knot > s->T) throw std::invalid_argument("set_cost_refs: knot out of range");
-  EmpcCostSet& set = s->user_sets[s->user_knot_set[knot]];
+  if ((int)s->user_knot_set.size() != s->T + 1) throw std::invalid_argument("set_cost_refs: the solver holds no problem");
+  const int set_index = s->user_knot_set[knot];
+  if (set_index < 0 || set_index >= (int)s->user_sets.size()) throw std::invalid_argument("set_cost_refs: knot refers to a missing cost set");
+  EmpcCostSet& set = s->user_sets[set_index];
   EmpcCost* c = nullptr;
   for (int i = 0; i < set.ncosts; ++i)
     if (std::strncmp(set.costs[i].name, cost_name, EMPC_NAME_LEN) == 0) c = &set.costs[i];
@@ -492,6 +528,7 @@ int empc_solver_set_convergence_init(EmpcSolver* s, double c) {
   EMPC_CATCH(RET_INT)
 }
 
+static int copy_out_fwd(EmpcSolver* s, const void* dsrc, void* hdst, size_t bytes);
 static void timed(EmpcSolver* s, int slot, double& acc_ms) {
   float ms = 0;
   if (hipEventElapsedTime(&ms, s->ev[slot], s->ev[slot + 1]) == hipSuccess) acc_ms += ms;
@@ -546,20 +583,9 @@ static Rk4Buffers chunk_rk4(const EmpcSolver* s, int b0) {
   return R;
 }
 
-int empc_solver_solve(EmpcSolver* s, int maxiter, int is_feasible) {
-  EMPC_TRY
-  if (!s) throw std::invalid_argument("solver is NULL");
-  if (maxiter < 1) throw std::invalid_argument("maxiter must be >= 1");
-  s->use();
-  flush_problem(s);
-  for (int b = 0; b < s->B; ++b) {
-    TrajState prev = s->h_st[b];
-    init_traj_state(s->h_st[b], s->H.P.prm, maxiter, is_feasible != 0, s->have_state ? &prev : nullptr);
-  }
-  upload_states(s);
-  if (s->D.solver_type != EMPC_SOLVER_SBFDDP)  // the BoxQP of knot t is warm-started at k_[t]: zeros at the start of a solve
-    HIP_CHECK(hipMemsetAsync(s->D.kff, 0, sizeof(double) * s->B * s->T * s->kt.nu, s->stream));
-  HIP_CHECK(hipStreamSynchronize(s->stream));
+// The sweep loop of one solve: every chunk of the batch runs calc -> linearize -> backward -> rollout -> select on its
+// stream until no trajectory of it is active any more.  `hard_cap` bounds the sweeps of a chunk.
+static void run_sweeps(EmpcSolver* s, int hard_cap) {
   EmpcSolveStats& S = s->stats;
   std::memset(&S, 0, sizeof(S));
   const KernelTable& k = s->kt;
@@ -581,7 +607,6 @@ int empc_solver_solve(EmpcSolver* s, int maxiter, int is_feasible) {
   }
   const hipEvent_t t_begin = s->t_begin, t_end = s->t_end;  // owned by the solver: nothing to leak on an error path
   HIP_CHECK(hipEventRecord(t_begin, s->stream));
-  const int hard_cap = 4 * (3 * (maxiter + 1) + 8);  // (passes + clean-up) x maxiter can never be exceeded
   // Every chunk runs its own sweep loop on its own stream, two sweeps deep: sweep k + 1 is queued before the host has
   // seen the active count of sweep k (its kernels return at once for finished trajectories), so the device never waits
   // for the host round trip between sweeps; the one surplus sweep at the end is empty and is not counted.
@@ -689,10 +714,214 @@ int empc_solver_solve(EmpcSolver* s, int maxiter, int is_feasible) {
   // a solve that ran into the sweep cap leaves no state a later "previous" warm start may build on
   s->have_state = (total_active == 0);
   if (total_active > 0) throw std::runtime_error("solve did not terminate within the sweep cap (internal error)");
+}
+
+int empc_solver_solve(EmpcSolver* s, int maxiter, int is_feasible) {
+  EMPC_TRY
+  if (!s) throw std::invalid_argument("solver is NULL");
+  if (maxiter < 1) throw std::invalid_argument("maxiter must be >= 1");
+  s->use();
+  flush_problem(s);
+  for (int b = 0; b < s->B; ++b) {
+    TrajState prev = s->h_st[b];
+    init_traj_state(s->h_st[b], s->H.P.prm, maxiter, is_feasible != 0, s->have_state ? &prev : nullptr);
+  }
+  upload_states(s);
+  if (s->D.solver_type != EMPC_SOLVER_SBFDDP)  // the BoxQP of knot t is warm-started at k_[t]: zeros at the start of a solve
+    HIP_CHECK(hipMemsetAsync(s->D.kff, 0, sizeof(double) * s->B * s->T * s->kt.nu, s->stream));
+  HIP_CHECK(hipStreamSynchronize(s->stream));
+  run_sweeps(s, 4 * (3 * (maxiter + 1) + 8));  // (passes + clean-up) x maxiter can never be exceeded
   return EMPC_OK;
   EMPC_CATCH(RET_INT)
 }
 
+int empc_solver_set_gains(EmpcSolver* s, const double* K, const double* k) {
+  EMPC_TRY
+  if (!s) throw std::invalid_argument("solver is NULL");
+  s->use();
+  const size_t B = s->B, T = s->T, n = s->kt.ndx, m = s->kt.nu;
+  if (K) HIP_CHECK(hipMemcpy(s->D.K, K, sizeof(double) * B * T * m * n, hipMemcpyHostToDevice));
+  if (k) HIP_CHECK(hipMemcpy(s->D.kff, k, sizeof(double) * B * T * m, hipMemcpyHostToDevice));
+  return EMPC_OK;
+  EMPC_CATCH(RET_INT)
+}
+
+// ---- streamed solves ("continuous batching", include/empc.h) -----------------------------------------------------------
+static size_t stream_row(const EmpcSolver* s) { return (size_t)(s->T + 1) * s->kt.nx + 2 * (size_t)s->T * s->kt.nu + 3; }
+
+int empc_solver_stream_begin(EmpcSolver* s, int n_jobs, const double* x0s) {
+  EMPC_TRY
+  if (!s || !x0s) throw std::invalid_argument("NULL argument");
+  if (n_jobs < 1) throw std::invalid_argument("stream: n_jobs must be >= 1");
+  s->use();
+  if (s->dq_x0) HIP_CHECK(hipFree(s->dq_x0));
+  if (s->dq_rows) HIP_CHECK(hipFree(s->dq_rows));
+  s->dq_x0 = s->dq_rows = nullptr;
+  s->q_njobs = 0;
+  if (!s->dq_head) {
+    HIP_CHECK(hipMalloc((void**)&s->dq_head, 16));
+    s->dq_iters = reinterpret_cast<unsigned long long*>(s->dq_head + 2);
+  }
+  HIP_CHECK(hipMalloc((void**)&s->dq_x0, sizeof(double) * (size_t)n_jobs * s->kt.nx));
+  HIP_CHECK(hipMalloc((void**)&s->dq_rows, sizeof(double) * (size_t)n_jobs * stream_row(s)));
+  HIP_CHECK(hipMemcpy(s->dq_x0, x0s, sizeof(double) * (size_t)n_jobs * s->kt.nx, hipMemcpyHostToDevice));
+  HIP_CHECK(hipMemset(s->dq_rows, 0, sizeof(double) * (size_t)n_jobs * stream_row(s)));
+  s->q_njobs = n_jobs;
+  return EMPC_OK;
+  EMPC_CATCH(RET_INT)
+}
+
+int empc_solver_stream_run(EmpcSolver* s, int maxiter) {
+  EMPC_TRY
+  if (!s) throw std::invalid_argument("solver is NULL");
+  if (maxiter < 1) throw std::invalid_argument("maxiter must be >= 1");
+  if (s->q_njobs < 1) throw std::invalid_argument("stream: call empc_solver_stream_begin first");
+  if (s->D.trace) throw std::invalid_argument("stream: the iteration trace belongs to plain solves (switch it off first)");
+  s->use();
+  flush_problem(s);
+  // the first jobs go to the slots directly: setCandidate([], []) + problem.x0 of the job
+  const int nfirst = std::min(s->B, s->q_njobs);
+  if (empc_solver_set_warmstart(s, nullptr, nullptr) != EMPC_OK) throw std::runtime_error(empc_last_error());
+  HIP_CHECK(hipMemcpyAsync(s->D.x0, s->dq_x0, sizeof(double) * (size_t)nfirst * s->kt.nx, hipMemcpyDeviceToDevice, s->stream));
+  for (int b = 0; b < s->B; ++b) {
+    init_traj_state(s->h_st[b], s->H.P.prm, maxiter, false, nullptr);
+    s->h_st[b].job = b < nfirst ? b : -1;
+    if (b >= nfirst) s->h_st[b].phase = PHASE_DONE;
+  }
+  upload_states(s);
+  HIP_CHECK(hipMemsetAsync(s->D.kff, 0, sizeof(double) * s->B * s->T * s->kt.nu, s->stream));
+  HIP_CHECK(hipMemsetAsync(s->dq_head, 0, 16, s->stream));
+  HIP_CHECK(hipMemcpyAsync(s->dq_head, &nfirst, sizeof(int), hipMemcpyHostToDevice, s->stream));
+  HIP_CHECK(hipStreamSynchronize(s->stream));
+  const DevBuffers keep = s->D;
+  s->D.q_x0 = s->dq_x0;
+  s->D.q_rows = s->dq_rows;
+  s->D.q_head = s->dq_head;
+  s->D.q_iters = s->dq_iters;
+  s->D.q_njobs = s->q_njobs;
+  s->D.q_maxiter = maxiter;
+  const long long per_solve = 4LL * (3 * (maxiter + 1) + 8);
+  const long long rounds = (s->q_njobs + s->B - 1) / s->B + 1;
+  try {
+    run_sweeps(s, (int)std::min<long long>(per_solve * rounds, 1LL << 30));
+  } catch (...) {
+    s->D = keep;
+    throw;
+  }
+  s->D = keep;
+  unsigned long long it = 0;
+  HIP_CHECK(hipMemcpy(&it, s->dq_iters, sizeof(it), hipMemcpyDeviceToHost));
+  s->stats.total_iters = (long long)it;
+  s->have_state = false;  // the slots hold the last jobs they worked on, not one solve of the batch
+  return EMPC_OK;
+  EMPC_CATCH(RET_INT)
+}
+
+int empc_solver_stream_results(EmpcSolver* s, double* rows, int* row_doubles) {
+  EMPC_TRY
+  if (!s) throw std::invalid_argument("solver is NULL");
+  if (row_doubles) *row_doubles = (int)stream_row(s);
+  if (!rows) return EMPC_OK;
+  if (s->q_njobs < 1 || !s->dq_rows) throw std::invalid_argument("stream: nothing to fetch");
+  s->use();
+  HIP_CHECK(hipMemcpy(rows, s->dq_rows, sizeof(double) * (size_t)s->q_njobs * stream_row(s), hipMemcpyDeviceToHost));
+  return EMPC_OK;
+  EMPC_CATCH(RET_INT)
+}
+
+// ---- step-wise entry points (include/empc.h): one iteration from any iterate -------------------------------------------
+int empc_solver_get_states(EmpcSolver* s, EmpcTrajState* states) {
+  EMPC_TRY
+  if (!s || !states) throw std::invalid_argument("NULL argument");
+  s->use();
+  download_states(s);
+  std::memcpy(states, s->h_st.data(), sizeof(TrajState) * s->B);
+  return EMPC_OK;
+  EMPC_CATCH(RET_INT)
+}
+int empc_solver_set_states(EmpcSolver* s, const EmpcTrajState* states) {
+  EMPC_TRY
+  if (!s || !states) throw std::invalid_argument("NULL argument");
+  s->use();
+  std::memcpy(s->h_st.data(), states, sizeof(TrajState) * s->B);
+  upload_states(s);
+  HIP_CHECK(hipStreamSynchronize(s->stream));
+  return EMPC_OK;
+  EMPC_CATCH(RET_INT)
+}
+int empc_sweep_batch(EmpcSolver* s, int stages) {
+  EMPC_TRY
+  if (!s) throw std::invalid_argument("solver is NULL");
+  if (stages <= 0 || (stages & ~EMPC_STAGE_ALL)) throw std::invalid_argument("sweep: unknown stage bits");
+  s->use();
+  flush_problem(s);
+  DevBuffers D = s->D;  // every trajectory, no work lists, no host hand-over
+  HIP_CHECK(hipMemsetAsync(D.n_active, 0, sizeof(int) * 4, s->stream));
+  std::memset(&s->stats, 0, sizeof(s->stats));
+  HIP_CHECK(hipEventRecord(s->ev[0], s->stream));
+  if (stages & EMPC_STAGE_LINEARIZE) {
+    s->kt.calc(D, s->stream);
+    if (s->D.integrator == EMPC_INTEGRATOR_RK4)
+      s->kt.rk4_linearize(D, s->R4, s->stream);
+    else
+      s->kt.linearize(D, s->stream);
+  }
+  HIP_CHECK(hipEventRecord(s->ev[1], s->stream));
+  if (stages & EMPC_STAGE_BACKWARD) s->kt.backward(D, s->stream);
+  HIP_CHECK(hipEventRecord(s->ev[2], s->stream));
+  if (stages & EMPC_STAGE_ROLLOUT) s->kt.rollout(D, s->stream);
+  HIP_CHECK(hipEventRecord(s->ev[3], s->stream));
+  if (stages & EMPC_STAGE_SELECT) s->kt.select(D, s->stream);
+  HIP_CHECK(hipEventRecord(s->ev[4], s->stream));
+  download_states(s);
+  HIP_CHECK(hipGetLastError());
+  timed(s, 0, s->stats.ms_linearize);
+  timed(s, 1, s->stats.ms_backward);
+  timed(s, 2, s->stats.ms_rollout);
+  timed(s, 3, s->stats.ms_select);
+  s->stats.sweeps = 1;
+  return EMPC_OK;
+  EMPC_CATCH(RET_INT)
+}
+int empc_select_batch(EmpcSolver* s, const int* try_ok, const double* try_cost, const double* try_dv) {
+  EMPC_TRY
+  if (!s) throw std::invalid_argument("solver is NULL");
+  s->use();
+  const size_t n = (size_t)s->B * s->NA;
+  if (try_ok) HIP_CHECK(hipMemcpyAsync(s->D.try_ok, try_ok, sizeof(int) * n, hipMemcpyHostToDevice, s->stream));
+  if (try_cost) HIP_CHECK(hipMemcpyAsync(s->D.try_cost, try_cost, sizeof(double) * n, hipMemcpyHostToDevice, s->stream));
+  if (try_dv) HIP_CHECK(hipMemcpyAsync(s->D.try_dv, try_dv, sizeof(double) * n, hipMemcpyHostToDevice, s->stream));
+  HIP_CHECK(hipStreamSynchronize(s->stream));  // the host arrays are the caller's
+  return empc_sweep_batch(s, EMPC_STAGE_SELECT);
+  EMPC_CATCH(RET_INT)
+}
+int empc_solver_get_trials(EmpcSolver* s, double* try_cost, double* try_dv, int* try_ok) {
+  EMPC_TRY
+  if (!s) throw std::invalid_argument("solver is NULL");
+  s->use();
+  const size_t n = (size_t)s->B * s->NA;
+  if (try_cost) HIP_CHECK(hipMemcpy(try_cost, s->D.try_cost, sizeof(double) * n, hipMemcpyDeviceToHost));
+  if (try_dv) HIP_CHECK(hipMemcpy(try_dv, s->D.try_dv, sizeof(double) * n, hipMemcpyDeviceToHost));
+  if (try_ok) HIP_CHECK(hipMemcpy(try_ok, s->D.try_ok, sizeof(int) * n, hipMemcpyDeviceToHost));
+  return EMPC_OK;
+  EMPC_CATCH(RET_INT)
+}
+int empc_solver_get_tape(EmpcSolver* s, double* tape) {
+  if (!s) return EMPC_ERR_INVALID;
+  return copy_out_fwd(s, s->D.tape, tape, sizeof(double) * (size_t)s->B * (s->T + 1) * s->kt.rec);
+}
+int empc_solver_get_gains(EmpcSolver* s, double* K, double* k, double* Vx) {
+  if (!s) return EMPC_ERR_INVALID;
+  const size_t B = s->B, T = s->T, n = s->kt.ndx, m = s->kt.nu;
+  int rc = EMPC_OK;
+  if (K && rc == EMPC_OK) rc = copy_out_fwd(s, s->D.K, K, sizeof(double) * B * T * m * n);
+  if (k && rc == EMPC_OK) rc = copy_out_fwd(s, s->D.kff, k, sizeof(double) * B * T * m);
+  if (Vx && rc == EMPC_OK) rc = copy_out_fwd(s, s->D.Vx, Vx, sizeof(double) * B * (T + 1) * n);
+  return rc;
+}
+
+static int copy_out(EmpcSolver* s, const void* dsrc, void* hdst, size_t bytes);
+static int copy_out_fwd(EmpcSolver* s, const void* dsrc, void* hdst, size_t bytes) { return copy_out(s, dsrc, hdst, bytes); }
 static int copy_out(EmpcSolver* s, const void* dsrc, void* hdst, size_t bytes) {
   EMPC_TRY
   if (!s || !hdst) throw std::invalid_argument("NULL argument");
@@ -873,6 +1102,7 @@ int empc_backward_batch(EmpcSolver* s, double xreg, int is_feasible, double* K, 
   EMPC_TRY
   if (!s) throw std::invalid_argument("solver is NULL");
   s->use();
+  flush_problem(s);
   const double smooth = s->h_st.empty() ? s->H.P.prm.smooth_init : s->h_st[0].smooth;
   phase_setup(s, smooth > 0 ? smooth : s->H.P.prm.smooth_init, is_feasible, xreg, false, true);
   HIP_CHECK(hipEventRecord(s->ev[0], s->stream));
@@ -905,6 +1135,7 @@ int empc_rollout_batch(EmpcSolver* s, double alpha, int ddp, int is_feasible, do
   EMPC_TRY
   if (!s) throw std::invalid_argument("solver is NULL");
   s->use();
+  flush_problem(s);
   int ai = -1;
   for (int i = 0; i < s->NA; ++i)
     if (std::ldexp(1.0, -i) == alpha) ai = i;

@@ -107,6 +107,20 @@ class SolveStats(C.Structure):
     ]
 
 
+class TrajState(C.Structure):
+    """EmpcTrajState (include/empc_types.h): the solver scalars of one trajectory"""
+    _fields_ = [(n, i32) for n in
+                ("phase", "iter", "total_iters", "status", "is_feasible", "was_feasible", "need_calc", "need_lin", "maxiter",
+                 "bwd_failed", "trace_count", "last_ok", "accepted_alpha", "last_alpha", "job", "reserved")] + \
+               [(n, d) for n in
+                ("smooth", "smooth_next", "convergence", "th_stop", "xreg", "ureg", "cost", "cost_prev", "stop", "steplength",
+                 "dV", "dVexp", "d0", "d1", "dg_u", "dq_u", "dg_f", "dq_f", "gapnorm", "qu2")]
+
+
+STAGE_LINEARIZE, STAGE_BACKWARD, STAGE_ROLLOUT, STAGE_SELECT, STAGE_ALL = 1, 2, 4, 8, 15
+PHASE_DDP, PHASE_DONE = 100, 255
+
+
 class TapeLayout(C.Structure):
     _fields_ = [(n, C.c_int) for n in
                 ("rec", "off_fx", "off_fu", "off_lxx", "off_lxu", "off_luu", "off_lx", "off_lu", "off_gap", "off_cost",

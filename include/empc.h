@@ -151,6 +151,45 @@ int empc_backward_batch(EmpcSolver* s, double xreg, int is_feasible, double* K /
 /* forwardPass(alpha) from the current candidate and gains; ddp != 0 selects forwardPassDDP (no gap terms) */
 int empc_rollout_batch(EmpcSolver* s, double alpha, int ddp, int is_feasible, double* xs_try, double* us_try,
                        double* cost_try /* batch */, int* ok /* batch */);
+/* ---- step-wise entry points: one iteration from any iterate ---------------------------------------------------------
+ * The loop body of solveFDDP / solveDDP (src/sbfddp.cpp:241-311, 329-389) as separately callable stages over the whole
+ * batch, starting from per-trajectory solver scalars the caller supplies.  Purpose: teacher-forced parity -- put every
+ * trajectory at an iterate recorded from a CPU solve (candidate via empc_solver_set_warmstart, x0 via
+ * empc_solver_set_x0, scalars via empc_solver_set_states), run ONE iteration, and compare every intermediate (tape,
+ * gains, the cost of every step length, accepted step, new regularisation, feasibility, stop decision) with the CPU
+ * side.  Unlike empc_linearize_batch & co. these calls never reset the scalars. */
+int empc_solver_get_states(EmpcSolver* s, EmpcTrajState* states /* batch */);
+int empc_solver_set_states(EmpcSolver* s, const EmpcTrajState* states /* batch */);
+/* runs the stages named in `stages` (EMPC_STAGE_* bits, in the order linearize, backward, rollout, select) once */
+int empc_sweep_batch(EmpcSolver* s, int stages);
+/* the line-search decision alone (select_decide_state: src/sbfddp.cpp:260-311, 348-389, 205-220): trial results are
+ * taken from the arguments (batch x n_alphas each; NULL = what the last rollout left on the device) */
+int empc_select_batch(EmpcSolver* s, const int* try_ok, const double* try_cost, const double* try_dv);
+/* results of the last rollout for every step length: cost_try, the gap term dv of expectedImprovement, ok flag */
+int empc_solver_get_trials(EmpcSolver* s, double* try_cost, double* try_dv, int* try_ok /* each batch x n_alphas */);
+/* device buffers as they are: tape batch x (T+1) x rec (empc_tape_layout); K batch x T x nu x ndx; k batch x T x nu;
+ * Vx batch x (T+1) x ndx.  Any pointer may be NULL. */
+int empc_solver_get_tape(EmpcSolver* s, double* tape);
+int empc_solver_get_gains(EmpcSolver* s, double* K, double* k, double* Vx);
+/* overwrite the gains on the device (NULL = keep): the box solvers warm-start the QP of knot t at k_[t] of the previous
+ * iteration, so an iterate of theirs includes k */
+int empc_solver_set_gains(EmpcSolver* s, const double* K, const double* k);
+
+/* ---- streamed solves ("continuous batching") ------------------------------------------------------------------------
+ * n_jobs independent solves of the solver's problem -- solve([], [], maxiter) from the initial states x0s, what the
+ * reference's benchmark loop does one after another (benchmark/utils/utils.hpp:15-27 + SolverSbFDDP::solve) -- pushed
+ * through the solver's `batch` slots: a slot whose trajectory finishes writes its result row and takes the next job of the
+ * queue inside the same sweep, so every sweep runs on a full batch until the queue is dry (a plain empc_solver_solve
+ * spends most of its sweeps on the few trajectories that need many iterations).  Each job's arithmetic is that of a plain
+ * solve (a trajectory never sees its batch neighbours), so its row is bitwise what empc_solver_solve gives for the same x0.
+ *   stream_begin   copies the queue to the device and allocates the result rows there (inputs resident in HBM)
+ *   stream_run     processes the whole queue
+ *   stream_results copies rows out: xs | us | us_squash | cost | iters | status per job (row length via row_doubles;
+ *                  rows == NULL only queries it) */
+int empc_solver_stream_begin(EmpcSolver* s, int n_jobs, const double* x0s /* n_jobs x nx */);
+int empc_solver_stream_run(EmpcSolver* s, int maxiter);
+int empc_solver_stream_results(EmpcSolver* s, double* rows /* n_jobs x row */, int* row_doubles);
+
 /* offsets (in doubles) of the blocks inside one tape record */
 typedef struct EmpcTapeLayout {
   int rec, off_fx, off_fu, off_lxx, off_lxu, off_luu, off_lx, off_lu, off_gap, off_cost;

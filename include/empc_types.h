@@ -181,6 +181,41 @@ typedef struct EmpcSolverParams {
 #define EMPC_STATUS_MAXITER 4     /* an inner loop ran out of iterations              */
 #define EMPC_STATUS_DDP_CLEANUP 8 /* solveDDP ran because the FDDP result was infeasible */
 
+/* Solver scalars of ONE trajectory: the members of crocoddyl::SolverAbstract / SolverDDP / SolverFDDP and of the fork's
+ * SolverSbFDDP that one pass through the loop body of solveFDDP / solveDDP (src/sbfddp.cpp:241-311, 329-389) reads and
+ * writes, plus the continuation bookkeeping of solve() (:205-220).  The solver keeps one per trajectory on the device; the
+ * step-wise entry points (empc_solver_get_states / set_states / empc_sweep_batch / empc_select_batch) expose it so that a
+ * test can put the solver at any iterate of any pass and run exactly one iteration from there (teacher-forced parity). */
+typedef struct EmpcTrajState {
+  int32_t phase;         /* 0,1,.. = FDDP pass index; 100 = DDP clean-up (solveDDP); 255 = done                     */
+  int32_t iter;          /* iter_ of the running pass; after the solve: total iterations - 1 (sbfddp.cpp:222)       */
+  int32_t total_iters;   /* iterations of the passes already finished                                               */
+  int32_t status;        /* EMPC_STATUS_* bits                                                                       */
+  int32_t is_feasible, was_feasible;
+  int32_t need_calc;     /* the pass starts: problem.calc at the candidate before calcDiff (iter_ == 0)              */
+  int32_t need_lin;      /* recalc flag of the loop: calcDiff runs in the next computeDirection                      */
+  int32_t maxiter;
+  int32_t bwd_failed;    /* computeDirection gave up at reg_max in this iteration                                    */
+  int32_t trace_count;   /* iteration records written in this solve                                                  */
+  int32_t last_ok;       /* the last solveFDDP / solveDDP returned true                                              */
+  int32_t accepted_alpha;/* index n of the step length 2^-n accepted by the last line search, -1 = none              */
+  int32_t last_alpha;    /* index of the last step length the line search tried                                      */
+  int32_t job;           /* streamed solves (empc_solver_solve_stream): the queue entry this slot works on, -1 = none */
+  int32_t reserved;
+  double smooth, smooth_next, convergence, th_stop;
+  double xreg, ureg, cost, cost_prev, stop, steplength, dV, dVexp, d0, d1;
+  double dg_u, dq_u;     /* sum Qu.k , -sum k.Quu k      (control part of dg / dq)                                    */
+  double dg_f, dq_f;     /* -sum Vx.f , +sum f.Vxx f     (gap part, used while the trajectory is infeasible)         */
+  double gapnorm, qu2;   /* norm of the gaps (EmpcGapNorm), sum |Qu|^2                                               */
+} EmpcTrajState;
+
+/* stages of one sweep, for empc_sweep_batch */
+#define EMPC_STAGE_LINEARIZE 1 /* calc (pass starts) + calcDiff           */
+#define EMPC_STAGE_BACKWARD 2  /* backwardPass + computeGains, with the regularisation retry of computeDirection */
+#define EMPC_STAGE_ROLLOUT 4   /* forwardPass / forwardPassDDP for every step length */
+#define EMPC_STAGE_SELECT 8    /* acceptance, regularisation update, stopping test, continuation */
+#define EMPC_STAGE_ALL 15
+
 /* One record of the per-iteration trace (empc_solver_enable_trace / empc_solver_get_trace): what a
  * crocoddyl::CallbackAbstract sees after stoppingCriteria() in solveFDDP / solveDDP
  * (reference src/sbfddp.cpp:303-307, 381-385).  EMPC_TRACE_WORDS doubles per record:

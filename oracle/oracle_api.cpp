@@ -106,6 +106,110 @@ int oracle_solver_trace(void* h, double* out, int max_records) {
 }
 int oracle_trace_record_len(void) { return (int)(sizeof(IterRecord) / sizeof(double)); }
 
+// ---- iterate recording + one-iteration probe (teacher-forced parity tests) ----------------------------------------------
+void oracle_solver_record_iterates(void* h, int on) { static_cast<Solver*>(h)->record_iterates = on != 0; }
+int oracle_solver_n_iterates(void* h) { return (int)static_cast<Solver*>(h)->iterates.size(); }
+// iterate i of the last solve: candidate (xs, us), integers {phase, iter, is_feasible, was_feasible, recalc, trace_index,
+// accepted_alpha, ended, returned}, reals {xreg, smooth, th_stop, cost, cost_prev}
+int oracle_solver_get_iterate(void* h, int i, double* xs, double* us, int* ints, double* reals, double* k) {
+  Solver* s = static_cast<Solver*>(h);
+  if (i < 0 || i >= (int)s->iterates.size()) return -1;
+  const Iterate& it = s->iterates[i];
+  if (xs) std::memcpy(xs, it.xs.data(), sizeof(double) * it.xs.size());
+  if (us) std::memcpy(us, it.us.data(), sizeof(double) * it.us.size());
+  if (k) std::memcpy(k, it.k.data(), sizeof(double) * it.k.size());
+  if (ints) {
+    const int v[9] = {it.phase, it.iter, it.is_feasible, it.was_feasible, it.recalc, it.trace_index, it.accepted_alpha, it.ended, it.returned};
+    std::memcpy(ints, v, sizeof(v));
+  }
+  if (reals) {
+    const double v[5] = {it.xreg, it.smooth, it.th_stop, it.cost, it.cost_prev};
+    std::memcpy(reals, v, sizeof(v));
+  }
+  return 0;
+}
+// One iteration's worth of work from a given iterate, WITHOUT the line search's early exit: calcDiff, computeDirection
+// (regularisation retries included), the expected-improvement sums, then forwardPass for EVERY step length.
+//   scal_in  {is_feasible, was_feasible, ddp (solveDDP iteration), xreg, smooth}
+//   scal_out {cost, is_feasible after calcDiff, gap norm, xreg after computeDirection, dg, dq, direction ok}
+//   per step length n: ok[n], cost_try[n], d0[n], d1[n] (expectedImprovement after that trial; the DDP values for ddp)
+// The solver object afterwards holds the tape (oracle_phase_tape) and the gains of that iterate.
+int oracle_iter_probe(void* h, const double* xs, const double* us, const double* k_in, const double* scal_in, double* scal_out,
+                      int* ok, double* cost_try, double* d0, double* d1) {
+  Solver* s = static_cast<Solver*>(h);
+  if (k_in)  // box solvers: the QP of knot t starts at k_[t] of the previous iteration
+    for (int t = 0; t < s->T; ++t) s->k[t].assign(k_in + (size_t)t * s->nu, k_in + (size_t)(t + 1) * s->nu);
+  const bool ddp = scal_in[2] != 0.0;
+  s->P.smooth = scal_in[4];
+  if (s->P.prm.solver_type == EMPC_SOLVER_SBFDDP) s->barrier_update(scal_in[4]);
+  s->set_candidate(xs, us, scal_in[0] != 0.0);
+  s->was_feasible = scal_in[1] != 0.0;
+  s->xreg = s->ureg = scal_in[3];
+  s->xs_try[0] = s->x0;
+  bool recalc = true;
+  const bool dir_ok = s->compute_direction(recalc);
+  scal_out[0] = s->cost;
+  scal_out[1] = s->is_feasible ? 1.0 : 0.0;
+  scal_out[2] = s->gap_norm();
+  scal_out[3] = s->xreg;
+  scal_out[6] = dir_ok ? 1.0 : 0.0;
+  if (!dir_ok) return 0;
+  if (ddp) {
+    s->expected_improvement_ddp();
+    scal_out[4] = s->d[0];
+    scal_out[5] = s->d[1];
+  } else {
+    s->update_expected_improvement();
+    scal_out[4] = s->dg;
+    scal_out[5] = s->dq;
+  }
+  const double d0_ddp = s->d[0], d1_ddp = s->d[1];
+  for (size_t n = 0; n < s->alphas.size(); ++n) {
+    const bool fok = s->forward_pass(s->alphas[n], ddp);
+    ok[n] = fok ? 1 : 0;
+    cost_try[n] = s->cost_try;
+    if (fok && !ddp) s->expected_improvement();
+    d0[n] = ddp ? d0_ddp : s->d[0];
+    d1[n] = ddp ? d1_ddp : s->d[1];
+  }
+  return 1;
+}
+
+// Exactly one pass through the loop body of solveFDDP / solveDDP from a given iterate (the function the solve loops call).
+//   scal_in  {is_feasible, was_feasible, ddp, xreg, smooth, th_stop, cost, cost_prev, iter, upstream test (box FDDP)}
+//   ints_out {result (0 go on, 1 returned true, -1 returned false), accepted alpha index, is_feasible, was_feasible, recorded}
+//   scal_out {steplength, xreg, cost, cost_prev, stop, dV, dVexp, d0, d1, gap norm}
+// The new candidate is read with oracle_solver_get.
+void oracle_iter_step(void* h, const double* xs, const double* us, const double* k_in, const double* scal_in, int* ints_out,
+                      double* scal_out) {
+  Solver* s = static_cast<Solver*>(h);
+  const bool ddp = scal_in[2] != 0.0;
+  if (k_in)
+    for (int t = 0; t < s->T; ++t) s->k[t].assign(k_in + (size_t)t * s->nu, k_in + (size_t)(t + 1) * s->nu);
+  s->P.smooth = scal_in[4];
+  if (s->P.prm.solver_type == EMPC_SOLVER_SBFDDP) s->barrier_update(scal_in[4]);
+  s->set_candidate(xs, us, scal_in[0] != 0.0);
+  s->was_feasible = scal_in[1] != 0.0;
+  s->xreg = s->ureg = scal_in[3];
+  s->th_stop = scal_in[5];
+  s->cost = scal_in[6];
+  s->cost_prev = scal_in[7];
+  s->iter = (int)scal_in[8];
+  s->xs_try[0] = s->x0;
+  s->phase = ddp ? 100 : 0;
+  bool recalc = true;
+  int acc_idx = -1;
+  bool recorded = false;
+  const int r = ddp ? s->ddp_iteration(recalc, acc_idx, recorded) : s->fddp_iteration(recalc, scal_in[9] != 0.0, acc_idx, recorded);
+  ints_out[0] = r;
+  ints_out[1] = acc_idx;
+  ints_out[2] = s->is_feasible ? 1 : 0;
+  ints_out[3] = s->was_feasible ? 1 : 0;
+  ints_out[4] = recorded ? 1 : 0;
+  const double o[10] = {s->steplength, s->xreg, s->cost, s->cost_prev, s->stop, s->dV, s->dVexp, s->d[0], s->d[1], s->gap_norm()};
+  std::memcpy(scal_out, o, sizeof(o));
+}
+
 // squashingUpdate + barrierUpdate (src/sbfddp.cpp:462-477)
 void oracle_solver_set_smooth(void* h, double smooth) {
   Solver* s = static_cast<Solver*>(h);

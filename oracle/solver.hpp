@@ -22,6 +22,20 @@ struct IterRecord {
 
 inline bool bad_number(double v) { return std::isnan(v) || std::isinf(v) || std::fabs(v) >= 1e30; }
 
+// Candidate and solver scalars at the TOP of one iteration of solveFDDP / solveDDP (before computeDirection), with the
+// outcome of that iteration filled in when it is over.  Recorded on request (Solver::record_iterates) for the
+// teacher-forced parity tests: the GPU solver is put at exactly this iterate and must reproduce the iteration.
+struct Iterate {
+  std::vector<double> xs, us;  // (T+1) x nx, T x nu
+  std::vector<double> k;       // T x nu: feed-forward terms of the previous iteration (warm start of the box QPs)
+  int phase, iter, is_feasible, was_feasible, recalc;
+  double xreg, smooth, th_stop, cost, cost_prev;
+  int trace_index;     // index of this iteration's IterRecord in Solver::trace, -1 when it ended without one
+  int accepted_alpha;  // index n of the accepted step length 2^-n, -1 = none
+  int ended;           // the pass ended with this iteration
+  int returned;        // ... because the stopping test passed (solveFDDP / solveDDP returned true)
+};
+
 struct Solver {
   Problem P;
   int T, nx, ndx, nu;
@@ -35,6 +49,41 @@ struct Solver {
   int iter, total_iters, status;
   std::vector<IterRecord> trace;
   int phase;
+  bool record_iterates = false;
+  std::vector<Iterate> iterates;
+
+  void open_iterate(bool recalc) {
+    if (!record_iterates) return;
+    Iterate it;
+    it.xs.reserve((size_t)(T + 1) * nx);
+    for (int t = 0; t <= T; ++t) it.xs.insert(it.xs.end(), xs[t].begin(), xs[t].end());
+    it.us.reserve((size_t)T * nu);
+    for (int t = 0; t < T; ++t) it.us.insert(it.us.end(), us[t].begin(), us[t].end());
+    for (int t = 0; t < T; ++t) it.k.insert(it.k.end(), k[t].begin(), k[t].end());
+    it.phase = phase;
+    it.iter = iter;
+    it.is_feasible = is_feasible ? 1 : 0;
+    it.was_feasible = was_feasible ? 1 : 0;
+    it.recalc = recalc ? 1 : 0;
+    it.xreg = xreg;
+    it.smooth = P.smooth;
+    it.th_stop = th_stop;
+    it.cost = cost;
+    it.cost_prev = cost_prev;
+    it.trace_index = -1;
+    it.accepted_alpha = -1;
+    it.ended = 0;
+    it.returned = 0;
+    iterates.push_back(std::move(it));
+  }
+  void close_iterate(int accepted_alpha, bool recorded, bool ended, bool returned) {
+    if (!record_iterates || iterates.empty()) return;
+    Iterate& it = iterates.back();
+    it.accepted_alpha = accepted_alpha;
+    it.trace_index = recorded ? (int)trace.size() - 1 : -1;
+    it.ended = ended ? 1 : 0;
+    it.returned = returned ? 1 : 0;
+  }
 
   // SolverSbFDDP ctor (src/sbfddp.cpp:5-38) + barrierInit (:169-190)
   void init(const EmpcProblemDesc& desc, const EmpcSolverParams& prm) {
@@ -589,93 +638,134 @@ struct Solver {
     trace.push_back(r);
   }
 
-  // sbfddp.cpp:228-315; upstream = crocoddyl::SolverFDDP::solve's own test (was_feasible_ && stop_ < th_stop_), used by
-  // SolverBoxFDDP
+  // One pass through the loop body of solveFDDP (sbfddp.cpp:241-311).  Returns 0 = go on, 1 = solveFDDP returns true,
+  // -1 = solveFDDP returns false.  upstream = crocoddyl::SolverFDDP::solve's own stopping test (was_feasible_ && stop_ <
+  // th_stop_), used by SolverBoxFDDP.  acc_idx: index of the accepted step length (-1 none); recorded: the iteration reached
+  // stoppingCriteria() and left an IterRecord.
+  int fddp_iteration(bool& recalc, bool upstream, int& acc_idx, bool& recorded) {
+    acc_idx = -1;
+    recorded = false;
+    if (!compute_direction(recalc)) {
+      status |= EMPC_STATUS_REG_MAX;
+      return -1;
+    }
+    update_expected_improvement();
+    recalc = false;
+    int ai = 0;
+    for (double alpha : alphas) {
+      steplength = alpha;
+      const int this_ai = ai++;
+      if (!forward_pass(alpha, false)) continue;
+      dV = cost - cost_try;
+      expected_improvement();
+      dVexp = steplength * (d[0] + 0.5 * steplength * d[1]);
+      if (dVexp >= 0) {
+        if (d[0] < P.prm.th_grad || dV > P.prm.th_acceptstep * dVexp) {
+          accept(is_feasible || steplength == 1.0);
+          recalc = true;
+          acc_idx = this_ai;
+          break;
+        }
+      } else {
+        if (dV > P.prm.th_acceptnegstep * dVexp) {
+          accept(is_feasible || steplength == 1.0);
+          recalc = true;
+          acc_idx = this_ai;
+          break;
+        }
+      }
+    }
+    if (steplength > P.prm.th_stepdec) decrease_reg();
+    if (steplength <= P.prm.th_stepinc) {
+      increase_reg();
+      if (xreg == P.prm.reg_max) {
+        status |= EMPC_STATUS_REG_MAX;
+        return -1;
+      }
+    }
+    stopping_criteria();
+    record();
+    recorded = true;
+    if (upstream ? stopping_test_feasible() : stopping_test_gaps()) return 1;
+    return 0;
+  }
+  // sbfddp.cpp:228-315
   bool solve_fddp(int maxiter, bool feasible, double reginit, bool upstream = false) {
     is_feasible = feasible;
     xreg = ureg = std::isnan(reginit) ? P.prm.reg_min : reginit;
     was_feasible = false;
     bool recalc = true;
     for (iter = 0; iter < maxiter; ++iter) {
-      if (!compute_direction(recalc)) {
-        status |= EMPC_STATUS_REG_MAX;
-        return false;
+      open_iterate(recalc);
+      int acc_idx;
+      bool recorded;
+      const int r = fddp_iteration(recalc, upstream, acc_idx, recorded);
+      if (r != 0) {
+        close_iterate(acc_idx, recorded, true, r > 0);
+        return r > 0;
       }
-      update_expected_improvement();
-      recalc = false;
-      for (double alpha : alphas) {
-        steplength = alpha;
-        if (!forward_pass(alpha, false)) continue;
-        dV = cost - cost_try;
-        expected_improvement();
-        dVexp = steplength * (d[0] + 0.5 * steplength * d[1]);
-        if (dVexp >= 0) {
-          if (d[0] < P.prm.th_grad || dV > P.prm.th_acceptstep * dVexp) {
-            accept(is_feasible || steplength == 1.0);
-            recalc = true;
-            break;
-          }
-        } else {
-          if (dV > P.prm.th_acceptnegstep * dVexp) {
-            accept(is_feasible || steplength == 1.0);
-            recalc = true;
-            break;
-          }
-        }
-      }
-      if (steplength > P.prm.th_stepdec) decrease_reg();
-      if (steplength <= P.prm.th_stepinc) {
-        increase_reg();
-        if (xreg == P.prm.reg_max) {
-          status |= EMPC_STATUS_REG_MAX;
-          return false;
-        }
-      }
-      stopping_criteria();
-      record();
-      if (upstream ? stopping_test_feasible() : stopping_test_gaps()) return true;
+      close_iterate(acc_idx, recorded, iter + 1 >= maxiter, false);
     }
     iter = iter >= maxiter ? maxiter - 1 : iter;
     status |= EMPC_STATUS_MAXITER;
     return false;
   }
 
+  // one pass through the loop body of solveDDP (sbfddp.cpp:329-389); return value as fddp_iteration
+  int ddp_iteration(bool& recalc, int& acc_idx, bool& recorded) {
+    acc_idx = -1;
+    recorded = false;
+    if (!compute_direction(recalc)) {
+      status |= EMPC_STATUS_REG_MAX;
+      return -1;
+    }
+    expected_improvement_ddp();
+    recalc = false;
+    int ai = 0;
+    for (double alpha : alphas) {
+      steplength = alpha;
+      const int this_ai = ai++;
+      if (!forward_pass(alpha, true)) continue;
+      dV = cost - cost_try;
+      dVexp = steplength * (d[0] + 0.5 * steplength * d[1]);
+      if (dVexp >= 0) {
+        if (d[0] < P.prm.th_grad || !is_feasible || dV > P.prm.th_acceptstep * dVexp) {
+          accept(true);
+          recalc = true;
+          acc_idx = this_ai;
+          break;
+        }
+      }
+    }
+    if (steplength > P.prm.th_stepdec) decrease_reg();
+    if (steplength <= P.prm.th_stepinc) {
+      increase_reg();
+      if (xreg == P.prm.reg_max) {
+        status |= EMPC_STATUS_REG_MAX;
+        return -1;
+      }
+    }
+    stopping_criteria();
+    record();
+    recorded = true;
+    if (stopping_test_feasible()) return 1;
+    return 0;
+  }
   // sbfddp.cpp:317-393
   bool solve_ddp(int maxiter, double reginit) {
     xreg = ureg = std::isnan(reginit) ? P.prm.reg_min : reginit;
     was_feasible = false;
     bool recalc = true;
     for (iter = 0; iter < maxiter; ++iter) {
-      if (!compute_direction(recalc)) {
-        status |= EMPC_STATUS_REG_MAX;
-        return false;
+      open_iterate(recalc);
+      int acc_idx;
+      bool recorded;
+      const int r = ddp_iteration(recalc, acc_idx, recorded);
+      if (r != 0) {
+        close_iterate(acc_idx, recorded, true, r > 0);
+        return r > 0;
       }
-      expected_improvement_ddp();
-      recalc = false;
-      for (double alpha : alphas) {
-        steplength = alpha;
-        if (!forward_pass(alpha, true)) continue;
-        dV = cost - cost_try;
-        dVexp = steplength * (d[0] + 0.5 * steplength * d[1]);
-        if (dVexp >= 0) {
-          if (d[0] < P.prm.th_grad || !is_feasible || dV > P.prm.th_acceptstep * dVexp) {
-            accept(true);
-            recalc = true;
-            break;
-          }
-        }
-      }
-      if (steplength > P.prm.th_stepdec) decrease_reg();
-      if (steplength <= P.prm.th_stepinc) {
-        increase_reg();
-        if (xreg == P.prm.reg_max) {
-          status |= EMPC_STATUS_REG_MAX;
-          return false;
-        }
-      }
-      stopping_criteria();
-      record();
-      if (stopping_test_feasible()) return true;
+      close_iterate(acc_idx, recorded, iter + 1 >= maxiter, false);
     }
     iter = iter >= maxiter ? maxiter - 1 : iter;
     status |= EMPC_STATUS_MAXITER;
@@ -691,6 +781,7 @@ struct Solver {
     total_iters = 0;
     status = 0;
     trace.clear();
+    iterates.clear();
     phase = 0;
     bool last = false;
     if (P.prm.solver_type != EMPC_SOLVER_SBFDDP) {

@@ -331,16 +331,25 @@ static void emu_select(Emu& e) {
     int acc_ai, last_ai;
     select_decide<DM>(e.D, b, acc_ai, last_ai);
     select_copy<DM>(e.D, b, acc_ai, last_ai, 0, 1);
+    if (e.D.q_rows) {  // streamed solves: the hand-over k_select performs
+      TrajState& st = e.st[b];
+      if (st.phase == PHASE_DONE && st.job >= 0) {
+        stream_write_row<DM>(e.D, b, 0, 1);
+        *e.D.q_iters += (unsigned long long)st.total_iters;
+        const int j = (*e.D.q_head)++;
+        const int job = j < e.D.q_njobs ? j : -1;
+        if (job >= 0) {
+          stream_refill<DM>(e.D, b, job, 0, 1);
+          traj_state_init(st, e.H.P.prm, e.D.q_maxiter, false, (const TrajState*)nullptr);
+        }
+        st.job = job;
+      }
+    }
     if (e.st[b].phase != PHASE_DONE) e.n_active++;
   }
 }
 template <class DM>
-static void emu_solve(Emu& e, int maxiter, int is_feasible) {
-  for (int b = 0; b < e.B; ++b) {
-    TrajState prev = e.st[b];
-    init_traj_state(e.st[b], e.H.P.prm, maxiter, is_feasible != 0, &prev);
-  }
-  if (e.H.P.prm.solver_type != EMPC_SOLVER_SBFDDP) std::fill(e.kff.begin(), e.kff.end(), 0.0);
+static void emu_run_sweeps(Emu& e) {
   e.sweeps = 0;
   while (true) {
     emu_calc<DM>(e);
@@ -349,8 +358,57 @@ static void emu_solve(Emu& e, int maxiter, int is_feasible) {
     emu_rollout<DM>(e);
     emu_select<DM>(e);
     e.sweeps++;
-    if (e.n_active == 0 || e.sweeps > 10000) break;
+    if (e.n_active == 0 || e.sweeps > 100000) break;
   }
+}
+template <class DM>
+static void emu_stream(Emu& e, int n_jobs, const double* x0s, int maxiter, double* rows, long long* total_iters) {
+  const int nfirst = n_jobs < e.B ? n_jobs : e.B;
+  int head = nfirst;
+  unsigned long long iters = 0;
+  std::fill(e.xs.begin(), e.xs.end(), 0.0);
+  for (size_t i = 0; i < (size_t)e.B * (e.T + 1); ++i) e.xs[i * e.nx + 6] = 1.0;
+  std::fill(e.us.begin(), e.us.end(), 0.0);
+  std::fill(e.kff.begin(), e.kff.end(), 0.0);
+  std::memcpy(e.x0.data(), x0s, sizeof(double) * (size_t)nfirst * e.nx);
+  for (int b = 0; b < e.B; ++b) {
+    init_traj_state(e.st[b], e.H.P.prm, maxiter, false, nullptr);
+    e.st[b].job = b < nfirst ? b : -1;
+    if (b >= nfirst) e.st[b].phase = PHASE_DONE;
+  }
+  const DevBuffers keep = e.D;
+  e.D.q_x0 = x0s;
+  e.D.q_rows = rows;
+  e.D.q_head = &head;
+  e.D.q_iters = &iters;
+  e.D.q_njobs = n_jobs;
+  e.D.q_maxiter = maxiter;
+  emu_run_sweeps<DM>(e);
+  e.D = keep;
+  if (total_iters) *total_iters = (long long)iters;
+}
+template <class DM>
+static void emu_sweep_stages(Emu& e, int stages) {
+  if (stages & EMPC_STAGE_LINEARIZE) {
+    emu_calc<DM>(e);
+    emu_linearize<DM>(e);
+  }
+  if (stages & EMPC_STAGE_BACKWARD) emu_backward<DM>(e);
+  if (stages & EMPC_STAGE_ROLLOUT) emu_rollout<DM>(e);
+  if (stages & EMPC_STAGE_SELECT) emu_select<DM>(e);
+}
+template <class DM>
+static int emu_row_doubles(Emu& e) {
+  return (int)stream_row_doubles<DM>(e.T);
+}
+template <class DM>
+static void emu_solve(Emu& e, int maxiter, int is_feasible) {
+  for (int b = 0; b < e.B; ++b) {
+    TrajState prev = e.st[b];
+    init_traj_state(e.st[b], e.H.P.prm, maxiter, is_feasible != 0, &prev);
+  }
+  if (e.H.P.prm.solver_type != EMPC_SOLVER_SBFDDP) std::fill(e.kff.begin(), e.kff.end(), 0.0);
+  emu_run_sweeps<DM>(e);
 }
 
 #define DISPATCH(e, FN, ...)                                                    \
@@ -499,5 +557,64 @@ void emu_phase_rollout(void* h, int ai, double* xs_try, double* us_try, double* 
     if (dv) dv[b] = e->try_dv[slot];
     if (ok) ok[b] = e->try_ok[slot];
   }
+}
+
+// ---- step-wise entry points (mirror of empc_solver_get_states / set_states / empc_sweep_batch / empc_select_batch) ----
+void emu_get_states(void* h, EmpcTrajState* out) {
+  Emu* e = static_cast<Emu*>(h);
+  std::memcpy(out, e->st.data(), sizeof(TrajState) * e->B);
+}
+void emu_set_states(void* h, const EmpcTrajState* in) {
+  Emu* e = static_cast<Emu*>(h);
+  std::memcpy(e->st.data(), in, sizeof(TrajState) * e->B);
+}
+void emu_sweep(void* h, int stages) {
+  Emu* e = static_cast<Emu*>(h);
+  DISPATCH(e, emu_sweep_stages, *e, stages);
+}
+void emu_set_trials(void* h, const int* ok, const double* cost, const double* dv) {
+  Emu* e = static_cast<Emu*>(h);
+  const size_t n = (size_t)e->B * e->NA;
+  if (ok) std::memcpy(e->try_ok.data(), ok, sizeof(int) * n);
+  if (cost) std::memcpy(e->try_cost.data(), cost, sizeof(double) * n);
+  if (dv) std::memcpy(e->try_dv.data(), dv, sizeof(double) * n);
+}
+void emu_get_trials(void* h, double* cost, double* dv, int* ok) {
+  Emu* e = static_cast<Emu*>(h);
+  const size_t n = (size_t)e->B * e->NA;
+  if (cost) std::memcpy(cost, e->try_cost.data(), sizeof(double) * n);
+  if (dv) std::memcpy(dv, e->try_dv.data(), sizeof(double) * n);
+  if (ok) std::memcpy(ok, e->try_ok.data(), sizeof(int) * n);
+}
+void emu_get_tape(void* h, double* tape) {
+  Emu* e = static_cast<Emu*>(h);
+  std::memcpy(tape, e->tape.data(), sizeof(double) * (e->tape.size() - 64));
+}
+void emu_get_gains(void* h, double* K, double* k, double* Vx) {
+  Emu* e = static_cast<Emu*>(h);
+  if (K) std::memcpy(K, e->K.data(), sizeof(double) * e->K.size());
+  if (k) std::memcpy(k, e->kff.data(), sizeof(double) * e->kff.size());
+  if (Vx) std::memcpy(Vx, e->Vx.data(), sizeof(double) * e->Vx.size());
+}
+void emu_set_gains(void* h, const double* K, const double* k) {
+  Emu* e = static_cast<Emu*>(h);
+  if (K) std::memcpy(e->K.data(), K, sizeof(double) * e->K.size());
+  if (k) std::memcpy(e->kff.data(), k, sizeof(double) * e->kff.size());
+}
+// streamed solves: n_jobs solves through the emulator's B slots; rows as empc_solver_stream_results
+int emu_stream_row_doubles(void* h) {
+  Emu* e = static_cast<Emu*>(h);
+  int n = 0;
+  if (e->nb == 1 && e->nrot == 6) n = emu_row_doubles<Dims<1, 6>>(*e);
+  else if (e->nb == 1 && e->nrot == 4) n = emu_row_doubles<Dims<1, 4>>(*e);
+  else if (e->nb == 3 && e->nrot == 6) n = emu_row_doubles<Dims<3, 6>>(*e);
+  else if (e->nb == 4 && e->nrot == 6) n = emu_row_doubles<Dims<4, 6>>(*e);
+  else if (e->nb == 6 && e->nrot == 6) n = emu_row_doubles<Dims<6, 6>>(*e);
+  return n;
+}
+int emu_stream_c(void* h, int n_jobs, const double* x0s, int maxiter, double* rows, long long* total_iters) {
+  Emu* e = static_cast<Emu*>(h);
+  DISPATCH(e, emu_stream, *e, n_jobs, x0s, maxiter, rows, total_iters);
+  return e->sweeps;
 }
 }

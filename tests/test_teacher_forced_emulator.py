@@ -1,0 +1,43 @@
+"""Teacher-forced parity of the kernel bodies on the CPU lane emulator (tests/stepwise.py): every iteration of the oracle's
+paths reproduced by the device code from the oracle's iterate, every iteration of the device's free-running paths
+reproduced by the oracle from the device's iterate, and the same minimiser from a common restart.  The GPU edition
+(tests/test_gpu_teacher_forced.py) runs the same driver through the C ABI on larger batches.
+Reference: the loop bodies of SolverSbFDDP::solveFDDP / solveDDP, src/sbfddp.cpp:241-311, 329-389."""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import stepwise as sw
+
+
+@pytest.fixture(scope="module")
+def emu():
+    return sw.load_emulator()
+
+
+@pytest.mark.parametrize("name,rollouts", [("displacement", 2), ("eagle_catch", 3)])
+def test_stepwise_parity_on_the_emulator(empc, problems, emu, name, rollouts):
+    _, problem = problems[name]
+    d = problem.desc
+    prm = ob.default_params()
+    x0s = empc.perturbed_x0s(problem.x0, rollouts, nq=d.model.nq)
+    rep = sw.stepwise_parity(lambda n, p2: sw.EmuBackend(emu, d, p2 if p2 is not None else prm, n), d, prm, x0s, chunk=64,
+                             tape_every=11, tight_maxiter=200)
+    assert rep["decisions_checked"] == rep["pairs"] > 0
+    assert rep["free_run"]["unexplained"] == 0
+    assert rep["same_minimum"]["xs_err_max"] < 1e-8  # (far inside the north-star bound: the restart is well conditioned)
+    print(name, {k: v for k, v in rep.items() if k != "max_rel"}, rep["max_rel"])
+
+
+def test_select_alone_follows_the_oracle(empc, problems, emu):
+    """The line-search decision in isolation (select_decide_state): fed with the ORACLE's trial costs and gap terms of real
+    iterates of the contact problem, it accepts the step the oracle accepted and leaves the scalars the oracle's trace holds
+    -- exactly, since no device arithmetic precedes it (src/sbfddp.cpp:260-311)."""
+    _, problem = problems["eagle_catch"]
+    d = problem.desc
+    prm = ob.default_params()
+    x0s = empc.perturbed_x0s(problem.x0, 2, nq=d.model.nq)
+    paths = sw.oracle_paths(d, prm, x0s)
+    pairs = [(b, i) for b in range(2) for i in range(len(paths[b]["iterates"]))]
+    checked = sw.select_in_isolation(lambda n: sw.EmuBackend(emu, d, prm, n), d, prm, x0s, paths, pairs)
+    assert checked == len(pairs)
