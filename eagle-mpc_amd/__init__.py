@@ -103,6 +103,7 @@ def lib():
     L.empc_solver_stream_begin.argtypes = [C.c_void_p, C.c_int, _dp]
     L.empc_solver_stream_run.argtypes = [C.c_void_p, C.c_int]
     L.empc_solver_stream_results.argtypes = [C.c_void_p, _dp, _ip]
+    L.empc_solver_stream_results_device.argtypes = [C.c_void_p, C.c_void_p]
     L.empc_plant_set_state.argtypes = [C.c_void_p, _dp]
     L.empc_plant_get_state.argtypes = [C.c_void_p, _dp]
     L.empc_plant_step.argtypes = [C.c_void_p, C.c_double, _dp, C.c_int]
@@ -587,6 +588,15 @@ class SolverSbFDDP:
         return dict(xs=rows[:, :nxs].reshape(-1, T_ + 1, nx).copy(), us=rows[:, nxs:nxs + nus].reshape(-1, T_, nu).copy(),
                     us_squash=rows[:, nxs + nus:nxs + 2 * nus].reshape(-1, T_, nu).copy(), cost=rows[:, nxs + 2 * nus].copy(),
                     iter=rows[:, nxs + 2 * nus + 1].astype(np.int32), status=rows[:, nxs + 2 * nus + 2].astype(np.int32))
+
+    def stream_row_doubles(self):
+        n = C.c_int()
+        _check(lib().empc_solver_stream_results(self._h, None, C.byref(n)))
+        return n.value
+
+    def stream_results_device(self, device_ptr):
+        """the result rows copied device to device to `device_ptr` (n_jobs x stream_row_doubles() doubles)"""
+        _check(lib().empc_solver_stream_results_device(self._h, C.c_void_p(device_ptr)))
 
     def solve_stream(self, x0s, maxiter=100):
         self.stream_begin(x0s)

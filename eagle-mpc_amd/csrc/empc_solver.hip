@@ -829,6 +829,17 @@ int empc_solver_stream_results(EmpcSolver* s, double* rows, int* row_doubles) {
   EMPC_CATCH(RET_INT)
 }
 
+int empc_solver_stream_results_device(EmpcSolver* s, double* dst_device) {
+  EMPC_TRY
+  if (!s || !dst_device) throw std::invalid_argument("NULL argument");
+  if (s->q_njobs < 1 || !s->dq_rows) throw std::invalid_argument("stream: nothing to fetch");
+  s->use();
+  HIP_CHECK(hipMemcpyAsync(dst_device, s->dq_rows, sizeof(double) * (size_t)s->q_njobs * stream_row(s), hipMemcpyDeviceToDevice, s->stream));
+  HIP_CHECK(hipStreamSynchronize(s->stream));
+  return EMPC_OK;
+  EMPC_CATCH(RET_INT)
+}
+
 // ---- step-wise entry points (include/empc.h): one iteration from any iterate -------------------------------------------
 int empc_solver_get_states(EmpcSolver* s, EmpcTrajState* states) {
   EMPC_TRY

@@ -189,6 +189,9 @@ int empc_solver_set_gains(EmpcSolver* s, const double* K, const double* k);
 int empc_solver_stream_begin(EmpcSolver* s, int n_jobs, const double* x0s /* n_jobs x nx */);
 int empc_solver_stream_run(EmpcSolver* s, int maxiter);
 int empc_solver_stream_results(EmpcSolver* s, double* rows /* n_jobs x row */, int* row_doubles);
+/* the same rows copied device to device (dst_device: n_jobs x row doubles of DEVICE memory, e.g. the send buffer of the
+ * multi-GPU gather): nothing of the payload touches the host */
+int empc_solver_stream_results_device(EmpcSolver* s, double* dst_device);
 
 /* offsets (in doubles) of the blocks inside one tape record */
 typedef struct EmpcTapeLayout {

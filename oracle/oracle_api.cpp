@@ -210,6 +210,19 @@ void oracle_iter_step(void* h, const double* xs, const double* us, const double*
   std::memcpy(scal_out, o, sizeof(o));
 }
 
+// gains and value-function gradient as the last backward pass left them (no recomputation: the box solvers' QPs depend on
+// their warm start, so a second backward pass is not the same computation)
+void oracle_get_gains(void* h, double* K, double* k, double* Vx) {
+  Solver* s = static_cast<Solver*>(h);
+  const int n = s->ndx, m = s->nu;
+  if (K)
+    for (int t = 0; t < s->T; ++t) std::memcpy(K + (size_t)t * m * n, s->K[t].data(), sizeof(double) * m * n);
+  if (k)
+    for (int t = 0; t < s->T; ++t) std::memcpy(k + (size_t)t * m, s->k[t].data(), sizeof(double) * m);
+  if (Vx)
+    for (int t = 0; t <= s->T; ++t) std::memcpy(Vx + (size_t)t * n, s->Vx[t].data(), sizeof(double) * n);
+}
+
 // squashingUpdate + barrierUpdate (src/sbfddp.cpp:462-477)
 void oracle_solver_set_smooth(void* h, double smooth) {
   Solver* s = static_cast<Solver*>(h);

@@ -68,6 +68,7 @@ def _bind(L):
     L.oracle_solver_get_iterate.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _ip, _dp, _dp]
     L.oracle_iter_probe.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _dp, _ip, _dp, _dp, _dp]
     L.oracle_iter_step.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _ip, _dp]
+    L.oracle_get_gains.argtypes = [C.c_void_p, _dp, _dp, _dp]
     L.oracle_solve_batch.restype = C.c_double
     L.oracle_solve_batch.argtypes = [C.POINTER(T.ProblemDesc), C.POINTER(T.SolverParams), C.c_int, _dp, C.c_int, C.c_int,
                                      _dp, _dp, _dp, _dp, _ip, _ip]
@@ -191,6 +192,14 @@ class OracleSolver:
         d.update(dict(zip(("steplength", "xreg", "cost", "cost_prev", "stop", "dV", "dVexp", "d0", "d1", "gapnorm"),
                           [float(v) for v in out])))
         return d
+
+    def last_gains(self):
+        """K, k, Vx as the last backward pass left them (no recomputation)"""
+        K = np.zeros((self.T, self.nu, self.ndx))
+        k = np.zeros((self.T, self.nu))
+        Vx = np.zeros((self.T + 1, self.ndx))
+        self.L.oracle_get_gains(self.h, P(K), P(k), P(Vx))
+        return K, k, Vx
 
     def node_calc(self, t, x, u, diff=True):
         n, m = self.ndx, self.nu

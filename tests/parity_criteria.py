@@ -1,35 +1,15 @@
-"""Parity criterion for the ill-conditioned workloads (perturbed eagle_catch, perturbed hover).  Test infrastructure:
-used by tests/ and by bench.py's parity / cpu_baseline leg, never by the product path.
+"""Statistics of a free-running batch against the oracle (perturbed eagle_catch, perturbed hover).  Test infrastructure:
+used by tests/ and by bench.py's parity leg, never by the product path.
 
-Why a criterion of its own.  profiles/r02_oracle_sensitivity.json (tools/oracle_sensitivity.py) solves the same 256
-perturbed eagle_catch rollouts with the oracle and with two rounding-only variants of the oracle itself: the same sources
-with FMA contraction, and the same binary with every component of x0 moved to the adjacent double.  Against the oracle
-those variants end with the same iteration count and within 1e-4 on xs/us on 178 resp. 185 of the 239 rollouts the oracle
-solves -- the GPU solver's figure is 183 (profiles/r01_parity_sweep.json).  The iteration paths part ways (a cost that
-differs by 1e-6 relative, or another step length) as early as iteration 3, at the median around iteration 17-21 of ~40.
-A 1e-4 bound on the final xs/us of EVERY perturbed rollout is therefore not a property any two correct FP64
-implementations of this algorithm share on this problem; the well-conditioned workloads (displacement, push_slide, the
-unperturbed YAML states) keep the plain bound.  What does survive, and is checked here on the GPU result:
-
-  A  early path       the first EARLY_K iteration records (pass, iteration, step length, feasibility, regularisation
-                      exactly; cost to 1e-5 relative) agree with the oracle on every sampled rollout, and the median first
-                      divergent iteration is >= MEDIAN_FIRST_DIVERGENCE_MIN
-  B  agreement rate   among the rollouts the oracle solves, the share with the same iteration count and xs/us within 1e-4
-                      is >= AGREEMENT_MIN (oracle vs its own variants: 0.745 / 0.774)
-  C  cost statistics  median relative cost difference among rollouts solved by both <= 1e-6 (oracle variants: 4e-9, 8e-9)
-  D  same problem     the oracle's cost evaluated at the GPU's (xs, us) equals the GPU's cost to 1e-9 relative, and the
-                      GPU's xs is the rollout of its us under the ORACLE's dynamics (one-step defects <= 1e-8) wherever
-                      the GPU reports convergence  -- i.e. both minimise the same function over the same feasible set
-  E  stationarity     at the GPU's converged points the oracle's own expected cost reduction of one more full step,
-                      |d0 + d1 / 2| (the Newton decrement the acceptance test uses, src/sbfddp.cpp:268-270), is of the
-                      order of the stopping threshold: <= max(10 th_stop, 3 x the largest value at the oracle's own
-                      converged points of the sample)
-"""
+These numbers are REPORTED, not asserted: the free-running iteration paths of the contact problem are rounding-sensitive
+(profiles/r02_oracle_sensitivity.json: the oracle against its own FMA build ends with the same iteration count and within
+1e-4 on 178 of 239 rollouts), so no threshold on an agreement rate says anything about the device code.  The parity claim
+is made step by step by tests/stepwise.py (teacher-forced in both directions + the same minimiser from a common restart).
+What IS asserted from here: both sides solve the same problem -- the oracle's cost at the GPU's final point equals the
+GPU's cost (1e-9) and the GPU's xs is the rollout of its us under the oracle's dynamics (defect 1e-8)."""
 import numpy as np
 
-EARLY_K = 3
-MEDIAN_FIRST_DIVERGENCE_MIN = 8
-AGREEMENT_MIN = 0.65
+EARLY_K = 3  # (only used to report how many rollouts share their first records with the oracle)
 TOL = 1e-4
 
 
@@ -107,18 +87,3 @@ def sample_checks(ob, d, x0s, gpu, gpu_traces, sample, final_smooth, th_stop, ma
             "expected_reduction_next_step_gpu_max": float(max(dec_gpu)) if dec_gpu else None,
             "expected_reduction_next_step_oracle_max": float(max(dec_ref)) if dec_ref else None,
             "expected_reduction_bound": float(bound_e)}
-
-
-def verdict(stats, smp):
-    """the five criteria as booleans + overall"""
-    v = {"A_early_path": smp["early_path_ok"] == len(smp["sample"]) and
-         smp["first_divergent_iteration_min_median"][1] >= MEDIAN_FIRST_DIVERGENCE_MIN,
-         "B_agreement_rate": stats["agreement_rate_among_oracle_solved"] >= AGREEMENT_MIN,
-         "C_cost_median": stats["cost_rel_err_median_solved_by_both"] is not None and
-         stats["cost_rel_err_median_solved_by_both"] <= 1e-6,
-         "D_same_problem": smp["oracle_cost_at_gpu_point_rel_err_max"] is not None and
-         smp["oracle_cost_at_gpu_point_rel_err_max"] <= 1e-9 and smp["oracle_dynamics_defect_at_gpu_point_max"] <= 1e-8,
-         "E_stationarity": smp["expected_reduction_next_step_gpu_max"] is not None and
-         smp["expected_reduction_next_step_gpu_max"] <= smp["expected_reduction_bound"]}
-    v["all"] = all(v.values())
-    return v

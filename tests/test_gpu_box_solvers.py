@@ -21,13 +21,12 @@ def box_problem(empc, name, dt):
     return tr, tr.createProblem(dt, False, "IntegratedActionModelEuler")
 
 
-# Cold starts that do not converge within the iteration budget and whose iteration path is rounding-sensitive: the oracle
-# against its own -ffp-contract=fast build differs by 15..50 on xs (hover, BoxFDDP) and up to 5 (eagle_catch), measured with
-# `tools/oracle_sensitivity.py --options` on exactly these batches (profiles/r02_oracle_sensitivity_options.json).  They are compared through their iteration
-# records (the first few of every rollout; the number = what the oracle's two builds themselves share: first divergent record
-# 2,4,2,7,2,2,6,6 on hover -- its cold start costs 2.5e9 after the first rollout -- and 12..30 on eagle_catch); the others
-# at the north-star bound.
-ILL_CONDITIONED = {("hover", 1): 2, ("eagle_catch", 1): 6, ("eagle_catch", 2): 6}
+# Cold starts whose free-running iteration path is rounding-sensitive (they do not converge within the iteration budget; the
+# oracle against its own -ffp-contract=fast build differs by 15..50 on xs for hover / BoxFDDP and up to 5 for eagle_catch,
+# `tools/oracle_sensitivity.py --options`, profiles/r02_oracle_sensitivity_options.json): their parity claim is the
+# step-wise one of tests/test_gpu_teacher_forced.py::test_box_solvers (every iteration reproduced from the other side's
+# iterate); here they are only required to stay finite and inside the control limits.  The others: the plain bound.
+STEPWISE_ONLY = {("hover", 1), ("eagle_catch", 1), ("eagle_catch", 2)}
 
 
 @pytest.mark.parametrize("solver_type", [1, 2])
@@ -35,15 +34,12 @@ ILL_CONDITIONED = {("hover", 1): 2, ("eagle_catch", 1): 6, ("eagle_catch", 2): 6
 def test_box_solve_matches_oracle(empc, name, dt, solver_type):
     """Cold start on a batch of perturbed initial states: same status as the oracle, controls inside their limits,
     us_squash equal to us (no squashing data), and trajectories within the north-star bound (1e-4 on the controls) --
-    or, for the rounding-sensitive cases, the same first iterations record by record."""
-    import parity_criteria as pc
-
+    the rounding-sensitive cold starts are judged step by step elsewhere (STEPWISE_ONLY)."""
     tr, problem = box_problem(empc, name, dt)
     d = problem.desc
     B, maxiter = 8, 30
     x0s = empc.perturbed_x0s(problem.x0, B, nq=d.model.nq)
     solver = getattr(empc, CLASSES[solver_type])(problem, batch=B)
-    solver.enable_trace(64)
     solver.solve([], [], maxiter, x0s=x0s)
     prm = ob.default_params()
     prm.solver_type = solver_type
@@ -53,14 +49,8 @@ def test_box_solve_matches_oracle(empc, name, dt, solver_type):
     us = solver.us_batch
     assert np.isfinite(us).all() and (us >= lb - 1e-12).all() and (us <= ub + 1e-12).all()
     assert np.array_equal(solver.us_squash_batch, us)  # no squashing: us_squash is us
-    if (name, solver_type) in ILL_CONDITIONED:
-        for b in range(B):
-            o = ob.OracleSolver(d, prm)
-            o.set_x0(x0s[b])
-            o.solve(None, None, maxiter)
-            tg, to = solver.trace(b), o.trace()
-            need = ILL_CONDITIONED[(name, solver_type)]
-            assert pc.first_divergence(tg, to) >= min(need, len(to)), (b, pc.first_divergence(tg, to))
+    if (name, solver_type) in STEPWISE_ONLY:
+        assert np.isfinite(solver.xs_batch).all()
         return
     assert np.array_equal(solver.iter_batch, ref["iter"]), (solver.iter_batch, ref["iter"])
     assert np.array_equal(solver.status_batch, ref["status"]), (solver.status_batch, ref["status"])

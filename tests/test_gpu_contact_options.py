@@ -24,23 +24,18 @@ def test_contact_options_phase_parity(empc, tmp_path, contact, gains):
 
 @pytest.mark.parametrize("contact,gains", VARIANTS)
 def test_contact_options_solve(empc, tmp_path, contact, gains):
-    """Full solves: the unperturbed problem and three perturbed initial states.  The contact problem's iteration path is
-    rounding-sensitive (profiles/r02_oracle_sensitivity.json), so a rollout must match the oracle either completely
-    (iterations, status, 1e-4 on xs / us) or on its first iterations record by record, and every rollout the GPU reports as
-    solved must be a solution of the same problem: the oracle's cost and gaps at the returned trajectory."""
+    """Full free-running solves: the unperturbed problem and three perturbed initial states.  A rollout either matches the
+    oracle completely (iterations, status, 1e-4 on xs / us) or -- the contact problem's iteration path is rounding-sensitive,
+    most of all with six constraint rows on this 9-dof arm -- it is covered by the step-wise parity of
+    tests/test_gpu_teacher_forced.py::test_contact_options (every iteration from the other side's iterate, same minimiser).
+    Asserted here on every rollout the GPU reports as solved: it is a solution of the same problem (the oracle's cost and
+    gaps at the returned trajectory)."""
     _, problem = contact_variant(empc, tmp_path, contact, gains)
     d = problem.desc
-    # six constraint rows on this 9-dof arm leave the KKT system (Jc M^-1 Jc^T) poorly conditioned: the oracle against its own
-    # -ffp-contract=fast build already differs by 2e-8..9e-8 (relative) in the cost of the FIRST iteration and takes another
-    # path from record 2..7 on (`tools/oracle_sensitivity.py --options`, profiles/r02_oracle_sensitivity_options.json, on exactly these inputs; the 3D contact:
-    # 1e-9 and record 37..43).  So for the 6D contact only the first record is required to agree (1e-5), next to the
-    # phase-level parity above and the same-problem checks below.
-    early = 1 if contact == "ContactModel6D" else pc.EARLY_K
     B = 4
     x0s = empc.perturbed_x0s(problem.x0, B, nq=d.model.nq, amplitude=0.02)
     x0s[0] = problem.x0
     s = empc.SolverSbFDDP(problem, batch=B)
-    s.enable_trace(256)
     s.solve([], [], 100, x0s=x0s)
     prm = empc.default_params()
     full = 0  # rollouts that agree completely (informational: printed with -s)
@@ -52,8 +47,6 @@ def test_contact_options_solve(empc, tmp_path, contact, gains):
         same = (s.iter_batch[b] == r["iter"] and s.status_batch[b] == r["status"]
                 and np.abs(s.xs_batch[b] - r["xs"]).max() < 1e-4 and np.abs(s.us_batch[b] - r["us"]).max() < 1e-4)
         full += int(same)
-        if not same:
-            assert pc.first_divergence(s.trace(b), o.trace()) >= early, (b, pc.first_divergence(s.trace(b), o.trace()))
         if pc.solved(s.status_batch[b:b + 1], s.cost_batch[b:b + 1])[0]:
             o2 = ob.OracleSolver(d)
             o2.set_x0(x0s[b])

@@ -1,0 +1,43 @@
+"""Streamed solves on the GPU (empc_solver_stream_begin / _run / _results): a queue of initial states pushed through fewer
+slots than jobs gives, row by row, bitwise the result of plain batched solves of the same initial states.  Reference: one
+SolverSbFDDP::solve([], [], maxiter) per initial state (src/sbfddp.cpp:192-226)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name,slots,jobs", [("eagle_catch", 64, 200), ("displacement", 32, 96), ("hover", 16, 40)])
+def test_stream_rows_equal_plain_solves(empc, problems, name, slots, jobs):
+    _, problem = problems[name]
+    d = problem.desc
+    x0s = empc.perturbed_x0s(problem.x0, jobs, nq=d.model.nq, amplitude=0.05 if name != "hover" else 0.01)
+    plain = empc.SolverSbFDDP(problem, batch=jobs)
+    plain.solve([], [], 100, x0s=x0s)
+    s = empc.SolverSbFDDP(problem, batch=slots)
+    r = s.solve_stream(x0s, 100)
+    assert np.array_equal(r["iter"], plain.iter_batch) and np.array_equal(r["status"], plain.status_batch)
+    assert np.array_equal(r["xs"], plain.xs_batch) and np.array_equal(r["us"], plain.us_batch)
+    assert np.array_equal(r["us_squash"], plain.us_squash_batch)
+    assert np.array_equal(r["cost"], plain.cost_batch)
+    st = s.stats()
+    assert st["total_iters"] == int((plain.iter_batch + 1).sum())
+    # the queue keeps the slots busy: fewer sweeps than the jobs solved batch after batch of `slots`
+    batches = [plain.iter_batch[i:i + slots] for i in range(0, jobs, slots)]
+    assert st["sweeps"] <= sum(int(b.max()) + 1 for b in batches) + len(batches)
+    # a second stream on the same solver (other queue length) works and a plain solve afterwards is unaffected
+    r2 = s.solve_stream(x0s[:slots // 2], 100)
+    assert np.array_equal(r2["xs"], plain.xs_batch[:slots // 2])
+    s.solve([], [], 100, x0s=x0s[:slots])
+    assert np.array_equal(s.xs_batch, plain.xs_batch[:slots])
+
+
+def test_stream_argument_errors(empc, problems):
+    _, problem = problems["hover"]
+    s = empc.SolverSbFDDP(problem, batch=2)
+    with pytest.raises(empc.EmpcError, match="stream_begin"):
+        s.stream_run(10)
+    s.enable_trace(8)
+    s.stream_begin(np.tile(problem.x0, (3, 1)))
+    with pytest.raises(empc.EmpcError, match="trace"):
+        s.stream_run(10)
