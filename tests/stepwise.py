@@ -493,8 +493,8 @@ def teacher_forced(backend_factory, desc, prm, x0s, paths, maxiter=100, chunk=10
                     upd("dV", abs(f.dV - r[7]) / (sc + abs(r[7])))
                     assert abs(f.dV - r[7]) <= max(1e-8 * amp * (sc + abs(r[7])), NOISE_FACTOR * sn["dV"]), (where, f.dV, r[7], sn)
                     assert abs(f.dVexp - r[8]) <= max(1e-7 * amp * (sc + abs(r[8])), NOISE_FACTOR * sn["dVexp"]), (where, f.dVexp, r[8], sn)
-            else:
-                assert (f.status & T.STATUS_REG_MAX) != 0, where
+            # (an iteration without a record ended its pass at reg_max: `ended` and `returned` above are its whole outcome -- the
+            #  status bits are cleared when the next pass starts)
             # the accepted candidate is the oracle's next iterate
             if it["accepted_alpha"] >= 0 and i + 1 < len(paths[b]["iterates"]):
                 nxt = paths[b]["iterates"][i + 1]

@@ -16,10 +16,11 @@ def test_stream_rows_equal_plain_solves(empc, problems, name, slots, jobs):
     plain.solve([], [], 100, x0s=x0s)
     s = empc.SolverSbFDDP(problem, batch=slots)
     r = s.solve_stream(x0s, 100)
+    # (bitwise, NaNs of rollouts that blow up included: equal_nan)
     assert np.array_equal(r["iter"], plain.iter_batch) and np.array_equal(r["status"], plain.status_batch)
-    assert np.array_equal(r["xs"], plain.xs_batch) and np.array_equal(r["us"], plain.us_batch)
-    assert np.array_equal(r["us_squash"], plain.us_squash_batch)
-    assert np.array_equal(r["cost"], plain.cost_batch)
+    assert np.array_equal(r["xs"], plain.xs_batch, equal_nan=True) and np.array_equal(r["us"], plain.us_batch, equal_nan=True)
+    assert np.array_equal(r["us_squash"], plain.us_squash_batch, equal_nan=True)
+    assert np.array_equal(r["cost"], plain.cost_batch, equal_nan=True)
     st = s.stats()
     assert st["total_iters"] == int((plain.iter_batch + 1).sum())
     # the queue keeps the slots busy: fewer sweeps than the jobs solved batch after batch of `slots`
@@ -27,9 +28,9 @@ def test_stream_rows_equal_plain_solves(empc, problems, name, slots, jobs):
     assert st["sweeps"] <= sum(int(b.max()) + 1 for b in batches) + len(batches)
     # a second stream on the same solver (other queue length) works and a plain solve afterwards is unaffected
     r2 = s.solve_stream(x0s[:slots // 2], 100)
-    assert np.array_equal(r2["xs"], plain.xs_batch[:slots // 2])
+    assert np.array_equal(r2["xs"], plain.xs_batch[:slots // 2], equal_nan=True)
     s.solve([], [], 100, x0s=x0s[:slots])
-    assert np.array_equal(s.xs_batch, plain.xs_batch[:slots])
+    assert np.array_equal(s.xs_batch, plain.xs_batch[:slots], equal_nan=True)
 
 
 def test_stream_argument_errors(empc, problems):
