@@ -497,7 +497,10 @@ def main():
             "trajectory_iters_per_s": iters_total / elapsed,
             "mean_iters_per_trajectory": iters_total / (B * world * args.steps),
             "sweeps_per_step": agg["sweeps"] / args.steps,
-            "kernel_ms_per_step": {k: kern[k][0] / args.steps for k in kern},
+            # (per-launch averages of the timed sweeps x sweeps per step: every EMPC_TIMING_EVERY-th sweep carries events)
+            "kernel_ms_per_step": {k: kern[k][0] / max(kern[k][1], 1) * agg["sweeps"] / args.steps for k in kern},
+            "other_kernels_avg_ms": {"select": agg["ms_select"] / max(agg["n_select"], 1), "calc": agg["ms_calc"] / max(agg["n_calc"], 1)},
+            "ms_per_sweep": elapsed * 1e3 / max(agg["sweeps"], 1),
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": "profiles/traffic_%s_%s.json (committed PMC pass, full batch)" % (args.config, dom) if traffic else None,

@@ -193,6 +193,20 @@ class Problem:
             pass
 
 
+class SquashingModelSmoothSat:
+    """Mirror of crocoddyl.SquashingModelSmoothSat(u_lb, u_ub, ns) as the reference builds it (src/trajectory.cpp:49-50):
+    plain data -- the limits of the smooth saturation sigma(s) and its smoothing.  The HIP kernels take the limits from the
+    problem (EmpcProblemDesc.u_lb / u_ub, the same numbers); a solver given a squashing model checks that they agree."""
+
+    def __init__(self, u_lb, u_ub, ns):
+        self.u_lb = np.asarray(u_lb, dtype=np.float64).copy()
+        self.u_ub = np.asarray(u_ub, dtype=np.float64).copy()
+        assert self.u_lb.shape == self.u_ub.shape == (int(ns),)
+        self.ns = int(ns)
+        self.s_lb, self.s_ub = self.u_lb.copy(), self.u_ub.copy()  # SquashingModelSmoothSat: s_lb = u_lb, s_ub = u_ub
+        self.smooth = 0.1
+
+
 class Trajectory:
     """Mirror of eagle_mpc.Trajectory (bindings/python/eagle_mpc/trajectory.hpp:24-63)."""
 
@@ -243,6 +257,12 @@ class Trajectory:
         _check(lib().empc_trajectory_get_platform(self._h, _ptr(tau_f), _ptr(lb), _ptr(ub), C.byref(n)))
         return tau_f, lb, ub
 
+    @property
+    def squash(self):
+        """get_squash(): SquashingModelSmoothSat(u_lb, u_ub, nu) of the platform (src/trajectory.cpp:49-50)"""
+        _, lb, ub = self.platform()
+        return SquashingModelSmoothSat(lb, ub, self.nu)
+
     def stage_info(self, i):
         name = C.create_string_buffer(64)
         v = [C.c_int() for _ in range(4)]
@@ -276,6 +296,35 @@ def default_params():
     return p
 
 
+class IterationRecord:
+    """What a crocoddyl callback reads from the solver after one iteration (names of crocoddyl.SolverAbstract)."""
+
+    def __init__(self, r, solver):
+        self.phase, self.iter = int(r[0]), int(r[1])
+        self.cost, self.stop, self.x_reg, self.u_reg, self.stepLength = float(r[2]), float(r[3]), float(r[4]), float(r[4]), float(r[5])
+        self.is_feasible = bool(r[6])
+        self.dV, self.dVexp, self.gap_norm, self.d = float(r[7]), float(r[8]), float(r[9]), (float(r[10]), float(r[11]))
+        self.solver = solver
+
+
+class CallbackVerbose:
+    """crocoddyl.CallbackVerbose: one line per iteration (iter, cost, stop, grad, xreg, ureg, step, feasibility)."""
+
+    def __init__(self, stream=None):
+        self.stream = stream
+        self.lines = []
+
+    def __call__(self, rec):
+        if rec.iter % 10 == 0 and (not self.lines or rec.iter == 0):
+            self._emit("iter \t cost \t      stop \t    grad \t  xreg \t      ureg \t step \t feas")
+        self._emit("%4d  %0.5e  %0.5e  %0.5e  %10.5e  %10.5e   %0.4f     %d" %
+                   (rec.iter, rec.cost, rec.stop, -rec.d[1], rec.x_reg, rec.u_reg, rec.stepLength, int(rec.is_feasible)))
+
+    def _emit(self, line):
+        self.lines.append(line)
+        print(line, file=self.stream)
+
+
 class SolverSbFDDP:
     """Batched mirror of eagle_mpc.SolverSbFDDP (bindings/python/eagle_mpc/sbfddp.hpp:24-80).
 
@@ -285,9 +334,22 @@ class SolverSbFDDP:
 
     SOLVER_TYPE = T.SOLVER_SBFDDP
 
-    def __init__(self, problem, batch=1, device=0, params=None):
+    def __init__(self, problem, squashing_model=None, *, batch=1, device=0, params=None):
+        """SolverSbFDDP(problem, squashing_model) as in the reference (include/eagle_mpc/sbfddp.hpp:39-40,
+        examples/python/trajectory.py:20-21: ``SolverSbFDDP(problem, trajectory.squash)``); keyword-only extensions:
+        ``batch`` rollouts of the problem on HIP device ``device``."""
         self.problem = problem
         self.batch = int(batch)
+        if squashing_model is not None:
+            if not isinstance(squashing_model, SquashingModelSmoothSat):
+                raise TypeError("squashing_model must be a SquashingModelSmoothSat (e.g. trajectory.squash)")
+            d = problem.desc
+            lb = np.array([d.u_lb[i] for i in range(d.nu)])
+            ub = np.array([d.u_ub[i] for i in range(d.nu)])
+            if squashing_model.ns != d.nu or not (np.array_equal(squashing_model.u_lb, lb) and np.array_equal(squashing_model.u_ub, ub)):
+                raise EmpcError("squashing model does not belong to this problem (control limits differ)")
+        self.squashing_model = squashing_model
+        self._callbacks = []
         prm = T.SolverParams.from_buffer_copy(params) if params is not None else default_params()
         prm.solver_type = self.SOLVER_TYPE
         h = lib().empc_solver_create(C.byref(problem.desc), C.byref(prm), self.batch, int(device))
@@ -299,6 +361,28 @@ class SolverSbFDDP:
         _, self.T, self.nx, self.ndx, self.nu, self.rec = [x.value for x in v]
         self._convergence_init = prm.convergence_init
         self._n_alphas = prm.n_alphas
+
+    # -- callbacks (SolverAbstract::setCallbacks; examples/python/trajectory.py:25) ----------------------------------------
+    def setCallbacks(self, callbacks):
+        """Callables invoked once per DDP iteration of trajectory 0 with a record of that iteration (attributes iter, cost,
+        stop, x_reg, u_reg, stepLength, dV, dVexp, is_feasible, phase ...).  The solve runs entirely on the device, so the
+        callbacks are replayed from the device iteration trace right after solve() returns, in iteration order -- the same
+        information at the same granularity as crocoddyl's per-iteration hook (src/sbfddp.cpp:303-307, 381-385)."""
+        self._callbacks = list(callbacks)
+        if self._callbacks and not getattr(self, "_trace_cap", 0):
+            self.enable_trace(512)
+
+    def getCallbacks(self):
+        return list(self._callbacks)
+
+    def _replay_callbacks(self):
+        if not self._callbacks:
+            return
+        xs, us = None, None
+        for r in self.trace(0):
+            rec = IterationRecord(r, self)
+            for cb in self._callbacks:
+                cb(rec)
 
     # -- reference API -------------------------------------------------------------------------------------
     def solve(self, init_xs=None, init_us=None, maxiter=100, is_feasible=False, regInit=1e-9, x0s=None):
@@ -319,6 +403,7 @@ class SolverSbFDDP:
             if init_xs != "previous" or init_us != "previous":
                 raise ValueError("init_xs / init_us must both be 'previous' to reuse the last solution")
             _check(lib().empc_solver_solve(self._h, int(maxiter), int(bool(is_feasible))))
+            self._replay_callbacks()
             return True
         xs = us = None
         if init_xs is not None and len(init_xs):
@@ -333,6 +418,7 @@ class SolverSbFDDP:
             assert us.shape == (B, T_, nu)
         _check(lib().empc_solver_set_warmstart(self._h, _ptr(xs), _ptr(us)))
         _check(lib().empc_solver_solve(self._h, int(maxiter), int(bool(is_feasible))))
+        self._replay_callbacks()
         return True
 
     @property

@@ -76,6 +76,11 @@ struct DevBuffers {
   const int* act_list = nullptr;
   const int* act_count = nullptr;
   int* act_list_out = nullptr;
+  // trajectories whose pass starts in the next sweep (need_calc): the calc kernel walks this list instead of scanning the batch
+  const int* calc_list = nullptr;
+  const int* calc_count = nullptr;
+  int* calc_list_out = nullptr;
+  int* calc_count_out = nullptr;
   // hand-over of the counters without host commands in the stream: select zeroes the counters of the NEXT sweep's slot
   // (nobody reads them any more) and the last workgroup to finish publishes the active count to pinned host memory
   int* counters_next = nullptr;   // {n_active, lin_count} of the other sweep slot
@@ -709,28 +714,32 @@ EMPC_HD void select_decide(const DevBuffers& D, int b, int& accepted_ai, int& la
   D.st[b] = st;
 }
 
-// copy helper used by select: candidate <- trial slot `ai` (xs, us, acc); threads cooperate
+// copy helper used by select: candidate <- trial slot `ai` (xs, us, acc); threads cooperate.  Four independent loads per
+// thread are issued before the first store (the copy is a chain of memory latencies otherwise).
+EMPC_HD void copy_doubles(double* dst, const double* src, int n, int tid, int nthreads) {
+  int i = tid;
+  for (; i + 3 * nthreads < n; i += 4 * nthreads) {
+    const double a = src[i], b = src[i + nthreads], c = src[i + 2 * nthreads], d = src[i + 3 * nthreads];
+    dst[i] = a;
+    dst[i + nthreads] = b;
+    dst[i + 2 * nthreads] = c;
+    dst[i + 3 * nthreads] = d;
+  }
+  for (; i < n; i += nthreads) dst[i] = src[i];
+}
 template <class DM>
 EMPC_HD void select_copy(const DevBuffers& D, int b, int accepted_ai, int last_ai, int tid, int nthreads) {
   const int T = D.T, NA = D.NA;
   if (accepted_ai >= 0) {
     const size_t slot = (size_t)b * NA + accepted_ai;
-    const double* xs_i = D.xs_try + slot * (T + 1) * DM::NX;
-    const double* us_i = D.us_try + slot * T * DM::NU;
-    const double* ac_i = D.acc_try + slot * (T + 1) * DM::NACC;
-    double* xs_o = D.xs + (size_t)b * (T + 1) * DM::NX;
-    double* us_o = D.us + (size_t)b * T * DM::NU;
-    double* ac_o = D.acc + (size_t)b * (T + 1) * DM::NACC;
-    for (int i = tid; i < (T + 1) * DM::NX; i += nthreads) xs_o[i] = xs_i[i];
-    for (int i = tid; i < T * DM::NU; i += nthreads) us_o[i] = us_i[i];
-    for (int i = tid; i < (T + 1) * DM::NACC; i += nthreads) ac_o[i] = ac_i[i];
+    copy_doubles(D.xs + (size_t)b * (T + 1) * DM::NX, D.xs_try + slot * (T + 1) * DM::NX, (T + 1) * DM::NX, tid, nthreads);
+    copy_doubles(D.us + (size_t)b * T * DM::NU, D.us_try + slot * T * DM::NU, T * DM::NU, tid, nthreads);
+    copy_doubles(D.acc + (size_t)b * (T + 1) * DM::NACC, D.acc_try + slot * (T + 1) * DM::NACC, (T + 1) * DM::NACC, tid, nthreads);
   }
   if (last_ai >= 0) {
     // fillSquashedOutputs reads the data of the LAST calc at every node: the last trial that was rolled out
     const size_t slot = (size_t)b * NA + last_ai;
-    const double* us_i = D.us_try + slot * T * DM::NU;
-    double* ul = D.us_last + (size_t)b * T * DM::NU;
-    for (int i = tid; i < T * DM::NU; i += nthreads) ul[i] = us_i[i];
+    copy_doubles(D.us_last + (size_t)b * T * DM::NU, D.us_try + slot * T * DM::NU, T * DM::NU, tid, nthreads);
   }
 }
 

@@ -57,11 +57,12 @@ KernelTable empc_table_6_6();
 template <class DM, int CT>
 __global__ void __launch_bounds__(64) k_calc(DevBuffers D) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  const int n = D.B * (D.T + 1);
-  if (idx >= n) return;
-  // consecutive lanes = consecutive trajectories of the same node (same cost set -> no divergence)
-  const int t = idx / D.B, b = idx % D.B;
-  calc_thread<DM, CT>(D, b, t);
+  // consecutive lanes = consecutive trajectories of the same node (same cost set -> no divergence); with the list of the
+  // trajectories that start a pass (written by the previous sweep's select) only those are walked
+  const int nb = D.calc_list ? *D.calc_count : D.B;
+  if (idx >= nb * (D.T + 1)) return;
+  const int t = idx / nb, i = idx % nb;
+  calc_thread<DM, CT>(D, D.calc_list ? D.calc_list[i] : i, t);
 }
 
 template <class DM, int CT>
@@ -228,13 +229,14 @@ __global__ void __launch_bounds__(64) k_backward4(DevBuffers D) {
 }
 
 template <class DM>
-__global__ void __launch_bounds__(64) k_select(DevBuffers D) {
+__global__ void __launch_bounds__(256) k_select(DevBuffers D) {
   __shared__ int sh[3];
   const int b = blockIdx.x;
   if (threadIdx.x == 0) {
     if (b == 0 && D.counters_next) {  // every reader of the other slot's counters ran before this kernel
       D.counters_next[0] = 0;
       D.counters_next[1] = 0;
+      D.counters_next[2] = 0;
     }
     int acc_ai, last_ai;
     select_decide<DM>(D, b, acc_ai, last_ai);
@@ -269,6 +271,7 @@ __global__ void __launch_bounds__(64) k_select(DevBuffers D) {
       const int pos = atomicAdd(D.n_active, 1);
       if (D.act_list_out) D.act_list_out[pos] = b;
       if (D.lin_count_out && D.st[b].need_lin) D.lin_list_out[atomicAdd(D.lin_count_out, 1)] = b;
+      if (D.calc_count_out && D.st[b].need_calc) D.calc_list_out[atomicAdd(D.calc_count_out, 1)] = b;
     }
     if (D.host_active) {
       __threadfence();
@@ -483,7 +486,7 @@ static void launch_rollout(DevBuffers D, hipStream_t s) {
 }
 template <class DM>
 static void launch_select(DevBuffers D, hipStream_t s) {
-  hipLaunchKernelGGL(k_select<DM>, dim3(D.B), dim3(64), 0, s, D);
+  hipLaunchKernelGGL(k_select<DM>, dim3(D.B), dim3(256), 0, s, D);
 }
 template <class DM>
 static void launch_squash_out(DevBuffers D, double* out, hipStream_t s) {

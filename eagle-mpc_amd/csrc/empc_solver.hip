@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -67,6 +68,7 @@ struct EmpcSolver {
   int* dlin_knots = nullptr;
   int* dlin_list = nullptr;  // [2][B] linearize lists of the two sweep slots
   int* dact_list = nullptr;  // [2][B] lists of the trajectories still iterating, same slots
+  int* dcalc_list = nullptr; // [2][B] lists of the trajectories that start a pass (need_calc), same slots
   double* dscratch = nullptr;  // output staging (squashed controls)
   double* dplant_x = nullptr;  // [B][NX] plant states of closed-loop runs (empc_plant_*)
   double* dplant_u = nullptr;  // [B][NU] staging of caller-supplied plant controls
@@ -296,11 +298,12 @@ EmpcSolver* empc_solver_create(const EmpcProblemDesc* problem, const EmpcSolverP
   D.try_dv = s->dalloc<double>(B * NA);
   D.try_ok = s->dalloc<int>(B * NA);
   D.us_last = s->dalloc<double>(B * T * k.nu);
-  D.n_active = s->dalloc<int>(4 * EmpcSolver::MAX_STREAMS);  // per chunk and sweep slot: {active trajectories, entries of the linearize list}
+  D.n_active = s->dalloc<int>(6 * EmpcSolver::MAX_STREAMS);  // per chunk and sweep slot: {active trajectories, entries of the linearize list, of the calc list}
   s->dticket = s->dalloc<int>(EmpcSolver::MAX_STREAMS);
   HIP_CHECK(hipMemsetAsync(s->dticket, 0, sizeof(int) * EmpcSolver::MAX_STREAMS, s->stream));
   s->dlin_list = s->dalloc<int>(2 * (size_t)batch);          // per sweep slot: the linearize list of every chunk, chunk after chunk
   s->dact_list = s->dalloc<int>(2 * (size_t)batch);
+  s->dcalc_list = s->dalloc<int>(2 * (size_t)batch);
   D.dbg = s->dalloc<unsigned long long>(64);
   HIP_CHECK(hipMemsetAsync(D.dbg, 0, 64 * sizeof(unsigned long long), s->stream));
   D.B = batch;
@@ -566,7 +569,7 @@ static DevBuffers chunk_view(const EmpcSolver* s, int b0, int nb, int idx) {
   D.try_ok += (size_t)b0 * NA;
   D.us_last += (size_t)b0 * T * k.nu;
   if (D.trace) D.trace += (size_t)b0 * D.trace_cap * EMPC_TRACE_WORDS;
-  D.n_active = s->D.n_active + 4 * idx;
+  D.n_active = s->D.n_active + 6 * idx;
   D.B = nb;
   return D;
 }
@@ -612,35 +615,49 @@ static void run_sweeps(EmpcSolver* s, int hard_cap) {
   // for the host round trip between sweeps; the one surplus sweep at the end is empty and is not counted.
   // Chunks start staggered -- chunk c waits for chunk c-1's first backward pass.
   std::vector<int> queued(nchunks, 0), retired(nchunks, 0);
+  std::vector<std::array<bool, 2>> timed_slot(nchunks, std::array<bool, 2>{false, false});
+  static const int timing_every = [] {
+    const char* e = std::getenv("EMPC_TIMING_EVERY");  // 1 = every sweep (default 4); the per-kernel times of EmpcSolveStats
+    const int v = e ? std::atoi(e) : 4;                 // are sums over the TIMED launches, n_* counts them
+    return v < 1 ? 1 : v;
+  }();
   auto enqueue = [&](Chunk& c) {
     const int q = queued[c.idx] & 1;
     DevBuffers Dq = c.D;
-    Dq.n_active = c.D.n_active + 2 * q;
+    Dq.n_active = c.D.n_active + 3 * q;  // per sweep slot: {active trajectories, linearize-list entries, calc-list entries}
     Dq.lin_count_out = Dq.n_active + 1;
+    Dq.calc_count_out = Dq.n_active + 2;
     Dq.lin_list_out = s->dlin_list + (size_t)q * s->B + c.b0;
     Dq.act_list_out = s->dact_list + (size_t)q * s->B + c.b0;
+    Dq.calc_list_out = s->dcalc_list + (size_t)q * s->B + c.b0;
     if (queued[c.idx] > 0) {  // the lists written by the previous sweep's select; the first sweep takes every trajectory
-      Dq.lin_count = c.D.n_active + 2 * (1 - q) + 1;
+      Dq.lin_count = c.D.n_active + 3 * (1 - q) + 1;
+      Dq.calc_count = c.D.n_active + 3 * (1 - q) + 2;
+      Dq.calc_list = s->dcalc_list + (size_t)(1 - q) * s->B + c.b0;
       Dq.lin_list = s->dlin_list + (size_t)(1 - q) * s->B + c.b0;
-      Dq.act_count = c.D.n_active + 2 * (1 - q);
+      Dq.act_count = c.D.n_active + 3 * (1 - q);
       Dq.act_list = s->dact_list + (size_t)(1 - q) * s->B + c.b0;
       Dq.lin_bound = c.active > 0 ? c.active : 1;  // the active set only shrinks: the last count the host saw bounds the list
     }
-    Dq.counters_next = c.D.n_active + 2 * (1 - q);  // zeroed by this sweep's select for the next sweep
+    Dq.counters_next = c.D.n_active + 3 * (1 - q);  // zeroed by this sweep's select for the next sweep
     Dq.done_ticket = s->dticket + c.idx;
     Dq.host_active = s->h_active_dev + 2 * c.idx + q;
-    HIP_CHECK(hipEventRecord(c.ev[q][0], c.stream));
+    // kernel-boundary events only on the sweeps that are timed (every `timing_every`-th: each record is a command in the
+    // stream, ~10 us of dead time between two kernels); the end-of-sweep event is always there (the host waits on it)
+    const bool timed = (queued[c.idx] % timing_every) == 0;
+    timed_slot[c.idx][q] = timed;
+    if (timed) HIP_CHECK(hipEventRecord(c.ev[q][0], c.stream));
     k.calc(Dq, c.stream);
-    HIP_CHECK(hipEventRecord(c.ev[q][1], c.stream));
+    if (timed) HIP_CHECK(hipEventRecord(c.ev[q][1], c.stream));
     if (s->D.integrator == EMPC_INTEGRATOR_RK4)
       k.rk4_linearize(Dq, chunk_rk4(s, c.b0), c.stream);
     else
       k.linearize(Dq, c.stream);
-    HIP_CHECK(hipEventRecord(c.ev[q][2], c.stream));
+    if (timed) HIP_CHECK(hipEventRecord(c.ev[q][2], c.stream));
     k.backward(Dq, c.stream);
-    HIP_CHECK(hipEventRecord(c.ev[q][3], c.stream));
+    if (timed) HIP_CHECK(hipEventRecord(c.ev[q][3], c.stream));
     k.rollout(Dq, c.stream);
-    HIP_CHECK(hipEventRecord(c.ev[q][4], c.stream));
+    if (timed) HIP_CHECK(hipEventRecord(c.ev[q][4], c.stream));
     k.select(Dq, c.stream);
     HIP_CHECK(hipEventRecord(c.ev[q][5], c.stream));  // the active count is in pinned memory once select is done
     queued[c.idx]++;
@@ -648,30 +665,32 @@ static void run_sweeps(EmpcSolver* s, int hard_cap) {
   auto retire = [&](Chunk& c) {  // oldest in-flight sweep of the chunk
     const int q = retired[c.idx] & 1;
     HIP_CHECK(hipEventSynchronize(c.ev[q][5]));
-    auto el = [&](int a) {
-      float ms = 0;
-      return hipEventElapsedTime(&ms, c.ev[q][a], c.ev[q][a + 1]) == hipSuccess ? (double)ms : 0.0;
-    };
-    S.ms_calc += el(0);
-    S.ms_linearize += el(1);
-    S.ms_backward += el(2);
-    S.ms_rollout += el(3);
-    S.ms_select += el(4);
-    S.n_calc++;
-    S.n_linearize++;
-    S.n_backward++;
-    S.n_rollout++;
-    S.n_select++;
-    S.backward_units += (long long)c.active * s->T;
-    S.rollout_units += (long long)c.active * s->NA * (s->T + 1);
-    S.linearize_units += (long long)c.active * (s->T + 1);  // upper bound: trajectories that re-linearize this sweep
+    if (timed_slot[c.idx][q]) {
+      auto el = [&](int a) {
+        float ms = 0;
+        return hipEventElapsedTime(&ms, c.ev[q][a], c.ev[q][a + 1]) == hipSuccess ? (double)ms : 0.0;
+      };
+      S.ms_calc += el(0);
+      S.ms_linearize += el(1);
+      S.ms_backward += el(2);
+      S.ms_rollout += el(3);
+      S.ms_select += el(4);
+      S.n_calc++;
+      S.n_linearize++;
+      S.n_backward++;
+      S.n_rollout++;
+      S.n_select++;
+      S.backward_units += (long long)c.active * s->T;
+      S.rollout_units += (long long)c.active * s->NA * (s->T + 1);
+      S.linearize_units += (long long)c.active * (s->T + 1);  // upper bound: trajectories that re-linearize this sweep
+    }
     c.active = s->h_active[2 * c.idx + q];
     retired[c.idx]++;
   };
   for (auto& c : chunks) {
     // counters of both sweep slots and the completion ticket start at zero; from then on select keeps them (no memset
     // and no copy command per sweep)
-    HIP_CHECK(hipMemsetAsync(c.D.n_active, 0, sizeof(int) * 4, c.stream));
+    HIP_CHECK(hipMemsetAsync(c.D.n_active, 0, sizeof(int) * 6, c.stream));
     HIP_CHECK(hipMemsetAsync(s->dticket + c.idx, 0, sizeof(int), c.stream));
     if (c.idx > 0) HIP_CHECK(hipStreamWaitEvent(c.stream, chunks[c.idx - 1].ev[0][3], 0));  // stagger the first sweep
     enqueue(c);
@@ -867,7 +886,7 @@ int empc_sweep_batch(EmpcSolver* s, int stages) {
   s->use();
   flush_problem(s);
   DevBuffers D = s->D;  // every trajectory, no work lists, no host hand-over
-  HIP_CHECK(hipMemsetAsync(D.n_active, 0, sizeof(int) * 4, s->stream));
+  HIP_CHECK(hipMemsetAsync(D.n_active, 0, sizeof(int) * 6, s->stream));
   std::memset(&s->stats, 0, sizeof(s->stats));
   HIP_CHECK(hipEventRecord(s->ev[0], s->stream));
   if (stages & EMPC_STAGE_LINEARIZE) {

@@ -91,6 +91,25 @@ class MultiCopterBaseParams {
 
 class Trajectory;
 
+// crocoddyl::SquashingModelSmoothSat(u_lb, u_ub, ns) as the reference builds it (src/trajectory.cpp:49-50): plain data -- the
+// limits of the smooth saturation and its smoothing.  The kernels take the limits from the problem (the same numbers);
+// SolverSbFDDP(problem, squashing_model) checks that they agree.
+struct SquashingModelSmoothSat {
+  SquashingModelSmoothSat(const VectorXd& u_lb, const VectorXd& u_ub, std::size_t ns) : u_lb_(u_lb), u_ub_(u_ub), ns_(ns) {}
+  const VectorXd& get_u_lb() const { return u_lb_; }
+  const VectorXd& get_u_ub() const { return u_ub_; }
+  const VectorXd& get_s_lb() const { return u_lb_; }  // s_lb = u_lb, s_ub = u_ub
+  const VectorXd& get_s_ub() const { return u_ub_; }
+  std::size_t get_ns() const { return ns_; }
+  double get_smooth() const { return smooth_; }
+  void set_smooth(double s) { smooth_ = s; }
+
+ private:
+  VectorXd u_lb_, u_ub_;
+  std::size_t ns_;
+  double smooth_ = 0.1;
+};
+
 // Registry of the operational frames a problem references (index = position in EmpcModelDesc's frame table).
 class FrameTable {
  public:
@@ -233,6 +252,10 @@ class Trajectory : public std::enable_shared_from_this<Trajectory> {
   FrameTable& frame_table() { return frames_; }
   const FrameTable& frame_table() const { return frames_; }
   const ProblemParams& get_problem_params() const { return problem_params_; }
+  // get_squash() (include/eagle_mpc/trajectory.hpp:68): the platform's SquashingModelSmoothSat
+  std::shared_ptr<SquashingModelSmoothSat> get_squash() const {
+    return std::make_shared<SquashingModelSmoothSat>(platform_params_->u_lb, platform_params_->u_ub, get_nu());
+  }
 
  private:
   Trajectory();
@@ -250,8 +273,32 @@ class Trajectory : public std::enable_shared_from_this<Trajectory> {
 
 // Batched Squash-box FDDP on the GPU.  The scalar interface below is the reference's; the *Batch methods are the
 // data-parallel extension (B independent rollouts of the same problem from different initial states).
+// What a crocoddyl callback reads from the solver after one iteration (crocoddyl::CallbackAbstract::operator()(SolverAbstract&)).
+struct IterationRecord {
+  int phase, iter;
+  double cost, stop, x_reg, u_reg, steplength, dV, dVexp, gap_norm, d0, d1;
+  bool is_feasible;
+};
+class CallbackAbstract {
+ public:
+  virtual ~CallbackAbstract() {}
+  virtual void operator()(const IterationRecord& rec) = 0;
+};
+// crocoddyl::CallbackVerbose: one line per iteration
+class CallbackVerbose : public CallbackAbstract {
+ public:
+  void operator()(const IterationRecord& rec) override;
+};
+
 class SolverSbFDDP {
  public:
+  // the reference's constructor (include/eagle_mpc/sbfddp.hpp:39-40): SolverSbFDDP(problem, trajectory->get_squash())
+  SolverSbFDDP(const std::shared_ptr<ShootingProblem>& problem, const std::shared_ptr<SquashingModelSmoothSat>& squashing_model,
+               std::size_t batch_size = 1, int device = 0);
+  // SolverAbstract::setCallbacks: invoked once per DDP iteration of trajectory 0, replayed from the device iteration trace
+  // right after solve() returns (the solve itself never leaves the device)
+  void setCallbacks(const std::vector<std::shared_ptr<CallbackAbstract>>& callbacks);
+  const std::vector<std::shared_ptr<CallbackAbstract>>& getCallbacks() const { return callbacks_; }
   // squashing model == the problem's (u_lb, u_ub) smooth saturation; batch_size trajectories on HIP device `device`
   // solver_type: EMPC_SOLVER_SBFDDP (the fork's solver, default) or the crocoddyl back ends MpcAbstract also accepts --
   // EMPC_SOLVER_BOXFDDP / EMPC_SOLVER_BOXDDP (include/eagle_mpc/mpc-base.hpp:36-47); same handle type, same getters
@@ -303,6 +350,8 @@ class SolverSbFDDP {
   double cost_ = 0, stop_ = 0;
   std::vector<double> xs_b_, us_b_, us_squash_b_, cost_b_;
   std::vector<int> iter_b_, status_b_;
+  std::vector<std::shared_ptr<CallbackAbstract>> callbacks_;
+  std::shared_ptr<SquashingModelSmoothSat> squashing_model_;
 };
 
 // ------------------------------------------------------------------------------------------------------------

@@ -1,5 +1,7 @@
 // SolverSbFDDP: C++ mirror of include/eagle_mpc/sbfddp.hpp:34-126 on top of the C ABI (include/empc.h).
 // All arithmetic runs in the HIP kernels; this class only moves buffers and keeps the reference's getters.
+#include <algorithm>
+#include <cstdio>
 #include <cstring>
 #include <stdexcept>
 
@@ -19,7 +21,30 @@ SolverSbFDDP::SolverSbFDDP(const std::shared_ptr<ShootingProblem>& problem, std:
   us_squash_.assign(T, VectorXd(problem_->get_nu(), 0.0));  // src/sbfddp.cpp:33-37
 }
 
+SolverSbFDDP::SolverSbFDDP(const std::shared_ptr<ShootingProblem>& problem, const std::shared_ptr<SquashingModelSmoothSat>& squashing_model,
+                           std::size_t batch_size, int device)
+    : SolverSbFDDP(problem, batch_size, device, EMPC_SOLVER_SBFDDP) {
+  if (!squashing_model) throw std::invalid_argument("SolverSbFDDP: squashing model is null");
+  const EmpcProblemDesc& d = problem_->desc();
+  bool same = squashing_model->get_ns() == (std::size_t)d.nu;
+  for (int i = 0; same && i < d.nu; ++i)
+    same = squashing_model->get_u_lb()[i] == d.u_lb[i] && squashing_model->get_u_ub()[i] == d.u_ub[i];
+  if (!same) throw std::invalid_argument("SolverSbFDDP: squashing model does not belong to this problem (control limits differ)");
+  squashing_model_ = squashing_model;
+}
+
 SolverSbFDDP::~SolverSbFDDP() { empc_solver_destroy(handle_); }
+
+void SolverSbFDDP::setCallbacks(const std::vector<std::shared_ptr<CallbackAbstract>>& callbacks) {
+  callbacks_ = callbacks;
+  if (!callbacks_.empty() && empc_solver_enable_trace(handle_, 512) != EMPC_OK) throw std::runtime_error(empc_last_error());
+}
+
+void CallbackVerbose::operator()(const IterationRecord& r) {
+  if (r.iter % 10 == 0) std::printf("iter \t cost \t      stop \t    grad \t  xreg \t      ureg \t step \t feas\n");
+  std::printf("%4d  %0.5e  %0.5e  %0.5e  %10.5e  %10.5e   %0.4f     %d\n", r.iter, r.cost, r.stop, -r.d1, r.x_reg, r.u_reg, r.steplength,
+              r.is_feasible ? 1 : 0);
+}
 
 void SolverSbFDDP::set_convergence_init(double convergence_init) {
   convergence_init_ = convergence_init;
@@ -94,6 +119,18 @@ void SolverSbFDDP::fetch() {
   iter_ = (std::size_t)iter_b_[0];
   cost_ = cost_b_[0];
   stop_ = stop[0];
+  if (!callbacks_.empty()) {
+    int n = 0;
+    if (empc_solver_get_trace(handle_, 0, nullptr, 0, &n) != EMPC_OK) throw std::runtime_error(empc_last_error());
+    const int k = std::min(n, 512);
+    std::vector<double> tr((std::size_t)k * EMPC_TRACE_WORDS);
+    if (k > 0 && empc_solver_get_trace(handle_, 0, tr.data(), k, &n) != EMPC_OK) throw std::runtime_error(empc_last_error());
+    for (int i = 0; i < k; ++i) {
+      const double* r = &tr[(std::size_t)i * EMPC_TRACE_WORDS];
+      const IterationRecord rec{(int)r[0], (int)r[1], r[2], r[3], r[4], r[4], r[5], r[7], r[8], r[9], r[10], r[11], r[6] != 0.0};
+      for (auto& cb : callbacks_) (*cb)(rec);
+    }
+  }
 }
 
 }  // namespace eagle_mpc

@@ -13,7 +13,8 @@ int main(int argc, char** argv) {
     auto trajectory = eagle_mpc::Trajectory::create();
     trajectory->autoSetup(eagle_mpc::yaml_dir() + "/hexacopter370_flying_arm_3/trajectories/displacement.yaml");
     auto problem = trajectory->createProblem(80, true, "IntegratedActionModelEuler");
-    eagle_mpc::SolverSbFDDP solver(problem);  // batch_size = 1: the reference call
+    eagle_mpc::SolverSbFDDP solver(problem, trajectory->get_squash());  // the reference's constructor; batch_size = 1
+    solver.setCallbacks({std::make_shared<eagle_mpc::CallbackVerbose>()});
     solver.solve({}, {}, 100);
     std::printf("iterations %zu cost %.6f\n", solver.get_iter(), solver.get_cost());
     const auto& xT = solver.get_xs().back();

@@ -20,7 +20,8 @@ trajectory = empc.Trajectory()
 trajectory.autoSetup(empc.yaml_path("hexacopter370_flying_arm_3/trajectories/displacement.yaml"))
 problem = trajectory.createProblem(dt, True, "IntegratedActionModelEuler")
 
-solver = empc.SolverSbFDDP(problem)            # batch = 1: the reference call
+solver = empc.SolverSbFDDP(problem, trajectory.squash)   # the reference call (examples/python/trajectory.py:21); batch = 1
+solver.setCallbacks([empc.CallbackVerbose()])
 solver.solve([], [], maxiter=100)
 print("iterations", solver.iter, "cost %.6f" % solver.cost, "final position", np.round(solver.xs[-1][:3], 4))
 print("first squashed control", np.round(solver.us_squash[0], 3))

@@ -124,8 +124,11 @@ typedef struct EmpcSolveStats {
   long long rollout_units;    /* (trajectory, alpha, node) units rolled out                                 */
   long long backward_units;   /* (trajectory, node) units of the backward pass                              */
   double ms_total;            /* wall time of the solve on the stream                                       */
-  double ms_linearize, ms_backward, ms_rollout, ms_select, ms_calc; /* summed kernel times (events)         */
-  int n_linearize, n_backward, n_rollout, n_select, n_calc;         /* launches                              */
+  /* kernel times from HIP events on the solver's stream, summed over the TIMED launches: every sweep of the phase-level
+   * calls, every EMPC_TIMING_EVERY-th sweep (default 4) of a solve -- an event record between two kernels costs ~10 us of
+   * stream time.  n_* and *_units count the same timed launches, so ms / n and units / n are per-launch averages. */
+  double ms_linearize, ms_backward, ms_rollout, ms_select, ms_calc;
+  int n_linearize, n_backward, n_rollout, n_select, n_calc;
 } EmpcSolveStats;
 int empc_solver_get_stats(EmpcSolver* s, EmpcSolveStats* stats);
 /* diagnostic builds only (-DEMPC_STAMPS): in-kernel cycle stamps of the backward kernel, trajectory 0 */
