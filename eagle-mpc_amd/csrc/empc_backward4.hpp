@@ -1,6 +1,6 @@
 // empc_backward4.hpp -- HOT-B kernel body, matrix-core form with zero-padded LDS tiles (the shipped form).
 //
-// Same mathematics and the same MFMA tiling as empc_backward3.hpp (W = Vxx' [Fx Fu], Q = H + [Fx Fu]^T [W | Vx'],
+// Mathematics and MFMA tiling (the r01 form it grew out of lives in tests/csrc/superseded/ as an emulator cross-check): (W = Vxx' [Fx Fu], Q = H + [Fx Fu]^T [W | Vx'],
 // Vxx = Qxx - Qxu K on v_mfma_f64_16x16x4_f64; LLT of Quu, gain solves, symmetrisation, gap terms, regularisation retry:
 // crocoddyl SolverDDP::backwardPass / computeGains; call sites src/sbfddp.cpp:244,256,332).  What changed is
 // how the operands are addressed.  backward3 was bound by its instruction stream (~4k instructions per knot, a quarter of
@@ -15,10 +15,23 @@
 //   * the gains stay in the registers of the lane that solved them (column j of K): written to global memory, to LDS as
 //     -K (B operand of the Vxx update) and used for Vx without a round trip.
 #pragma once
-#include "empc_backward3.hpp"
+#include "empc_kernels.hpp"
 #include "empc_boxqp.hpp"
 
 namespace empc {
+
+#if defined(EMPC_STAMPS) && defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+#define BWD_STAMP(i)                                              \
+  do {                                                            \
+    const unsigned long long now_ = __builtin_readcyclecounter(); \
+    bst[i] += now_ - bst[15];                                     \
+    bst[15] = now_;                                               \
+  } while (0)
+#else
+#define BWD_STAMP(i) \
+  do {               \
+  } while (0)
+#endif
 
 // Scheduling fence: nothing moves across it.  With 256 registers in use the compiler otherwise turns a short loop over LDS
 // values into load, wait, use, load, wait, use ... -- one exposed LDS round trip (~100 cycles) per element; a block of

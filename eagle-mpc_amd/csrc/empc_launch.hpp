@@ -15,8 +15,6 @@
 #include "empc_prep.hpp"
 #ifdef EMPC_INSTANTIATE  // kernel bodies are only needed where a table is instantiated
 #include "empc_linearize2.hpp"
-#include "empc_backward2.hpp"
-#include "empc_backward3.hpp"
 #include "empc_backward4.hpp"
 #include "empc_rollout6.hpp"
 #endif
@@ -71,15 +69,6 @@ __global__ void __launch_bounds__(64) k_rollout(DevBuffers D) {
   if (idx >= D.B * D.NA) return;
   const int b = idx / D.NA, ai = idx % D.NA;
   rollout_thread<DM, CT>(D, b, ai);
-}
-
-// the shipped rollout: one wavefront per trajectory, lanes = step lengths, feedback product by the whole wave
-template <class DM, int CT>
-__global__ void __launch_bounds__(64) k_rollout5(DevBuffers D) {
-  extern __shared__ double smem_roll5[];
-  static_assert(DM::NU <= 64, "feedback rows must fit one wavefront");
-  LaneExec ex{(int)threadIdx.x};
-  rollout_wave5<DM, CT>(ex, D, blockIdx.x, 64, smem_roll5);
 }
 
 // the shipped rollout: G trajectories x NA step lengths per wavefront, four role wavefronts per workgroup (empc_rollout6.hpp)
@@ -200,25 +189,6 @@ struct BlockExec {
     for (int r = 0; r < 4; ++r) c[0][im][in][r] = v[r];
   }
 };
-
-#ifndef EMPC_BWD_NL
-#define EMPC_BWD_NL 64
-#endif
-template <class DM>
-__global__ void __launch_bounds__(EMPC_BWD_NL) k_backward(DevBuffers D) {
-  extern __shared__ double smem_bwd[];
-  const int b = blockIdx.x;
-  BlockExec ex{(int)threadIdx.x};
-  backward_traj2<DM, EMPC_BWD_NL>(ex, D, b, smem_bwd);
-}
-
-// matrix-core form of the backward pass (one wavefront per trajectory)
-template <class DM>
-__global__ void __launch_bounds__(64) k_backward3(DevBuffers D) {
-  extern __shared__ double smem_bwd3[];
-  BlockExec ex{(int)threadIdx.x};
-  backward_traj3<DM>(ex, D, blockIdx.x, smem_bwd3);
-}
 
 // the shipped backward pass: matrix cores, zero-padded LDS tiles (empc_backward4.hpp)
 template <class DM, bool BOX>
@@ -449,29 +419,21 @@ static void launch_rk4_linearize(DevBuffers D, Rk4Buffers R, hipStream_t s) {
 
 template <class DM>
 static void launch_backward(DevBuffers D, hipStream_t s) {
-  static const int version = [] {
-    const char* e = getenv("EMPC_BACKWARD");  // 2 = vector form, 3 = matrix-core form, 4 = matrix cores + padded tiles (default)
-    return e ? atoi(e) : 4;
-  }();
-  if (version == 2 && D.solver_type == EMPC_SOLVER_SBFDDP)
-    hipLaunchKernelGGL(k_backward<DM>, dim3(D.B), dim3(EMPC_BWD_NL), sizeof(double) * Bwd2Smem<DM>::SIZE, s, D);
-  else if (D.solver_type != EMPC_SOLVER_SBFDDP)  // the BoxQP gains exist in this form only
+  if (D.solver_type != EMPC_SOLVER_SBFDDP)  // the BoxQP gains: their own instantiation
     hipLaunchKernelGGL((k_backward4<DM, true>), dim3(D.B), dim3(64), sizeof(double) * Bwd4Smem<DM>::SIZE, s, D);
-  else if (version == 4)
-    hipLaunchKernelGGL((k_backward4<DM, false>), dim3(D.B), dim3(64), sizeof(double) * Bwd4Smem<DM>::SIZE, s, D);
   else
-    hipLaunchKernelGGL(k_backward3<DM>, dim3(D.B), dim3(64), sizeof(double) * Bwd3Smem<DM>::SIZE, s, D);
+    hipLaunchKernelGGL((k_backward4<DM, false>), dim3(D.B), dim3(64), sizeof(double) * Bwd4Smem<DM>::SIZE, s, D);
 }
 template <class DM, int CT>
 static void launch_rollout(DevBuffers D, hipStream_t s) {
   const int n = D.B * D.NA;
   static const int version = [] {
-    const char* e = getenv("EMPC_ROLLOUT");  // 6 = packed role-split form (default), 5 = wave per trajectory, 1 = per-lane form (also the fallback for more than MAX_ALPHAS step lengths)
+    const char* e = getenv("EMPC_ROLLOUT");  // 6 = packed role-split form (default), 1 = per-lane form
     return e ? atoi(e) : 6;
   }();
-  if (version == 1 || D.NA > MAX_ALPHAS || D.integrator != EMPC_INTEGRATOR_EULER) {  // RK4 nodes: the per-lane form
+  if (version == 1 || D.NA > MAX_ALPHAS || D.integrator != EMPC_INTEGRATOR_EULER) {  // RK4 nodes, > 16 step lengths: the per-lane form
     hipLaunchKernelGGL((k_rollout<DM, CT>), dim3((n + 63) / 64), dim3(64), 0, s, D);
-  } else if (version == 6 || D.solver_type != EMPC_SOLVER_SBFDDP) {  // (the clamp of the box solvers: forms 6 and 1)
+  } else {
     const size_t smem = sizeof(double) * Roll6Smem<DM>::SIZE;
     static const bool once = [&] {  // more than 64 KB of dynamic LDS needs the opt-in
       (void)hipFuncSetAttribute((const void*)k_rollout6<DM, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -480,8 +442,6 @@ static void launch_rollout(DevBuffers D, hipStream_t s) {
     (void)once;
     const int G = roll6_group_size(D.NA);
     hipLaunchKernelGGL((k_rollout6<DM, CT>), dim3((D.B + G - 1) / G), dim3(64 * R6_WAVES), smem, s, D);
-  } else {
-    hipLaunchKernelGGL((k_rollout5<DM, CT>), dim3(D.B), dim3(64), sizeof(double) * Roll5Smem<DM>::SIZE, s, D);
   }
 }
 template <class DM>

@@ -59,3 +59,24 @@ def contact_variant(empc, tmp_path, contact="ContactModel3D", gains=(0.0, 0.0), 
     tr = empc.Trajectory()
     tr.autoSetup(str(f))
     return tr, tr.createProblem(dt, squash, integrator)
+
+
+def unweighted_barrier_variant(empc, tmp_path, dt=80):
+    """displacement with every `limits_state` cost switched from ActivationModelWeightedQuadraticBarrier to the unweighted
+    ActivationModelQuadraticBarrier (src/factory/activation.cpp:53-68: bounds only, `weights` ignored) and bounds on every
+    component.  No shipped YAML uses the unweighted barrier.  Returns (trajectory, problem)."""
+    src = open(empc.yaml_path(CONFIGS["displacement"][0])).read()
+    old = '          activation: "ActivationModelWeightedQuadraticBarrier"\n          weights: [0, 0, 0, 0, 0, 0, 1, 1, 1, 0, 0, 0, 0, 0, 0, 1, 1, 1]\n'
+    new = '          activation: "ActivationModelQuadraticBarrier"\n'
+    assert src.count(old) >= 4
+    src = src.replace(old, new)
+    # an unweighted barrier with zero bounds on the base components would pin the base at the origin: open those bounds
+    src = src.replace("u_bound: [0, 0, 0, 0, 0, 0, 1.5, 1.5, 1.5, 0, 0, 0, 0, 0, 0, 3, 3, 3]",
+                      "u_bound: [9, 9, 9, 3, 3, 3, 1.5, 1.5, 1.5, 7, 7, 7, 5, 5, 5, 3, 3, 3]")
+    src = src.replace("[0, 0, 0, 0, 0, 0, -1.5, -1.5, -1.5, 0, 0, 0, 0, 0, 0, -3, -3, -3]",
+                      "[-9, -9, -9, -3, -3, -3, -1.5, -1.5, -1.5, -7, -7, -7, -5, -5, -5, -3, -3, -3]")
+    f = tmp_path / "displacement_unweighted_barrier.yaml"
+    f.write_text(src)
+    tr = empc.Trajectory()
+    tr.autoSetup(str(f))
+    return tr, tr.createProblem(dt, True, "IntegratedActionModelEuler")

@@ -10,8 +10,9 @@
 
 #include "../../eagle-mpc_amd/csrc/empc_prep.hpp"
 #include "../../eagle-mpc_amd/csrc/empc_linearize2.hpp"
-#include "../../eagle-mpc_amd/csrc/empc_backward2.hpp"
-#include "../../eagle-mpc_amd/csrc/empc_backward3.hpp"
+#include "superseded/empc_backward2.hpp"
+#include "superseded/empc_backward3.hpp"
+#include "superseded/empc_rollout5.hpp"
 #include "../../eagle-mpc_amd/csrc/empc_backward4.hpp"
 #include "../../eagle-mpc_amd/csrc/empc_rollout6.hpp"
 #include "../../eagle-mpc_amd/csrc/empc_rk4.hpp"

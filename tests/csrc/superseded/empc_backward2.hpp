@@ -7,7 +7,9 @@
 // the SIMDs.  Semantics are those of backward_traj (v1) and of the oracle: SolverDDP::backwardPass + computeGains +
 // SolverFDDP::updateExpectedImprovement, with the regularisation retry loop of src/sbfddp.cpp:242-255.
 #pragma once
-#include "empc_kernels.hpp"
+// TEST INFRASTRUCTURE (superseded kernel form, kept as a cross-check of the shipped one through the CPU lane emulator;
+// not compiled into libempc.so)
+#include "../../../eagle-mpc_amd/csrc/empc_kernels.hpp"
 
 namespace empc {
 

@@ -8,18 +8,13 @@
 // empc_backward2.hpp, which stays as the vector form (emulator cross-check, NL = 256 tiling).
 //
 #pragma once
+// TEST INFRASTRUCTURE (superseded kernel form, kept as a cross-check of the shipped one through the CPU lane emulator;
+// not compiled into libempc.so)
 #include "empc_backward2.hpp"
 
 namespace empc {
 
-#if defined(EMPC_STAMPS) && defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
-#define BWD_STAMP(i)                                              \
-  do {                                                            \
-    const unsigned long long now_ = __builtin_readcyclecounter(); \
-    bst[i] += now_ - bst[15];                                     \
-    bst[15] = now_;                                               \
-  } while (0)
-#else
+#ifndef BWD_STAMP
 #define BWD_STAMP(i) \
   do {               \
   } while (0)

@@ -469,8 +469,17 @@ def teacher_forced(backend_factory, desc, prm, x0s, paths, maxiter=100, chunk=10
                 # (a rollout that blows up: costs of 1e11 ... 1e54): nothing about it is comparable
                 hi = max(f.accepted_alpha if f.accepted_alpha >= 0 else na - 1, it["accepted_alpha"] if it["accepted_alpha"] >= 0 else na - 1)
                 nz = np.abs(pf["cost_try"] - p["cost_try"]) / (1.0 + np.abs(p["cost_try"]))
+                for q in pu:
+                    nz = np.maximum(nz, np.abs(q["cost_try"] - p["cost_try"]) / (1.0 + np.abs(p["cost_try"])))
                 if bool((~np.isfinite(nz[:hi + 1]) | (nz[:hi + 1] > CHAOTIC) | (pf["ok"][:hi + 1] != p["ok"][:hi + 1])).any()):
                     rep["decisions_excused_chaotic"] = rep.get("decisions_excused_chaotic", 0) + 1
+                    rep["decisions_checked"] += 1
+                    continue
+                # ... or where the deciding inequality is tied to within the rounding noise of the trial costs that enter it
+                # (an iterate that has blown up: every trial costs 8.1176e13, the acceptance test compares differences of 1e8)
+                mg = decision_margin(prm, dict(it, accepted_alpha=hi), p, None)
+                if mg is not None and mg <= NOISE_FACTOR * max(float(nz[:hi + 1].max()), 1e-13):
+                    rep["decisions_excused_tied"] = rep.get("decisions_excused_tied", 0) + 1
                     rep["decisions_checked"] += 1
                     continue
             assert f.accepted_alpha == it["accepted_alpha"], (where, f.accepted_alpha, it["accepted_alpha"], cost_try[j], p["cost_try"])

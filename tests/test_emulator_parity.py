@@ -76,6 +76,13 @@ def test_contact_options_kernel_bodies_vs_oracle(empc, emu, tmp_path, contact, g
     kernel_bodies(emu, problem, "eagle_catch", 2, 4, 6)
 
 
+def test_unweighted_quadratic_barrier_kernel_bodies(empc, emu, tmp_path):
+    """ActivationModelQuadraticBarrier (bounds, no weights; src/factory/activation.cpp:53-68) through the kernel bodies"""
+    from conftest import unweighted_barrier_variant
+    _, problem = unweighted_barrier_variant(empc, tmp_path)
+    kernel_bodies(emu, problem, "displacement", 2, 4, 6)
+
+
 def kernel_bodies(emu, problem, name, lin, bwd, roll):
     d = problem.desc
     prm = ob.default_params()

@@ -44,6 +44,24 @@ def test_phase_parity(empc, problems, name):
     phase_parity(empc, problem, name)
 
 
+def test_unweighted_quadratic_barrier(empc, tmp_path):
+    """ActivationModelQuadraticBarrier (src/factory/activation.cpp:53-68: bounds, no weights) through the three kernels and a
+    full solve: the one activation type no shipped YAML evaluates (VERDICT r02 missing #4)."""
+    from conftest import unweighted_barrier_variant
+    _, problem = unweighted_barrier_variant(empc, tmp_path)
+    d = problem.desc
+    acts = {d.sets[i].costs[j].activation for i in range(d.n_sets) for j in range(d.sets[i].ncosts)}
+    assert empc.T.ACT_QUADRATIC_BARRIER in acts
+    phase_parity(empc, problem, "displacement/unweighted-barrier")
+    B = 4
+    x0s = empc.perturbed_x0s(problem.x0, B, nq=d.model.nq)
+    s = empc.SolverSbFDDP(problem, batch=B)
+    s.solve([], [], 100, x0s=x0s)
+    r = ob.solve_batch(d, x0s, 100, nthreads=4)
+    assert np.array_equal(s.iter_batch, r["iter"]) and np.array_equal(s.status_batch, r["status"])
+    assert np.abs(s.xs_batch - r["xs"]).max() < 1e-4 and np.abs(s.us_batch - r["us"]).max() < 1e-4
+
+
 def phase_parity(empc, problem, name):
     d = problem.desc
     B = 3
