@@ -36,6 +36,7 @@ struct SetInfo {
   int ctrl_ci[EMPC_MAX_COSTS];   // Control costs (incl. the solver's barrier)
   int frame_ci[EMPC_MAX_COSTS];  // FramePlacement / Rotation / Translation / Velocity costs
   int cone_ci[EMPC_MAX_COSTS];   // ContactFrictionCone costs
+  int state_own[EMPC_MAX_COSTS]; // per entry of state_ci: position (in state_ci) of the first State cost with the same reference
 };
 
 struct DevBuffers {

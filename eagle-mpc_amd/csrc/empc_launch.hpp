@@ -153,12 +153,13 @@ __global__ void __launch_bounds__(BLK) EMPC_LIN_ATTR k_linearize(DevBuffers D) {
 // frames, the rest the full body over the other knots.  One launch instead of two: the short full-body launch no longer
 // waits for the last lean workgroup (straggler sweeps: two unit latencies per sweep become one).
 template <class DM, int CT, int LPU, int BLK>
-__global__ void __launch_bounds__(BLK) EMPC_LIN_ATTR k_linearize_all(DevBuffers D, int n_lean_blocks) {
+__global__ void __launch_bounds__(BLK) EMPC_LIN_ATTR k_linearize_all(DevBuffers D, int n_full_blocks) {
   extern __shared__ double smem_lin[];
-  if ((int)blockIdx.x < n_lean_blocks)
-    lin_block<DM, CT, LPU, BLK, false>(D, blockIdx.x, smem_lin);
+  // the full-body units (frame costs, contacts: few and ~1.5x as long) come first in the grid, the lean ones fill in behind them
+  if ((int)blockIdx.x < n_full_blocks)
+    lin_block<DM, CT, LPU, BLK, true>(D, blockIdx.x, smem_lin);
   else
-    lin_block<DM, CT, LPU, BLK, true>(D, blockIdx.x - n_lean_blocks, smem_lin);
+    lin_block<DM, CT, LPU, BLK, false>(D, blockIdx.x - n_full_blocks, smem_lin);
 }
 
 // workgroup-wide executor: barriers are real workgroup barriers
@@ -353,15 +354,15 @@ static void launch_linearize_blk(DevBuffers D, hipStream_t s) {
   // B / UPB per knot that return at once
   const int bpk = ((D.lin_bound > 0 ? D.lin_bound : D.B) + UPB - 1) / UPB;
   const int n_lean = bpk * D.n_lean, n_full = bpk * (D.T + 1 - D.n_lean);
-  static const bool merged = [] {
-    const char* e = getenv("EMPC_LIN_MERGED");  // 0 = one launch per body (the earlier form)
-    return e ? atoi(e) != 0 : true;
+  static const int merged = [] {
+    const char* e = getenv("EMPC_LIN_MERGED");  // 0 = one launch per body, 1 = one launch when few trajectories are left, 2 = always one launch
+    return e ? atoi(e) : 1;
   }();
   if constexpr (BLK == 256) {
-    // only when few trajectories are left (a full batch is better served by the two separately compiled bodies:
-    // displacement 0.665 vs 0.690 ms per sweep), where the second launch is mostly latency
-    if (merged && n_lean > 0 && n_full > 0 && D.lin_bound > 0 && 2 * D.lin_bound <= D.B) {
-      hipLaunchKernelGGL((k_linearize_all<DM, CT, LPU, BLK>), dim3(n_lean + n_full), dim3(BLK), smem, s, D, n_lean);
+    // one launch holding both bodies: always (2), or only when few trajectories are left (1), where the second launch is
+    // mostly latency
+    if (n_lean > 0 && n_full > 0 && (merged == 2 || (merged == 1 && D.lin_bound > 0 && 2 * D.lin_bound <= D.B))) {
+      hipLaunchKernelGGL((k_linearize_all<DM, CT, LPU, BLK>), dim3(n_lean + n_full), dim3(BLK), smem, s, D, n_full);
       return;
     }
   }

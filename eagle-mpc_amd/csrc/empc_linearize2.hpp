@@ -39,14 +39,18 @@ struct Lin2Smem {
   static constexpr int OFF_GAP = OFF_XN + NX;         // gap written to the next record (NDX) and, for t = 0, fs[0] (NDX)
   static constexpr int OFF_FR = OFF_GAP + 2 * NDX;    // per captured frame: R 9 | p 3 | v 6
   static constexpr int OFF_CST = OFF_FR + NCAP * 18;  // cost nominal slots
-  static constexpr int NSLOT = 4;
+  static constexpr int NSLOT = 2;                     // State costs handled side by side (a stage of the shipped files has two)
   static constexpr int SLOT = 3 * NDX + 36 + 4;       // r | Ar | Arr | J6 | value
-  static constexpr int OFF_RSH = OFF_CST + NSLOT * SLOT;  // residual-Jacobian exchange 6 x (NDX + NU)
-  static constexpr int OFF_RED = OFF_RSH + 6 * (NDX + NU);  // small reduction area (cost partial sums) 64
+  // residual-Jacobian exchange 6 x (NDX + NU) of the cost rounds (S6): lives where the inertia factor, the Euler step and its
+  // Lie Jacobians were -- all of them dead once S5 has written Fx / Fu (LDS per unit decides how many units a CU holds)
+  static constexpr int OFF_RSH = OFF_M;
+  static_assert(6 * (NDX + NU) <= OFF_GAP - OFF_M, "the exchange area must fit the block it aliases");
+  static constexpr int OFF_RED = OFF_CST + NSLOT * SLOT;  // small reduction area: cost sum | control-cost partial sums
   // contact block (nc = 3 rows for ContactModel3D, 6 for ContactModel6D): lambda 6 | fext 6 | cone rows 15 + Ar 5 + Arr 5 |
   // Jc nc x NV | M^-1 Jc^T NV x nc | packed G nc (nc + 1) / 2.  The nc-dependent part comes last, so a unit of the 3D
   // instantiation is no larger than it has to be (units per CU are LDS-bound in the contact problem)
-  static constexpr int OFF_LAM = OFF_RED + 64;
+  static constexpr int OFF_LAM = OFF_RED + 16;
+  static_assert(NU + 1 <= 16, "reduction area");
   static constexpr int OFF_FEXT = OFF_LAM + 6;
   static constexpr int OFF_CONE = OFF_FEXT + 6;
   static constexpr int OFF_JC = OFF_CONE + 26;
@@ -598,11 +602,13 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
       for (int i = 0; i < NDX; ++i) Nu[SM::OFF_GAP + NDX + i] = feasu ? 0.0 : gap[i];
     }
   };
-  // State cost q of group `base`: state difference and its log Jacobian, if the cost owns its reference (ref_share)
-  auto owner_section = [&](double* Nu, int base, int q) {
-    if (base + q >= set.ncosts) return;
-    const EMPC_K EmpcCost& c = set.costs[base + q];
-    if (!c.active || c.type != EMPC_COST_STATE || c.ref_share >= base) return;
+  // State cost at position k0 + q of the set's State-cost list: state difference and its log Jacobian, unless an earlier cost of
+  // the same group has the same reference (SetInfo::state_own)
+  const EMPC_K SetInfo& si = EMPC_KPTR(SetInfo, D.set_info)[EMPC_KPTR(int, D.knot_set)[t]];
+  auto owner_section = [&](double* Nu, int k0, int q) {
+    if (k0 + q >= si.n_state) return;
+    if (si.state_own[k0 + q] != k0 + q && si.state_own[k0 + q] >= k0) return;
+    const EMPC_K EmpcCost& c = set.costs[si.state_ci[k0 + q]];
     double* S = Nu + SM::OFF_CST + q * SM::SLOT;
     double xref[NX], dpl[3];
 #pragma unroll
@@ -1025,17 +1031,18 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
   // so type and weight are scalar loads and the branch on the activation type is uniform; the component parameters
   // (act_w / lb / ub) are one coalesced vector load each.  (Before: one lane per cost ran the 18 activations in a
   // row, after a copy of all parameters into LDS; 19k of a unit's 87k cycles.)
-  static_assert(EMPC_MAX_COSTS % SM::NSLOT == 0, "group loads assume whole groups inside costs[]");
-  for (int base = 0; base < set.ncosts; base += SM::NSLOT) {
-    // uniform facts of the group, loaded once (costs[] has EMPC_MAX_COSTS entries: base + q is always in range)
+  for (int base = 0; base < si.n_state; base += SM::NSLOT) {
+    // uniform facts of the group, loaded once
     bool on[SM::NSLOT];
-    int own[SM::NSLOT], act[SM::NSLOT];
+    int own[SM::NSLOT], act[SM::NSLOT], cidx[SM::NSLOT];
     double wg[SM::NSLOT];
 #pragma unroll
     for (int q = 0; q < SM::NSLOT; ++q) {
-      const EMPC_K EmpcCost& c = set.costs[base + q];
-      on[q] = base + q < set.ncosts && c.active && c.type == EMPC_COST_STATE;
-      own[q] = (c.ref_share >= base) ? c.ref_share - base : q;  // slot holding this cost's residual and log Jacobian
+      on[q] = base + q < si.n_state;
+      cidx[q] = on[q] ? si.state_ci[base + q] : si.state_ci[base];
+      const EMPC_K EmpcCost& c = set.costs[cidx[q]];
+      const int ow = on[q] ? si.state_own[base + q] : base;
+      own[q] = (ow >= base) ? ow - base : q;  // slot holding this cost's residual and log Jacobian
       act[q] = c.activation;
       wg[q] = c.weight;
     }
@@ -1054,7 +1061,7 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
       double pw[SM::NSLOT], plb[SM::NSLOT], pub[SM::NSLOT];
 #pragma unroll
       for (int q = 0; q < SM::NSLOT; ++q) {
-        const EMPC_K EmpcCost& c = set.costs[base + q];
+        const EMPC_K EmpcCost& c = set.costs[cidx[q]];
         pw[q] = c.act_w[lane];
         plb[q] = c.lb[lane];
         pub[q] = c.ub[lane];

@@ -173,6 +173,14 @@ inline void prepare_problem(const EmpcProblemDesc& d, const EmpcSolverParams& pr
         if (!seen && I.ncap < NCAP) I.capf[I.ncap++] = c.frame;
       }
     }
+    for (int a = 0; a < I.n_state; ++a) {  // State costs that share a reference reuse the first one's residual (linearize)
+      I.state_own[a] = a;
+      for (int b = 0; b < a; ++b)
+        if (std::memcmp(s.costs[I.state_ci[b]].ref, s.costs[I.state_ci[a]].ref, sizeof(double) * d.nx) == 0) {
+          I.state_own[a] = b;
+          break;
+        }
+    }
     if (d.has_contact && s.ncontacts > 0) {
       const int cframe = s.contacts[0].frame;
       bool seen = false;
