@@ -252,6 +252,7 @@ def main():
     ap.add_argument("--mode", default="stream", choices=["stream", "batch"],
                     help="stream: the steps x batch initial states go through the batch slots as one queue; batch: one plain solve per step")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short displacement run appended at N = 1")
+    ap.add_argument("--no-single-batch", action="store_true", help="skip the plain batched solves appended to a stream run at N = 1")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-launched workers (0 = pick a free one)")
     ap.add_argument("--maxiter", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -523,7 +524,7 @@ def main():
         if is_mpc:
             out["mpc_cycles_per_s"] = args.steps * MPC_CYCLES_PER_STEP / elapsed
             out["plant_controller_cycles_per_s"] = args.steps * MPC_CYCLES_PER_STEP * B * world / elapsed
-        if stream and world == 1:
+        if stream and world == 1 and not args.no_single_batch:
             # the same rollouts as plain batched solves (the latency view: one batch at a time, stragglers included)
             nb = min(2, args.steps)
             tb = time.perf_counter()
