@@ -203,7 +203,7 @@ def cpu_baseline_and_parity(empc, solver, problem, d, x0s, B, maxiter, unit):
                     "decisions_exact": rep["decisions_checked"] - rep.get("decisions_excused_chaotic", 0) - rep.get("direction_ties_excused", 0) - rep.get("decisions_excused_tied", 0),
                     "decisions_excused_blown_up_trial_or_tie": rep.get("decisions_excused_chaotic", 0) + rep.get("direction_ties_excused", 0) + rep.get("decisions_excused_tied", 0),
                     "trial_costs_checked": rep["trial_costs_checked"], "trial_costs_beyond_1e-9": rep.get("trial_costs_beyond_1e-9", 0),
-                    "tapes_checked": rep["tapes_checked"],
+                    "tapes_checked": rep["tapes_checked"], "iterates_skipped_exploded": rep.get("iterates_skipped_exploded", 0),
                     "max_rel": {k: rep["max_rel"].get(k) for k in ("cost", "tape_Fx", "tape_Lxx", "tape_Lx", "K", "k", "Vx", "cost_try_accepted")},
                     "gpu_iterations_reproduced_by_oracle": fr["oracle_reproduces_device_decision"],
                     "gpu_iterations": fr["device_iterations"], "unexplained": fr["unexplained"],
