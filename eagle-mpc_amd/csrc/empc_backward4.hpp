@@ -328,10 +328,11 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
       BWD_STAMP(2);
       // computeGains: LLT(Quu + ureg I) in every lane; lane j < n solves column j of K = Quu^-1 Qxu^T, lane n solves k and
       // forms Quu k.  The columns stay in registers.
-      // SolverBoxDDP::computeGains always, SolverBoxFDDP::computeGains once the trajectory is feasible: k from the box QP over
+      // SolverBoxDDP::computeGains / SolverBoxFDDP::computeGains once the trajectory is feasible (both fall back to the plain
+      // gains while the gaps are open: `!has_control_limits || !is_feasible_` -> SolverDDP::computeGains): k from the box QP over
       // [u_lb - us, u_ub - us] (one lane), K = (free block of Quu)^-1 Qux on the free controls and zero on the clamped ones, Qu
       // zeroed on the clamped ones (it enters the stopping criterion, the expected improvement and Vx below)
-      const bool box_gains = BOX && (P.prm.solver_type == EMPC_SOLVER_BOXDDP || (P.prm.solver_type == EMPC_SOLVER_BOXFDDP && is_feasible));
+      const bool box_gains = BOX && is_feasible && (P.prm.solver_type == EMPC_SOLVER_BOXDDP || P.prm.solver_type == EMPC_SOLVER_BOXFDDP);
       if (box_gains) {
         ex.each([&](int lane, int sl) {
           if (lane != n) return;
@@ -349,7 +350,7 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
             xq[i] = kprev[i];
           }
           const bool okq = box_qp_lane<m>(Hq, qq, lbq, ubq, xq, fm, hinv, P.prm.boxqp_maxiter, P.prm.boxqp_th_acceptstep,
-                                          P.prm.boxqp_th_grad, P.prm.boxqp_reg, D.NA);
+                                          P.prm.boxqp_th_grad, P.prm.boxqp_reg);
           flag[0] = okq ? 0.0 : 1.0;
 #pragma unroll
           for (int i = 0; i < m * m; ++i) Hinv[i] = hinv[i];

@@ -15,7 +15,9 @@ namespace empc {
 // Returns false when a factorisation fails (crocoddyl throws "backward_error").
 template <int M>
 EMPC_HD bool box_qp_lane(const double* H, const double* q, const double* lb, const double* ub, double* x, int* free_mask, double* Hinv,
-                         int maxiter, double th_acceptstep, double th_grad, double reg, int n_alphas) {
+                         int maxiter, double th_acceptstep, double th_grad, double reg) {
+  // crocoddyl::BoxQP builds its own ten step lengths 2^-n whatever the outer solver's line search uses
+  constexpr int n_alphas = 10;
   double g[M], xnew[M], dx[M];
   int prev_mask[M];
   bool have_inv = false, ok = true;
@@ -78,7 +80,13 @@ EMPC_HD bool box_qp_lane(const double* H, const double* q, const double* lb, con
       if (!same) ok = factor_free(free_mask);
       return ok;
     }
-    if (!factor_free(free_mask)) return false;
+    {
+      // the factorisation of an unchanged free set is the one already held
+      bool same = have_inv;
+#pragma unroll
+      for (int i = 0; i < M; ++i) same = same && prev_mask[i] == free_mask[i];
+      if (!same && !factor_free(free_mask)) return false;
+    }
     // Newton step on the free space: dxf = -Hff^-1 (qf + Hfc xc) - xf
     for (int i = 0; i < M; ++i) {
       double a = 0;
@@ -92,6 +100,7 @@ EMPC_HD bool box_qp_lane(const double* H, const double* q, const double* lb, con
       dx[i] = free_mask[i] ? a - x[i] : 0.0;
     }
     const double fold = fval(x);
+    bool moved = false;
     for (int ia = 0; ia < n_alphas; ++ia) {
       const double alpha = ldexp(1.0, -ia);
 #pragma unroll
@@ -102,10 +111,16 @@ EMPC_HD bool box_qp_lane(const double* H, const double* q, const double* lb, con
       for (int i = 0; i < M; ++i) gd += g[i] * (x[i] - xnew[i]);
       if (fold - fnew > th_acceptstep * gd) {
 #pragma unroll
-        for (int i = 0; i < M; ++i) x[i] = xnew[i];
+        for (int i = 0; i < M; ++i) {
+          moved = moved || x[i] != xnew[i];
+          x[i] = xnew[i];
+        }
         break;
       }
     }
+    // an iteration that left x where it was repeats itself (same gradient, same free set, same step) until maxiter: the
+    // result is the one at hand (a control clamped with a non-zero multiplier keeps the gradient norm above th_grad for ever)
+    if (!moved) return true;
   }
   return true;
 }

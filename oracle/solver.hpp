@@ -295,7 +295,11 @@ struct Solver {
         if (!same && !factor_free(free_mask)) return false;  // (the reference factors at k == 0; later it keeps the last one)
         return true;
       }
-      if (!factor_free(free_mask)) return false;
+      {
+        bool same = have_inv;
+        for (int i = 0; i < m; ++i) same = same && prev_mask[i] == free_mask[i];
+        if (!same && !factor_free(free_mask)) return false;  // an unchanged free set keeps its factorisation
+      }
       // Newton step on the free space: dxf = -Hff^-1 (qf + Hfc xc) - xf
       for (int i = 0; i < m; ++i) {
         dx[i] = 0;
@@ -320,7 +324,8 @@ struct Solver {
         return f;
       };
       const double fold = fval(x);
-      for (double alpha : alphas) {
+      for (int ia = 0; ia < 10; ++ia) {  // BoxQP's own step lengths (n_alphas_ = 10 in its constructor), not the solver's
+        const double alpha = std::ldexp(1.0, -ia);
         for (int i = 0; i < m; ++i) xnew[i] = std::max(std::min(x[i] + alpha * dx[i], ub[i]), lb[i]);
         const double fnew = fval(xnew);
         double gd = 0;
@@ -391,9 +396,11 @@ struct Solver {
       }
       if (!std::isnan(ureg))
         for (int i = 0; i < m; ++i) Quu[t][i * m + i] += ureg;
-      // computeGains.  SolverBoxDDP::computeGains always, SolverBoxFDDP::computeGains once the trajectory is feasible:
-      // k from the box QP over [u_lb - us, u_ub - us], K on the free controls only, Qu zeroed on the clamped ones
-      const bool box_gains = P.prm.solver_type == EMPC_SOLVER_BOXDDP || (P.prm.solver_type == EMPC_SOLVER_BOXFDDP && is_feasible);
+      // computeGains.  SolverBoxDDP::computeGains and SolverBoxFDDP::computeGains (crocoddyl ~1.8 box-ddp.cpp / box-fddp.cpp)
+      // start with `if (!has_control_limits || !is_feasible_) { SolverDDP::computeGains(t); return; }`: the box QP runs once
+      // the trajectory is feasible.  k from the box QP over [u_lb - us, u_ub - us], K on the free controls only, Qu zeroed on
+      // the clamped ones
+      const bool box_gains = is_feasible && (P.prm.solver_type == EMPC_SOLVER_BOXDDP || P.prm.solver_type == EMPC_SOLVER_BOXFDDP);
       if (box_gains) {
         double lb[NU], ub[NU], xq[NU], Hinv[NU * NU];
         int fm[NU];

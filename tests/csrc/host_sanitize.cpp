@@ -21,6 +21,8 @@ int empc_solver_get_cost(EmpcSolver*, double*) { return -1; }
 int empc_solver_get_stop(EmpcSolver*, double*) { return -1; }
 int empc_solver_get_iters(EmpcSolver*, int*) { return -1; }
 int empc_solver_get_status(EmpcSolver*, int*) { return -1; }
+int empc_solver_enable_trace(EmpcSolver*, int) { return -1; }
+int empc_solver_get_trace(EmpcSolver*, int, double*, int, int*) { return -1; }
 }
 using namespace eagle_mpc;
 int main(int argc, char** argv) {

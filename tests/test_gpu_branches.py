@@ -269,3 +269,28 @@ def test_set_cost_refs_equals_table_update(empc, problems):
         a.set_cost_refs(knot, "no_such_cost", weight=1.0)
     with pytest.raises(empc.EmpcError, match="knot out of range"):
         a.set_cost_refs(d.T + 1, state_cost, weight=1.0)
+
+
+def test_update_problem_rejects_another_problem_class(empc, problems):
+    """empc_solver_update_problem validates the new description against the class the solver's kernels were chosen for
+    (integrator, free / contact dynamics, squashing, shapes) BEFORE anything is swapped: a rejected update leaves the solver
+    solving its old problem, bit for bit."""
+    tr, _ = problems["displacement"]
+    problem = tr.createProblem(80, True, "IntegratedActionModelEuler")
+    s = empc.SolverSbFDDP(problem, batch=2)
+    s.solve([], [], 100)
+    xs, us, it = s.xs_batch.copy(), s.us_batch.copy(), s.iter
+    lib = empc.lib()
+    import ctypes as C
+    for other, what in ((tr.createProblem(80, True, "IntegratedActionModelRK4"), "integrator"),
+                        (tr.createProblem(80, False, "IntegratedActionModelEuler"), "use_squash"),
+                        (tr.createProblem(40, True, "IntegratedActionModelEuler"), "shapes")):
+        rc = lib.empc_solver_update_problem(s._h, C.byref(other.desc))
+        assert rc != 0 and what in empc.last_error(), (what, empc.last_error())
+        s.solve([], [], 100)
+        assert np.array_equal(s.xs_batch, xs) and np.array_equal(s.us_batch, us) and s.iter == it
+    tc, _ = problems["eagle_catch"]
+    contact = tc.createProblem(32, True, "IntegratedActionModelEuler")
+    assert lib.empc_solver_update_problem(s._h, C.byref(contact.desc)) != 0
+    s.solve([], [], 100)
+    assert np.array_equal(s.xs_batch, xs) and s.iter == it
