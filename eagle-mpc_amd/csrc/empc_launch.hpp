@@ -39,7 +39,7 @@ struct KernelTable {
 
 
 // (bodies, rotors) = (1,4) iris | (1,6) hexacopter370 / hextilt | (3,6) hexacopter680_flying_arm_2 |
-// (4,6) hexacopter370_flying_arm_3, free and contact dynamics | (6,6) hextilt_flying_arm_5
+// (4,6) hexacopter370_flying_arm_3, free and contact dynamics | (6,6) hextilt_flying_arm_5, free and contact dynamics
 KernelTable empc_table_1_4();
 KernelTable empc_table_1_6();
 KernelTable empc_table_3_6();
@@ -47,6 +47,8 @@ KernelTable empc_table_4_6();
 KernelTable empc_table_4_6_contact();
 KernelTable empc_table_4_6_contact6();
 KernelTable empc_table_6_6();
+KernelTable empc_table_6_6_contact();
+KernelTable empc_table_6_6_contact6();
 
 #ifdef EMPC_INSTANTIATE
 // --------------------------------------------------------------------------------------------------------------------

@@ -42,6 +42,8 @@ static bool find_table(int nb, int nrot, bool contact, int contact_rows, KernelT
   else if (nb == 4 && nrot == 6 && contact && contact_rows != 6) k = empc_table_4_6_contact();
   else if (nb == 4 && nrot == 6 && contact && contact_rows == 6) k = empc_table_4_6_contact6();
   else if (nb == 6 && nrot == 6 && !contact) k = empc_table_6_6();
+  else if (nb == 6 && nrot == 6 && contact && contact_rows != 6) k = empc_table_6_6_contact();
+  else if (nb == 6 && nrot == 6 && contact && contact_rows == 6) k = empc_table_6_6_contact6();
   else return false;
   return true;
 }

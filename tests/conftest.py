@@ -80,3 +80,61 @@ def unweighted_barrier_variant(empc, tmp_path, dt=80):
     tr = empc.Trajectory()
     tr.autoSetup(str(f))
     return tr, tr.createProblem(dt, True, "IntegratedActionModelEuler")
+
+
+ARM5_CONTACT_STAGE = '''
+    - name: "push"
+      duration: 520 #ms
+      transition: false
+      costs:
+        - name: "reg_state"
+          type: "CostModelState"
+          weight: 1e-2
+          reference: [0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0]
+          activation: "ActivationModelWeightedQuad"
+          weights: [1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1]
+
+        - name: "reg_control"
+          type: "CostModelControl"
+          weight: 1e-2
+          reference: [0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0]
+          activation: "ActivationModelWeightedQuad"
+          weights: [1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1]
+
+        - name: "translation_ee"
+          type: "CostModelFrameTranslation"
+          weight: 500
+          link_name: "flying_arm_5__gripper"
+          position: [0.6, 0.1, 0.7]
+
+        - name: "friction_cone"
+          type: "CostModelContactFrictionCone"
+          weight: 10
+          n_surf: [0, 0, 1]
+          mu: 0.7
+          link_name: "flying_arm_5__gripper"
+
+      contacts:
+        - name: "end_effector"
+          type: "%(contact)s"
+          link_name: "flying_arm_5__gripper"
+          position: [0.6, 0.1, 0.7]
+%(orientation)s          gains: [%(g0)r, %(g1)r]
+'''
+
+
+def arm5_contact_variant(empc, tmp_path, contact="ContactModel3D", gains=(0.0, 0.0), dt=26):
+    """push_slide's robot (hextilt_flying_arm_5: 6 bodies, 6 tilted rotors, 11 velocity dimensions) with a contact stage
+    appended -- contact dynamics on the second arm class (src/factory/contacts.cpp:26-79 builds a contact for any robot; no
+    shipped YAML has one on this robot).  Returns (trajectory, problem)."""
+    src = open(empc.yaml_path(CONFIGS["push_slide"][0])).read()
+    src = src.replace("duration: 2000 #ms", "duration: 1040 #ms")
+    assert src.count("duration: 1040 #ms") == 1
+    src = src.rstrip("\n") + "\n" + ARM5_CONTACT_STAGE % dict(
+        contact=contact, orientation='          orientation: [0, 0, 0, 1]\n' if contact == "ContactModel6D" else "",
+        g0=float(gains[0]), g1=float(gains[1]))
+    f = tmp_path / ("arm5_%s_%g_%g.yaml" % (contact, gains[0], gains[1]))
+    f.write_text(src)
+    tr = empc.Trajectory()
+    tr.autoSetup(str(f))
+    return tr, tr.createProblem(dt, True, "IntegratedActionModelEuler")

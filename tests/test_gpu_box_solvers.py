@@ -22,11 +22,12 @@ def box_problem(empc, name, dt):
 
 
 # Cold starts whose free-running iteration path is rounding-sensitive (they do not converge within the iteration budget; the
-# oracle against its own -ffp-contract=fast build differs by 15..50 on xs for hover / BoxFDDP and up to 5 for eagle_catch,
+# oracle against its own -ffp-contract=fast build differs by 15..50 on xs for hover (both box solvers start with the plain gains
+# while the gaps are open, from the zero guess with a 1e-9 regularisation) and up to 5 for eagle_catch,
 # `tools/oracle_sensitivity.py --options`, profiles/r02_oracle_sensitivity_options.json): their parity claim is the
 # step-wise one of tests/test_gpu_teacher_forced.py::test_box_solvers (every iteration reproduced from the other side's
 # iterate); here they are only required to stay finite and inside the control limits.  The others: the plain bound.
-STEPWISE_ONLY = {("hover", 1), ("eagle_catch", 1), ("eagle_catch", 2)}
+STEPWISE_ONLY = {("hover", 1), ("hover", 2), ("eagle_catch", 1), ("eagle_catch", 2)}
 
 
 @pytest.mark.parametrize("solver_type", [1, 2])

@@ -81,7 +81,7 @@ def test_contact_options(empc, tmp_path, contact, gains):
     check(rep)
 
 
-@pytest.mark.parametrize("name,dt,solver_type", [("hover", 40, 1), ("eagle_catch", 32, 1), ("eagle_catch", 32, 2), ("displacement", 80, 2)])
+@pytest.mark.parametrize("name,dt,solver_type", [("hover", 40, 1), ("hover", 40, 2), ("eagle_catch", 32, 1), ("eagle_catch", 32, 2), ("displacement", 80, 2)])
 def test_box_solvers(empc, name, dt, solver_type):
     tr = empc.Trajectory()
     tr.autoSetup(empc.yaml_path(CONFIGS[name][0]))
