@@ -96,6 +96,9 @@ EMPC_HD void inertia_apply(const EMPC_K EmpcModelDesc& m, int b, const S* mot, S
 // Operational-frame capture: placement and LOCAL velocity / acceleration of up to NCAP frames, filled during the
 // forward recursion when the recursion reaches the frame's body.
 constexpr int NCAP = 2;
+// contact rows of a kernel instantiation (template parameter CT / NC): 0 free dynamics, 3 ContactModel3D, 6 ContactModel6D,
+// CT_MIXED a problem whose stages use both (the bodies of 3 and 6 behind a uniform branch on the node's contact type)
+constexpr int CT_MIXED = 9;
 template <class S>
 struct FrameCap {
   S R[9], p[3];  // world placement
@@ -602,9 +605,18 @@ EMPC_HD void cone_rows(const double* nsurf, double mu, double AR[5][3]) {
 template <class DM, int NC, class ContactT>
 EMPC_HD void contact_forward(const EMPC_K EmpcModelDesc& m, const ContactT& ct, const FrameCap<double>& ck, const double* R0,
                              const double* q, const double* cs, const double* sn, const double* L, double* a, double* lam) {
+  if constexpr (NC == CT_MIXED) {
+    // a problem with stages of both contact types: the type of this node's contact picks the body (uniform over the
+    // lanes of a wavefront: they hold trajectories at the same knot)
+    if (ct.type == EMPC_CONTACT_6D)
+      contact_forward<DM, 6>(m, ct, ck, R0, q, cs, sn, L, a, lam);
+    else
+      contact_forward<DM, 3>(m, ct, ck, R0, q, cs, sn, L, a, lam);
+    return;
+  }
   constexpr int NV = DM::NV;
-  constexpr int nc = NC;
-  static_assert(NC == 3 || NC == 6, "ContactModel3D or ContactModel6D");
+  constexpr int nc = (NC == CT_MIXED) ? 6 : NC;
+  static_assert(NC == 3 || NC == 6 || NC == CT_MIXED, "ContactModel3D, ContactModel6D or both");
   // drift (frame acceleration at qdd = 0, no gravity): the bias pass carries gravity as a base acceleration -g, which
   // reaches every frame as the pure translation R_f^T (-g); take it out again
   double ng[3] = {-m.gravity[0], -m.gravity[1], -m.gravity[2]}, gf[3], a0[6];

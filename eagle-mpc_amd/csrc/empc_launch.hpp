@@ -46,6 +46,7 @@ KernelTable empc_table_3_6();
 KernelTable empc_table_4_6();
 KernelTable empc_table_4_6_contact();
 KernelTable empc_table_4_6_contact6();
+KernelTable empc_table_4_6_contact_mixed();
 KernelTable empc_table_6_6();
 KernelTable empc_table_6_6_contact();
 KernelTable empc_table_6_6_contact6();
@@ -101,6 +102,11 @@ __global__ void __launch_bounds__(64 * R6_WAVES) k_rollout6(DevBuffers D) {
     rollout_group6<DM, CT, R6_D>(ex, D, blockIdx.x, smem_roll6);
 }
 
+// constraint rows of the contact of knot t (3 when the knot has none)
+__device__ __forceinline__ int knot_contact_rows(const DevBuffers& D, int t) {
+  const EMPC_K EmpcCostSet& set = EMPC_KPTR(EmpcCostSet, D.sets)[EMPC_KPTR(int, D.knot_set)[t]];
+  return (set.ncontacts > 0 && set.contacts[0].type == EMPC_CONTACT_6D) ? 6 : 3;
+}
 template <class DM, int CT, int LPU, int BLK, bool FR>
 // Two wavefronts per SIMD: at the compiler's own choice (326 registers, one wavefront per SIMD) the kernel sits at
 // ~1 resident wave per SIMD with 37 % of its time in waits; capping the budget at 256 registers costs ~250 spilled
@@ -139,10 +145,24 @@ __device__ __forceinline__ void lin_block(const DevBuffers& D, const int block, 
   if constexpr (RW > 0) {
     if (!__syncthreads_or(active ? 1 : 0)) return;  // nothing to do in the whole block
     const LinRole R{(int)threadIdx.x, UPB, USZ, i0, nlist, D.lin_list, smem_lin, active};
-    linearize_unit2<DM, CT, FR, LaneExec, RW>(ex, D, b, t, LPU, smem_lin + (size_t)u * USZ, &R);
+    if constexpr (CT == CT_MIXED) {
+      // stages of both contact types in one problem: all units of a block are trajectories of ONE knot, so the type of
+      // its contact is uniform over the workgroup (the barriers inside stay in uniform control flow)
+      if (knot_contact_rows(D, t) == 6)
+        linearize_unit2<DM, 6, FR, LaneExec, RW>(ex, D, b, t, LPU, smem_lin + (size_t)u * USZ, &R);
+      else
+        linearize_unit2<DM, 3, FR, LaneExec, RW>(ex, D, b, t, LPU, smem_lin + (size_t)u * USZ, &R);
+    } else
+      linearize_unit2<DM, CT, FR, LaneExec, RW>(ex, D, b, t, LPU, smem_lin + (size_t)u * USZ, &R);
   } else {
     if (!active) return;
-    linearize_unit2<DM, CT, FR>(ex, D, b, t, LPU, smem_lin + (size_t)u * USZ);
+    if constexpr (CT == CT_MIXED) {
+      if (knot_contact_rows(D, t) == 6)
+        linearize_unit2<DM, 6, FR>(ex, D, b, t, LPU, smem_lin + (size_t)u * USZ);
+      else
+        linearize_unit2<DM, 3, FR>(ex, D, b, t, LPU, smem_lin + (size_t)u * USZ);
+    } else
+      linearize_unit2<DM, CT, FR>(ex, D, b, t, LPU, smem_lin + (size_t)u * USZ);
   }
 }
 #define EMPC_LIN_ATTR __attribute__((amdgpu_waves_per_eu(DM::NV > 9 ? EMPC_LIN_WAVES_BIG : EMPC_LIN_WAVES, DM::NV > 9 ? EMPC_LIN_WAVES_BIG : EMPC_LIN_WAVES)))

@@ -56,7 +56,7 @@ struct Lin2Smem {
   static constexpr int OFF_JC = OFF_CONE + 26;
   static constexpr int off_mij(int nc) { return OFF_JC + nc * NV; }
   static constexpr int off_g(int nc) { return OFF_JC + 2 * nc * NV; }
-  static constexpr int size_for(int nc) { return nc == 0 ? SIZE_NC : (off_g(nc) + nc * (nc + 1) / 2 + 1) / 2 * 2; }
+  static constexpr int size_for(int nc) { return nc == 0 ? SIZE_NC : (nc == CT_MIXED ? size_for(6) : (off_g(nc) + nc * (nc + 1) / 2 + 1) / 2 * 2); }
   static constexpr int SIZE = (OFF_JC + 12 * NV + 21 + 1) / 2 * 2;  // the largest unit (six rows)
   static constexpr int SIZE_NC = (OFF_LAM + 1) / 2 * 2;  // problems without contacts never touch the contact block
 };

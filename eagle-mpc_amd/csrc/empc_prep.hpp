@@ -142,9 +142,8 @@ inline void prepare_problem(const EmpcProblemDesc& d, const EmpcSolverParams& pr
       // the number of constraint rows is a compile-time constant of the kernels (3: ContactModel3D, 6: ContactModel6D)
       const int rows = s.contacts[0].type == EMPC_CONTACT_3D ? 3 : (s.contacts[0].type == EMPC_CONTACT_6D ? 6 : -1);
       if (rows < 0) throw std::runtime_error("unknown contact type in a cost set");
-      if (H.contact_rows != 0 && H.contact_rows != rows)
-        throw std::runtime_error("ContactModel3D and ContactModel6D stages in one problem are not supported by the kernels");
-      H.contact_rows = rows;
+      // stages of both types in one problem: the mixed instantiation (CT_MIXED), which branches on the node's contact type
+      H.contact_rows = (H.contact_rows != 0 && H.contact_rows != rows) ? CT_MIXED : rows;
     }
   }
   // work lists per cost set (SetInfo); the capture order is the one node_nominal derives by scanning the table

@@ -35,14 +35,17 @@ using namespace empc;
 // contact_rows: 0 for problems built on the free dynamics; 3 / 6 for Contact dynamics (DifferentialActionModelContactFwdDynamics
 // on every node) whose contact stages hold a ContactModel3D / ContactModel6D
 static bool find_table(int nb, int nrot, bool contact, int contact_rows, KernelTable& k) {
+  // diagnostic: run a single-type contact problem through the mixed instantiation (tests: bitwise the same results)
+  if (contact && nb == 4 && std::getenv("EMPC_FORCE_MIXED_CONTACT")) contact_rows = empc::CT_MIXED;
   if (nb == 1 && nrot == 4 && !contact) k = empc_table_1_4();
   else if (nb == 1 && nrot == 6 && !contact) k = empc_table_1_6();
   else if (nb == 3 && nrot == 6 && !contact) k = empc_table_3_6();
   else if (nb == 4 && nrot == 6 && !contact) k = empc_table_4_6();
+  else if (nb == 4 && nrot == 6 && contact && contact_rows == empc::CT_MIXED) k = empc_table_4_6_contact_mixed();
   else if (nb == 4 && nrot == 6 && contact && contact_rows != 6) k = empc_table_4_6_contact();
   else if (nb == 4 && nrot == 6 && contact && contact_rows == 6) k = empc_table_4_6_contact6();
   else if (nb == 6 && nrot == 6 && !contact) k = empc_table_6_6();
-  else if (nb == 6 && nrot == 6 && contact && contact_rows != 6) k = empc_table_6_6_contact();
+  else if (nb == 6 && nrot == 6 && contact && contact_rows != 6 && contact_rows != empc::CT_MIXED) k = empc_table_6_6_contact();
   else if (nb == 6 && nrot == 6 && contact && contact_rows == 6) k = empc_table_6_6_contact6();
   else return false;
   return true;

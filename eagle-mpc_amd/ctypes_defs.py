@@ -136,3 +136,4 @@ STATUS_DDP_CLEANUP = 8
 COST_STATE, COST_CONTROL, COST_FRAME_PLACEMENT, COST_FRAME_ROTATION, COST_FRAME_VELOCITY, COST_FRAME_TRANSLATION, \
     COST_CONTACT_FRICTION_CONE = range(7)
 ACT_QUAD, ACT_WEIGHTED_QUAD, ACT_QUADRATIC_BARRIER, ACT_WEIGHTED_QUADRATIC_BARRIER = range(4)
+CONTACT_3D, CONTACT_6D = 0, 1  # EmpcContactType

@@ -138,3 +138,22 @@ def arm5_contact_variant(empc, tmp_path, contact="ContactModel3D", gains=(0.0, 0
     tr = empc.Trajectory()
     tr.autoSetup(str(f))
     return tr, tr.createProblem(dt, True, "IntegratedActionModelEuler")
+
+
+def mixed_contact_variant(empc, tmp_path, gains6=(0.0, 0.0), dt=32):
+    """eagle_catch with its grasp stage followed by a copy of it ("hold") whose contact is a ContactModel6D: a problem with
+    stages of BOTH contact types (src/factory/contacts.cpp:26-79 builds either per stage; no shipped YAML mixes them).
+    Returns (trajectory, problem)."""
+    src = open(empc.yaml_path(CONFIGS["eagle_catch"][0])).read()
+    i, j = src.index('    - name: "grasp"'), src.index('    - name: "move_away"')
+    grasp = src[i:j]
+    old = '          type: "ContactModel3D"\n          link_name: "flying_arm_3__gripper"\n          position: [0, 0, 0]\n          gains: [0, 0]\n'
+    assert grasp.count(old) == 1
+    hold = grasp.replace('- name: "grasp"', '- name: "hold"').replace(
+        old, '          type: "ContactModel6D"\n          link_name: "flying_arm_3__gripper"\n          position: [0, 0, 0]\n'
+             '          orientation: [0, 0, 0, 1]\n          gains: [%r, %r]\n' % (float(gains6[0]), float(gains6[1])))
+    f = tmp_path / ("eagle_catch_mixed_%g_%g.yaml" % tuple(gains6))
+    f.write_text(src[:j] + hold + src[j:])
+    tr = empc.Trajectory()
+    tr.autoSetup(str(f))
+    return tr, tr.createProblem(dt, True, "IntegratedActionModelEuler")

@@ -144,6 +144,12 @@ static void emu_alloc(Emu& e) {
   for (int b = 0; b < B; ++b) std::memcpy(&e.x0[(size_t)b * DM::NX], e.H.x0.data(), sizeof(double) * DM::NX);
 }
 
+// constraint rows of the contact of knot t: the problem's, or the knot's own in a problem with stages of both types
+static int emu_knot_rows(const Emu& e, int t) {
+  if (e.H.contact_rows != CT_MIXED) return e.H.contact_rows;
+  const EmpcCostSet& set = e.H.sets[e.H.knot_set[t]];
+  return (set.ncontacts > 0 && set.contacts[0].type == EMPC_CONTACT_6D) ? 6 : 3;
+}
 template <class DM>
 static void emu_calc(Emu& e) {
   const bool ct = e.H.P.has_contact != 0;
@@ -151,7 +157,9 @@ static void emu_calc(Emu& e) {
     for (int t = 0; t <= e.T; ++t) {
       if constexpr (DM::NB == 4) {
         if (ct) {
-          if (e.H.contact_rows == 6) {
+          if (e.H.contact_rows == CT_MIXED) {
+            calc_thread<DM, CT_MIXED>(e.D, b, t);
+          } else if (e.H.contact_rows == 6) {
             calc_thread<DM, 6>(e.D, b, t);
           } else {
             calc_thread<DM, 3>(e.D, b, t);
@@ -178,7 +186,9 @@ static void emu_linearize_rk4(Emu& e) {
     for (int b = 0; b < e.B; ++b) {
       if constexpr (DM::NB == 4) {
         if (ct) {
-          if (e.H.contact_rows == 6) {
+          if (e.H.contact_rows == CT_MIXED) {
+            rk4_stage_thread<DM, CT_MIXED>(e.D, R, b, t);
+          } else if (e.H.contact_rows == 6) {
             rk4_stage_thread<DM, 6>(e.D, R, b, t);
           } else {
             rk4_stage_thread<DM, 3>(e.D, R, b, t);
@@ -224,12 +234,12 @@ static void emu_linearize_view(Emu& e, const DevBuffers& Dl) {
       CpuExec<64> ex{LPU};
       if constexpr (DM::NB == 4) {
         if (e.H.P.has_contact) {
-          if (e.H.contact_rows == 6) {
+          if (emu_knot_rows(e, t) == 6) {
             linearize_unit2<DM, 6, false>(ex, Dl, b, t, LPU, smem.data());
           } else {
             linearize_unit2<DM, 3, false>(ex, Dl, b, t, LPU, smem.data());
           }
-          if (e.H.contact_rows == 6) {
+          if (emu_knot_rows(e, t) == 6) {
             linearize_unit2<DM, 6, true>(ex, Dl, b, t, LPU, smem.data());
           } else {
             linearize_unit2<DM, 3, true>(ex, Dl, b, t, LPU, smem.data());
@@ -281,7 +291,9 @@ static void emu_rollout(Emu& e) {
     for (int grp = 0; grp * G < e.B; ++grp) {
       if constexpr (DM::NB == 4) {
         if (ct) {
-          if (e.H.contact_rows == 6) {
+          if (e.H.contact_rows == CT_MIXED) {
+            emu_rollout_group6<DM, CT_MIXED>(e.D, grp, smem6.data());
+          } else if (e.H.contact_rows == 6) {
             emu_rollout_group6<DM, 6>(e.D, grp, smem6.data());
           } else {
             emu_rollout_group6<DM, 3>(e.D, grp, smem6.data());
@@ -301,7 +313,9 @@ static void emu_rollout(Emu& e) {
         CpuExec<64> ex{64};
         if constexpr (DM::NB == 4) {
           if (ct) {
-            if (e.H.contact_rows == 6) {
+            if (e.H.contact_rows == CT_MIXED) {
+              rollout_wave5<DM, CT_MIXED>(ex, e.D, b, 64, smem5.data());
+            } else if (e.H.contact_rows == 6) {
               rollout_wave5<DM, 6>(ex, e.D, b, 64, smem5.data());
             } else {
               rollout_wave5<DM, 3>(ex, e.D, b, 64, smem5.data());
@@ -314,7 +328,9 @@ static void emu_rollout(Emu& e) {
       }
       if constexpr (DM::NB == 4) {
         if (ct) {
-          if (e.H.contact_rows == 6) {
+          if (e.H.contact_rows == CT_MIXED) {
+            rollout_thread<DM, CT_MIXED>(e.D, b, ai);
+          } else if (e.H.contact_rows == 6) {
             rollout_thread<DM, 6>(e.D, b, ai);
           } else {
             rollout_thread<DM, 3>(e.D, b, ai);
@@ -429,7 +445,9 @@ static void emu_node(Emu& e, int t, const double* x, const double* u, double smo
   double c = 0;
   if constexpr (DM::NB == 4) {
     if (e.H.P.has_contact) {
-      if (e.H.contact_rows == 6) {
+      if (e.H.contact_rows == CT_MIXED) {
+        node_nominal<DM, CT_MIXED>(e.H.P, set, smooth, x, u, u == nullptr, xnext, acc, c, usq, lam);
+      } else if (e.H.contact_rows == 6) {
         node_nominal<DM, 6>(e.H.P, set, smooth, x, u, u == nullptr, xnext, acc, c, usq, lam);
       } else {
         node_nominal<DM, 3>(e.H.P, set, smooth, x, u, u == nullptr, xnext, acc, c, usq, lam);

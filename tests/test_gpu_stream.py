@@ -7,7 +7,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name,slots,jobs", [("eagle_catch", 64, 200), ("displacement", 32, 96), ("hover", 16, 40)])
+@pytest.mark.parametrize("name,slots,jobs", [("eagle_catch", 64, 200), ("displacement", 32, 96), ("hover", 16, 40),
+                                             ("eagle_catch", 1024, 2048)])  # the last: the bench line's slot count
 def test_stream_rows_equal_plain_solves(empc, problems, name, slots, jobs):
     _, problem = problems[name]
     d = problem.desc
