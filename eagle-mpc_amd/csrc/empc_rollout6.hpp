@@ -152,15 +152,16 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
   // ---- staging of the nominal data: work items of this lane, fixed for the whole rollout ----------------------------------
   // item = (element offset at knot 0 in its global array, offset inside one staging buffer); -1 = nothing to do.
   // B moves the gain rows (16 bytes per item), D everything else (8 bytes per item).
-  int kI[Exec::SLOTS][SM::NKI], kO[Exec::SLOTS][SM::NKI];
-  int xI[Exec::SLOTS][SM::NXI], xO[Exec::SLOTS][SM::NXI], gI[Exec::SLOTS][SM::NGI], gO[Exec::SLOTS][SM::NGI];
-  int vI[Exec::SLOTS][SM::NGI], uI[Exec::SLOTS][SM::NUI], uO[Exec::SLOTS][SM::NUI];
+  // (global offsets are 64-bit: b * (T + 1) * REC passes 2^31 at ~19k trajectories of the arm robots)
+  typedef long long goff;
+  goff kI[Exec::SLOTS][SM::NKI], xI[Exec::SLOTS][SM::NXI], gI[Exec::SLOTS][SM::NGI], vI[Exec::SLOTS][SM::NGI], uI[Exec::SLOTS][SM::NUI];
+  int kO[Exec::SLOTS][SM::NKI], xO[Exec::SLOTS][SM::NXI], gO[Exec::SLOTS][SM::NGI], uO[Exec::SLOTS][SM::NUI];
   if constexpr (ROLE == R6_B) ex.each([&](int lane, int sl) {
 #pragma unroll
     for (int k = 0; k < SM::NKI; ++k) {
       const int idx = lane + NL * k, g = idx / SM::KE, e = idx % SM::KE;
       const int b = (g < G) ? TB[g] : -1;
-      kI[sl][k] = (b >= 0) ? (b * T * NU * NDX + 2 * e) : -1;
+      kI[sl][k] = (b >= 0) ? ((goff)b * T * NU * NDX + 2 * e) : -1;
       kO[sl][k] = SM::NOM_K + g * SM::KS + 2 * e;  // inside a staging buffer
     }
   });
@@ -169,22 +170,22 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
     for (int k = 0; k < SM::NXI; ++k) {
       const int idx = lane + NL * k, g = idx / NX, e = idx % NX;
       const int b = (g < G) ? TB[g] : -1;
-      xI[sl][k] = (b >= 0) ? (b * (T + 1) * NX + e) : -1;
+      xI[sl][k] = (b >= 0) ? ((goff)b * (T + 1) * NX + e) : -1;
       xO[sl][k] = SM::NOM_X + g * SM::XS + e;
     }
 #pragma unroll
     for (int k = 0; k < SM::NGI; ++k) {
       const int idx = lane + NL * k, g = idx / NDX, e = idx % NDX;
       const int b = (g < G) ? TB[g] : -1;
-      gI[sl][k] = (b >= 0) ? (b * (T + 1) * REC + DM::OFF_GAP + e) : -1;
-      vI[sl][k] = (b >= 0) ? (b * (T + 1) * NDX + e) : -1;
+      gI[sl][k] = (b >= 0) ? ((goff)b * (T + 1) * REC + DM::OFF_GAP + e) : -1;
+      vI[sl][k] = (b >= 0) ? ((goff)b * (T + 1) * NDX + e) : -1;
       gO[sl][k] = g * SM::GS + e;  // relative to NOM_GAP resp. NOM_VF
     }
 #pragma unroll
     for (int k = 0; k < SM::NUI; ++k) {
       const int idx = lane + NL * k, g = idx / NU, e = idx % NU;
       const int b = (g < G) ? TB[g] : -1;
-      uI[sl][k] = (b >= 0) ? (b * T * NU + e) : -1;
+      uI[sl][k] = (b >= 0) ? ((goff)b * T * NU + e) : -1;
       uO[sl][k] = g * SM::US + e;  // relative to NOM_US resp. NOM_KF
     }
   });

@@ -245,10 +245,6 @@ EmpcSolver* empc_solver_create(const EmpcProblemDesc* problem, const EmpcSolverP
     empc::set_last_error("no kernel instantiation for this (bodies, rotors, contact) combination");
     return nullptr;
   }
-  // the packed rollout stages its nominal data through 32-bit element offsets (empc_rollout6.hpp): the largest array it
-  // indexes is the tape
-  if ((long long)batch * (problem->T + 1) * s->kt.rec >= (1LL << 31))
-    throw std::invalid_argument("batch x (T + 1) x record length exceeds 2^31 elements: split the batch over several solvers");
   s->use();
   s->B = batch;
   s->T = problem->T;

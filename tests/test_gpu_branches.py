@@ -294,3 +294,22 @@ def test_update_problem_rejects_another_problem_class(empc, problems):
     assert lib.empc_solver_update_problem(s._h, C.byref(contact.desc)) != 0
     s.solve([], [], 100)
     assert np.array_equal(s.xs_batch, xs) and s.iter == it
+
+
+def test_batch_beyond_32bit_element_offsets(empc, problems):
+    """20 000 rollouts of displacement: the tape holds 20 000 x 101 x 1104 doubles -- element offsets beyond 2^31 in every
+    kernel (the packed rollout's staging items included).  The last rollouts repeat the first ones' initial states and must give
+    bitwise their results, which are those of a small batch."""
+    _, problem = problems["displacement"]
+    d = problem.desc
+    B = 20000
+    x0s = empc.perturbed_x0s(problem.x0, B, nq=d.model.nq)
+    x0s[-3:] = x0s[:3]
+    big = empc.SolverSbFDDP(problem, batch=B)
+    big.solve([], [], 100, x0s=x0s)
+    small = empc.SolverSbFDDP(problem, batch=3)
+    small.solve([], [], 100, x0s=x0s[:3])
+    assert np.array_equal(big.iter_batch[:3], small.iter_batch) and np.array_equal(big.iter_batch[-3:], small.iter_batch)
+    assert np.array_equal(big.xs_batch[:3], small.xs_batch) and np.array_equal(big.xs_batch[-3:], small.xs_batch)
+    assert np.array_equal(big.us_batch[-3:], small.us_batch)
+    assert (big.status_batch & 1).mean() > 0.99
