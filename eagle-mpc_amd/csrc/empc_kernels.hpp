@@ -62,6 +62,7 @@ struct DevBuffers {
   double* try_cost; // [B][NA]
   double* try_dv;   // [B][NA]
   int* try_ok;      // [B][NA]
+  int* try_ncalc;   // [B][NA]  running nodes whose calc ran in this trial: T, or (failing knot + 1) after a "forward_error"
   double* us_last;  // [B][T][NU]  control of the last IAM.calc at every node (fillSquashedOutputs semantics)
   int* n_active;    // [1]
   // trajectories that linearize in this sweep, written by the previous sweep's select (compact, any order); nullptr =
@@ -265,6 +266,7 @@ EMPC_HD void rollout_thread(const DevBuffers& D, int b, int ai) {
 #else
   unsigned long long* stp = nullptr;
 #endif
+  int ncalc = 0;  // knots completed without a failure
   for (int t = 0; t <= T; ++t) {
     const double* rec = D.tape + ((size_t)b * (T + 1) + t) * REC;
     const double* xc = D.xs + ((size_t)b * (T + 1) + t) * NX;
@@ -277,10 +279,12 @@ EMPC_HD void rollout_thread(const DevBuffers& D, int b, int ai) {
     if (!rollout_knot<DM, CT>(P, set, L, t, T, plain, !ddp && !feas, alpha, smooth, xc, uc, kk, KK, rec + DM::OFF_GAP, vf, xs_o,
                               us_o, ac_o, stp))
       break;
+    ncalc = (t + 1 < T) ? t + 1 : T;
   }
   D.try_cost[slot] = L.cost_try;
   D.try_dv[slot] = L.dv;
   D.try_ok[slot] = L.ok;
+  D.try_ncalc[slot] = L.ok ? T : ((ncalc + 1 < T) ? ncalc + 1 : T);  // the failing knot's calc ran too
 #if defined(EMPC_STAMPS) && defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
   if (stp)
     for (int i = 0; i < 16; ++i) D.dbg[i] = stamps[i];
@@ -549,9 +553,22 @@ EMPC_HD void select_copy(const DevBuffers& D, int b, int accepted_ai, int last_a
     copy_doubles(D.acc + (size_t)b * (T + 1) * DM::NACC, D.acc_try + slot * (T + 1) * DM::NACC, (T + 1) * DM::NACC, tid, nthreads);
   }
   if (last_ai >= 0) {
-    // fillSquashedOutputs reads the data of the LAST calc at every node: the last trial that was rolled out
+    // fillSquashedOutputs reads the data of the LAST calc at every node.  The step lengths are tried one after the other
+    // (0 .. last_ai) and a trial that fails ("forward_error") stops at its failing knot: node t keeps the control of the last
+    // trial whose rollout reached it -- or what the calc of the iterate left there when none did
     const size_t slot = (size_t)b * NA + last_ai;
-    copy_doubles(D.us_last + (size_t)b * T * DM::NU, D.us_try + slot * T * DM::NU, T * DM::NU, tid, nthreads);
+    if (D.try_ncalc[slot] >= T) {
+      copy_doubles(D.us_last + (size_t)b * T * DM::NU, D.us_try + slot * T * DM::NU, T * DM::NU, tid, nthreads);
+    } else {
+      for (int i = tid; i < T * DM::NU; i += nthreads) {
+        const int t = i / DM::NU;
+        for (int aj = last_ai; aj >= 0; --aj)
+          if (D.try_ncalc[(size_t)b * NA + aj] > t) {
+            D.us_last[(size_t)b * T * DM::NU + i] = D.us_try[((size_t)b * NA + aj) * T * DM::NU + i];
+            break;
+          }
+      }
+    }
   }
 }
 

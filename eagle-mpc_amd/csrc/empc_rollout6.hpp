@@ -272,6 +272,7 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
   double dvA[Exec::SLOTS];                    // A: -f^T Vxx (xs (-) xs_try) summed over the knots
   double Lc[Exec::SLOTS][DM::NTRI];           // C: Cholesky factor of M, from phase I to phase II of a knot
   int okC[Exec::SLOTS];                       // C: trial state stayed finite
+  int ncC[Exec::SLOTS], ncD[Exec::SLOTS];     // C / D: running nodes reached before the first failure (T: none)
   double costD[Exec::SLOTS];                  // D: cost of the trial
   int okD[Exec::SLOTS];
 
@@ -279,6 +280,7 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
   if constexpr (ROLE == R6_C) ex.each([&](int lane, int sl) {
     const Roll6Lane& L = LL[sl];
     okC[sl] = 1;
+    ncC[sl] = T;
     if (!L.live) return;
     const double* gap0 = NOM + SM::NOM_GAP + L.g * SM::GS;  // staging buffer 0
     double xn[NX], xt[NX];
@@ -300,6 +302,7 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
   if constexpr (ROLE == R6_D) ex.each([&](int lane, int sl) {
     costD[sl] = 0.0;
     okD[sl] = 1;
+    ncD[sl] = T;
   });
   ex.sync();
 
@@ -328,7 +331,10 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
     ell += ELLF[(tp & 1) * NL + lane];
     const double cscale = (terminal && !P.prm.terminal_dt_scaling) ? 1.0 : dt;
     costD[sl] += cscale * ell;
-    if (bad_number(costD[sl])) okD[sl] = 0;
+    if (bad_number(costD[sl])) {
+      if (okD[sl]) ncD[sl] = (tp + 1 < T) ? tp + 1 : T;
+      okD[sl] = 0;
+    }
     // acceleration | contact force of the knot -> acc_try (linearize reuses them for the accepted trial)
     double* ac_o = D.acc_try + ((size_t)L.b * NA + L.ai) * (T + 1) * DM::NACC + (size_t)tp * DM::NACC;
 #pragma unroll
@@ -624,7 +630,10 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
           mx = fmax(mx, fabs(xn[i]));
           isn = isn || (xn[i] != xn[i]);
         }
-        if (isn || bad_number(mx)) okC[sl] = 0;
+        if (isn || bad_number(mx)) {
+          if (okC[sl]) ncC[sl] = (t + 1 < T) ? t + 1 : T;
+          okC[sl] = 0;
+        }
         if (L.plain) {
 #pragma unroll
           for (int i = 0; i < NX; ++i) xt[i] = xn[i];
@@ -686,7 +695,8 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
     });
 #endif
   // ---- results of the trials -------------------------------------------------------------------------------------------------------
-  if constexpr (ROLE == R6_C) ex.each([&](int lane, int sl) { FLAG[lane] = okC[sl] ? 1.0 : 0.0; });
+  // (C hands D the number of running nodes it reached, T + 1 = the rollout stayed finite)
+  if constexpr (ROLE == R6_C) ex.each([&](int lane, int sl) { FLAG[lane] = okC[sl] ? (double)(T + 1) : (double)ncC[sl]; });
   if constexpr (ROLE == R6_A) ex.each([&](int lane, int sl) {
     const Roll6Lane& L = LL[sl];
     if (L.live) D.try_dv[(size_t)L.b * NA + L.ai] = dvA[sl];
@@ -698,7 +708,9 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
     finish_cost(T, lane, sl, L);
     const size_t slot = (size_t)L.b * NA + L.ai;
     D.try_cost[slot] = costD[sl];
-    D.try_ok[slot] = (okD[sl] && FLAG[lane] != 0.0) ? 1 : 0;
+    const int ncc = (int)FLAG[lane];
+    D.try_ok[slot] = (okD[sl] && ncc > T) ? 1 : 0;
+    D.try_ncalc[slot] = (ncc < ncD[sl]) ? ncc : ncD[sl];
   });
 }
 

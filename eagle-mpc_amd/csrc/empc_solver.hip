@@ -298,6 +298,7 @@ EmpcSolver* empc_solver_create(const EmpcProblemDesc* problem, const EmpcSolverP
   D.try_cost = s->dalloc<double>(B * NA);
   D.try_dv = s->dalloc<double>(B * NA);
   D.try_ok = s->dalloc<int>(B * NA);
+  D.try_ncalc = s->dalloc<int>(B * NA);
   D.us_last = s->dalloc<double>(B * T * k.nu);
   D.n_active = s->dalloc<int>(6 * EmpcSolver::MAX_STREAMS);  // per chunk and sweep slot: {active trajectories, entries of the linearize list, of the calc list}
   s->dticket = s->dalloc<int>(EmpcSolver::MAX_STREAMS);
@@ -568,6 +569,7 @@ static DevBuffers chunk_view(const EmpcSolver* s, int b0, int nb, int idx) {
   D.try_cost += (size_t)b0 * NA;
   D.try_dv += (size_t)b0 * NA;
   D.try_ok += (size_t)b0 * NA;
+  D.try_ncalc += (size_t)b0 * NA;
   D.us_last += (size_t)b0 * T * k.nu;
   if (D.trace) D.trace += (size_t)b0 * D.trace_cap * EMPC_TRACE_WORDS;
   D.n_active = s->D.n_active + 6 * idx;

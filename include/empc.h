@@ -137,7 +137,8 @@ int empc_solver_dims(const EmpcSolver* s, int* batch, int* T, int* nx, int* ndx,
 /* 1 when empc_solver_create would accept this problem (a kernel instantiation exists for its (bodies, rotors, contact)
  * class and the problem passes the device-side limits), 0 otherwise with the reason in empc_last_error().  Needs no GPU.
  * Instantiated: (1,4) iris | (1,6) hexacopter370, hextilt | (3,6) hexacopter680_flying_arm_2 |
- * (4,6) hexacopter370_flying_arm_3, free and ContactModel3D dynamics | (6,6) hextilt_flying_arm_5. */
+ * (4,6) hexacopter370_flying_arm_3: free, ContactModel3D, ContactModel6D and mixed-contact dynamics |
+ * (6,6) hextilt_flying_arm_5: free, ContactModel3D and ContactModel6D dynamics. */
 int empc_solver_supported(const EmpcProblemDesc* problem, const EmpcSolverParams* params);
 
 /* ---- phase-level entry points (device kernels, one call = one launch over the whole batch) ------------------

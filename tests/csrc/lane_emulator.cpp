@@ -77,7 +77,7 @@ struct Emu {
   int B, T, NA, nb, nrot;
   std::vector<TrajState> st;
   std::vector<double> x0, xs, us, acc, tape, K, kff, Vx, Vf, xs_try, us_try, acc_try, try_cost, try_dv, us_last;
-  std::vector<int> try_ok, lin_knots;
+  std::vector<int> try_ok, try_ncalc, lin_knots;
   int n_lean;
   int n_active;
   int rec, nx, ndx, nu, nv;
@@ -109,6 +109,7 @@ static void emu_alloc(Emu& e) {
   e.try_cost.assign((size_t)B * NA, 0);
   e.try_dv.assign((size_t)B * NA, 0);
   e.try_ok.assign((size_t)B * NA, 0);
+  e.try_ncalc.assign((size_t)B * NA, 0);
   e.us_last.assign((size_t)B * T * DM::NU, 0);
   DevBuffers& D = e.D;
   D.P = &e.H.P;
@@ -131,6 +132,7 @@ static void emu_alloc(Emu& e) {
   D.try_cost = e.try_cost.data();
   D.try_dv = e.try_dv.data();
   D.try_ok = e.try_ok.data();
+  D.try_ncalc = e.try_ncalc.data();
   D.us_last = e.us_last.data();
   D.n_active = &e.n_active;
   D.dbg = nullptr;

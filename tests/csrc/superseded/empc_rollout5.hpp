@@ -46,6 +46,7 @@ EMPC_HD void rollout_wave5(Exec& ex, const DevBuffers& D, int b, int nl, double*
   double krow[Exec::SLOTS][NDX], ku[Exec::SLOTS], kk[Exec::SLOTS];  // row i of K[t], us[t][i], k[t][i]
   double pre[Exec::SLOTS][SM::NPRE];
   int alive[Exec::SLOTS];
+  int ncalc_l[Exec::SLOTS];
 
   auto fetch_in = [&](int t, int i) -> double {
     if (i < SM::IN_GAP) return D.xs[((size_t)b * (T + 1) + t) * NX + (i - SM::IN_X)];
@@ -68,6 +69,7 @@ EMPC_HD void rollout_wave5(Exec& ex, const DevBuffers& D, int b, int nl, double*
     L[sl].cost_try = 0;
     L[sl].dv = 0;
     L[sl].ok = 1;
+    ncalc_l[sl] = T;
     alive[sl] = (lane < NA) ? 1 : 0;
 #pragma unroll
     for (int k = 0; k < SM::NPRE; ++k) {
@@ -158,6 +160,7 @@ EMPC_HD void rollout_wave5(Exec& ex, const DevBuffers& D, int b, int nl, double*
         for (int i = 0; i < 6; ++i) ac_o[(size_t)t * DM::NACC + NV + i] = lam[i];
         L[sl].cost_try += cost;
         if (bad_number(L[sl].cost_try)) {
+          if (L[sl].ok) ncalc_l[sl] = (t + 1 < T) ? t + 1 : T;
           L[sl].ok = 0;
           alive[sl] = 0;
         } else if (t < T) {
@@ -169,6 +172,7 @@ EMPC_HD void rollout_wave5(Exec& ex, const DevBuffers& D, int b, int nl, double*
             isn = isn || (L[sl].xnext[i] != L[sl].xnext[i]);
           }
           if (isn || bad_number(mx)) {
+            if (L[sl].ok) ncalc_l[sl] = (t + 1 < T) ? t + 1 : T;
             L[sl].ok = 0;
             alive[sl] = 0;
           }
@@ -191,6 +195,7 @@ EMPC_HD void rollout_wave5(Exec& ex, const DevBuffers& D, int b, int nl, double*
     D.try_cost[slot] = L[sl].cost_try;
     D.try_dv[slot] = L[sl].dv;
     D.try_ok[slot] = L[sl].ok;
+    D.try_ncalc[slot] = L[sl].ok ? T : ncalc_l[sl];
   });
 }
 
