@@ -336,7 +336,10 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
       if (box_gains) {
         ex.each([&](int lane, int sl) {
           if (lane != n) return;
-          double Hq[m * m], qq[m], lbq[m], ubq[m], xq[m], hinv[m * m];
+          // H of the QP and the inverse of its free block live in LDS (W is dead between the symmetrise stage of the previous
+          // knot and the Vxx stage of this one): 2 m^2 doubles in the registers of one lane put the whole kernel into scratch
+          double* Hq = W;
+          double qq[m], lbq[m], ubq[m], xq[m];
           int fm[m];
           const double* usg = D.us + ((size_t)b * T + t) * m;
           const double* kprev = D.kff + ((size_t)b * T + t) * m;  // k_[t] of the previous iteration: the QP's warm start
@@ -349,11 +352,9 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
             ubq[i] = P.u_ub[i] - usg[i];
             xq[i] = kprev[i];
           }
-          const bool okq = box_qp_lane<m>(Hq, qq, lbq, ubq, xq, fm, hinv, P.prm.boxqp_maxiter, P.prm.boxqp_th_acceptstep,
+          const bool okq = box_qp_lane<m>(Hq, qq, lbq, ubq, xq, fm, Hinv, P.prm.boxqp_maxiter, P.prm.boxqp_th_acceptstep,
                                           P.prm.boxqp_th_grad, P.prm.boxqp_reg);
           flag[0] = okq ? 0.0 : 1.0;
-#pragma unroll
-          for (int i = 0; i < m * m; ++i) Hinv[i] = hinv[i];
 #pragma unroll
           for (int i = 0; i < m; ++i) {
             kf[i] = -xq[i];

@@ -26,26 +26,30 @@ EMPC_HD bool box_qp_lane(const double* H, const double* q, const double* lb, con
     x[i] = fmax(fmin(x[i], ub[i]), lb[i]);
     prev_mask[i] = -1;
   }
+  // LLT of the free block (kept: the Newton step is one pair of triangular solves, crocoddyl's Hff_inv_llt_.solveInPlace);
+  // the inverse itself (solution_.Hff_inv, which SolverBox*::computeGains multiplies with Qux) is formed at the exits only
+  double L[M * (M + 1) / 2];
   auto factor_free = [&](const int* mask) {
-    double L[M * (M + 1) / 2];
 #pragma unroll
     for (int i = 0; i < M; ++i)
 #pragma unroll
       for (int j = 0; j <= i; ++j)
         L[i * (i + 1) / 2 + j] = (mask[i] && mask[j]) ? H[i * M + j] + ((i == j) ? reg : 0.0) : ((i == j) ? 1.0 : 0.0);
     if (!chol_packed<M>(L)) return false;
+#pragma unroll
+    for (int i = 0; i < M; ++i) prev_mask[i] = mask[i];
+    have_inv = true;
+    return true;
+  };
+  auto invert_free = [&]() {
     for (int c = 0; c < M; ++c) {
       double col[M];
 #pragma unroll
       for (int i = 0; i < M; ++i) col[i] = (i == c) ? 1.0 : 0.0;
       chol_solve_packed<M>(L, col);
 #pragma unroll
-      for (int i = 0; i < M; ++i) Hinv[i * M + c] = (mask[i] && mask[c]) ? col[i] : 0.0;
+      for (int i = 0; i < M; ++i) Hinv[i * M + c] = (prev_mask[i] && prev_mask[c]) ? col[i] : 0.0;
     }
-#pragma unroll
-    for (int i = 0; i < M; ++i) prev_mask[i] = mask[i];
-    have_inv = true;
-    return true;
   };
   auto fval = [&](const double* z) {
     double f = 0;
@@ -78,6 +82,7 @@ EMPC_HD bool box_qp_lane(const double* H, const double* q, const double* lb, con
 #pragma unroll
       for (int i = 0; i < M; ++i) same = same && prev_mask[i] == free_mask[i];
       if (!same) ok = factor_free(free_mask);
+      if (ok) invert_free();
       return ok;
     }
     {
@@ -87,17 +92,20 @@ EMPC_HD bool box_qp_lane(const double* H, const double* q, const double* lb, con
       for (int i = 0; i < M; ++i) same = same && prev_mask[i] == free_mask[i];
       if (!same && !factor_free(free_mask)) return false;
     }
-    // Newton step on the free space: dxf = -Hff^-1 (qf + Hfc xc) - xf
-    for (int i = 0; i < M; ++i) {
-      double a = 0;
+    // Newton step on the free space: dxf = -Hff^-1 (qf + Hfc xc) - xf (the clamped rows of the factor are unit pivots)
+    {
+      double r[M];
+#pragma unroll
       for (int j = 0; j < M; ++j) {
-        if (!free_mask[j]) continue;
-        double r = -q[j];
+        double a = -q[j];
+#pragma unroll
         for (int c = 0; c < M; ++c)
-          if (!free_mask[c]) r -= H[j * M + c] * x[c];
-        a += Hinv[i * M + j] * r;
+          if (!free_mask[c]) a -= H[j * M + c] * x[c];
+        r[j] = free_mask[j] ? a : 0.0;
       }
-      dx[i] = free_mask[i] ? a - x[i] : 0.0;
+      chol_solve_packed<M>(L, r);
+#pragma unroll
+      for (int i = 0; i < M; ++i) dx[i] = free_mask[i] ? r[i] - x[i] : 0.0;
     }
     const double fold = fval(x);
     bool moved = false;
@@ -120,8 +128,12 @@ EMPC_HD bool box_qp_lane(const double* H, const double* q, const double* lb, con
     }
     // an iteration that left x where it was repeats itself (same gradient, same free set, same step) until maxiter: the
     // result is the one at hand (a control clamped with a non-zero multiplier keeps the gradient norm above th_grad for ever)
-    if (!moved) return true;
+    if (!moved) {
+      invert_free();
+      return true;
+    }
   }
+  if (have_inv) invert_free();
   return true;
 }
 

@@ -257,23 +257,26 @@ struct Solver {
       x[i] = std::max(std::min(xinit[i], ub[i]), lb[i]);
       prev_mask[i] = -1;
     }
+    // LLT of the free block, as an m x m problem with the clamped dimensions decoupled (unit pivots): same arithmetic on the
+    // free entries as factoring Hff alone.  The factor is kept: the Newton step is a pair of triangular solves (crocoddyl's
+    // Hff_inv_llt_.solveInPlace); the inverse (solution_.Hff_inv) is formed at the exits.
+    double Hm[NU * NU];
     auto factor_free = [&](const int* mask) {
-      // LLT of the free block, as an m x m problem with the clamped dimensions decoupled (unit pivots): same arithmetic
-      // on the free entries as factoring Hff alone
-      double Hm[NU * NU];
       for (int i = 0; i < m; ++i)
         for (int j = 0; j < m; ++j)
           Hm[i * m + j] = (mask[i] && mask[j]) ? H[i * m + j] + ((i == j) ? P.prm.boxqp_reg : 0.0) : ((i == j) ? 1.0 : 0.0);
       if (!cholesky(Hm, m)) return false;
+      for (int i = 0; i < m; ++i) prev_mask[i] = mask[i];
+      have_inv = true;
+      return true;
+    };
+    auto invert_free = [&]() {
       for (int c = 0; c < m; ++c) {
         double col[NU];
         for (int i = 0; i < m; ++i) col[i] = (i == c) ? 1.0 : 0.0;
         cholesky_solve(Hm, m, col);
-        for (int i = 0; i < m; ++i) Hinv[i * m + c] = (mask[i] && mask[c]) ? col[i] : 0.0;
+        for (int i = 0; i < m; ++i) Hinv[i * m + c] = (prev_mask[i] && prev_mask[c]) ? col[i] : 0.0;
       }
-      for (int i = 0; i < m; ++i) prev_mask[i] = mask[i];
-      have_inv = true;
-      return true;
     };
     for (int k = 0; k < P.prm.boxqp_maxiter; ++k) {
       double gmax = 0;
@@ -293,6 +296,7 @@ struct Solver {
         bool same = have_inv;
         for (int i = 0; i < m; ++i) same = same && prev_mask[i] == free_mask[i];
         if (!same && !factor_free(free_mask)) return false;  // (the reference factors at k == 0; later it keeps the last one)
+        invert_free();
         return true;
       }
       {
@@ -300,19 +304,17 @@ struct Solver {
         for (int i = 0; i < m; ++i) same = same && prev_mask[i] == free_mask[i];
         if (!same && !factor_free(free_mask)) return false;  // an unchanged free set keeps its factorisation
       }
-      // Newton step on the free space: dxf = -Hff^-1 (qf + Hfc xc) - xf
-      for (int i = 0; i < m; ++i) {
-        dx[i] = 0;
-        if (!free_mask[i]) continue;
-        double a = 0;
+      // Newton step on the free space: dxf = -Hff^-1 (qf + Hfc xc) - xf (the clamped rows of the factor are unit pivots)
+      {
+        double r[NU];
         for (int j = 0; j < m; ++j) {
-          if (!free_mask[j]) continue;
-          double r = -q[j];
+          double a = -q[j];
           for (int c = 0; c < m; ++c)
-            if (!free_mask[c]) r -= H[j * m + c] * x[c];
-          a += Hinv[i * m + j] * r;
+            if (!free_mask[c]) a -= H[j * m + c] * x[c];
+          r[j] = free_mask[j] ? a : 0.0;
         }
-        dx[i] = a - x[i];
+        cholesky_solve(Hm, m, r);
+        for (int i = 0; i < m; ++i) dx[i] = free_mask[i] ? r[i] - x[i] : 0.0;
       }
       auto fval = [&](const double* z) {
         double f = 0;
@@ -336,6 +338,7 @@ struct Solver {
         }
       }
     }
+    if (have_inv) invert_free();
     return true;
   }
 
