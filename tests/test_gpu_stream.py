@@ -43,3 +43,25 @@ def test_stream_argument_errors(empc, problems):
     s.stream_begin(np.tile(problem.x0, (3, 1)))
     with pytest.raises(empc.EmpcError, match="trace"):
         s.stream_run(10)
+
+
+@pytest.mark.parametrize("variant", ["SolverBoxFDDP", "SolverBoxDDP", "RK4"])
+def test_stream_of_option_variants(empc, variant):
+    """The queue form with the box solvers (the QP warm start k_ of a refilled slot is a fresh solver's: zero) and with RK4
+    nodes: rows bitwise those of plain batched solves."""
+    tr = empc.Trajectory()
+    tr.autoSetup(empc.yaml_path("hexacopter370_flying_arm_3/trajectories/displacement.yaml"))
+    if variant == "RK4":
+        problem, cls, maxiter = tr.createProblem(80, True, "IntegratedActionModelRK4"), empc.SolverSbFDDP, 100
+    else:
+        problem, cls, maxiter = tr.createProblem(80, False, "IntegratedActionModelEuler"), getattr(empc, variant), 30
+    d = problem.desc
+    jobs, slots = 24, 8
+    x0s = empc.perturbed_x0s(problem.x0, jobs, nq=d.model.nq)
+    plain = cls(problem, batch=jobs)
+    plain.solve([], [], maxiter, x0s=x0s)
+    s = cls(problem, batch=slots)
+    r = s.solve_stream(x0s, maxiter)
+    assert np.array_equal(r["iter"], plain.iter_batch) and np.array_equal(r["status"], plain.status_batch)
+    assert np.array_equal(r["xs"], plain.xs_batch, equal_nan=True) and np.array_equal(r["us"], plain.us_batch, equal_nan=True)
+    assert np.array_equal(r["us_squash"], plain.us_squash_batch, equal_nan=True)
