@@ -207,6 +207,25 @@ class SquashingModelSmoothSat:
         self.smooth = 0.1
 
 
+class PlatformParams:
+    """MultiCopterBaseParams as far as the hot path reads it: tau_f (6 x n_rotors), control limits (rotor thrusts, then arm
+    joint torques), n_rotors."""
+
+    def __init__(self, tau_f, u_lb, u_ub):
+        self.tau_f, self.u_lb, self.u_ub = tau_f, u_lb, u_ub
+        self.n_rotors = tau_f.shape[1]
+        self.max_thrust, self.min_thrust = float(u_ub[0]), float(u_lb[0])
+
+
+class RobotModel:
+    """What `trajectory.robot_model` / `mpcController.robot_model` hand to user code: name and dimensions.  `_owner` is the
+    object whose kinematic tree this is (a Trajectory or a controller): utils.simulator.AerialSimulator runs its plant on
+    the owner's device-side model."""
+
+    def __init__(self, name, nq, nv, owner):
+        self.name, self.nq, self.nv, self._owner = name, nq, nv, owner
+
+
 class Trajectory:
     """Mirror of eagle_mpc.Trajectory (bindings/python/eagle_mpc/trajectory.hpp:24-63)."""
 
@@ -256,6 +275,18 @@ class Trajectory:
         ub = np.zeros(self.nu)
         _check(lib().empc_trajectory_get_platform(self._h, _ptr(tau_f), _ptr(lb), _ptr(ub), C.byref(n)))
         return tau_f, lb, ub
+
+    @property
+    def platform_params(self):
+        """get_platform_params(): the fields of MultiCopterBaseParams the hot path uses (tau_f, u_lb, u_ub, n_rotors;
+        bindings/python/eagle_mpc/multicopter-base-params.hpp)"""
+        tau_f, lb, ub = self.platform()
+        return PlatformParams(tau_f, lb, ub)
+
+    @property
+    def robot_model(self):
+        """get_robot_model(): a handle naming the robot (the pinocchio model itself lives behind the C ABI as EmpcModelDesc)"""
+        return RobotModel(self.get_param("robot/name").strip(chr(34)), self.nx - self.ndx // 2, self.ndx // 2, self)
 
     @property
     def squash(self):
@@ -779,6 +810,16 @@ class CarrotMpc:
             self._solver = cls(self.problem, batch=self._batch, device=self._device, params=self._params)
         return self._solver
 
+    @property
+    def robot_model(self):
+        """get_robot_model() of MpcAbstract (include/eagle_mpc/mpc-base.hpp)"""
+        m = self.problem.desc.model
+        return RobotModel(self.trajectory.robot_model.name, m.nq, m.nv, self)
+
+    @property
+    def platform_params(self):
+        return self.trajectory.platform_params
+
     def updateProblem(self, current_time):
         _check(lib().empc_carrot_mpc_update_problem(self._h, int(current_time)))
         if self._solver is not None:
@@ -817,6 +858,18 @@ class _Mpc:
             cls = _SOLVER_CLASSES[lib().empc_mpc_solver_type(None, self._h)]
             self._solver = cls(self.problem, batch=self._batch, device=self._device, params=self._params)
         return self._solver
+
+    @property
+    def robot_model(self):
+        m = self.problem.desc.model
+        tr = getattr(self, "trajectory", None)
+        return RobotModel(tr.robot_model.name if tr is not None else "robot", m.nq, m.nv, self)
+
+    @property
+    def platform_params(self):
+        d = self.problem.desc
+        tau_f = np.array([[d.tau_f[r * d.n_rotors + c] for c in range(d.n_rotors)] for r in range(6)])
+        return PlatformParams(tau_f, np.array([d.u_lb[i] for i in range(d.nu)]), np.array([d.u_ub[i] for i in range(d.nu)]))
 
     def updateProblem(self, current_time):
         _check(lib().empc_mpc_update_problem(self._h, int(current_time)))
