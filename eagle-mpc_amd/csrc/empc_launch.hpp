@@ -87,19 +87,19 @@ struct RoleExec {
   // drain them (vmcnt(0)) twice per knot.
   __device__ __forceinline__ void sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 };
-template <class DM, int CT>
+template <class DM, int CT, bool RK4>
 __global__ void __launch_bounds__(64 * R6_WAVES) k_rollout6(DevBuffers D) {
   extern __shared__ double smem_roll6[];
   RoleExec ex{(int)(threadIdx.x & 63)};
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: the role switch is a scalar branch
   if (wave == R6_A)
-    rollout_group6<DM, CT, R6_A>(ex, D, blockIdx.x, smem_roll6);
+    rollout_group6<DM, CT, R6_A, RoleExec, RK4>(ex, D, blockIdx.x, smem_roll6);
   else if (wave == R6_B)
-    rollout_group6<DM, CT, R6_B>(ex, D, blockIdx.x, smem_roll6);
+    rollout_group6<DM, CT, R6_B, RoleExec, RK4>(ex, D, blockIdx.x, smem_roll6);
   else if (wave == R6_C)
-    rollout_group6<DM, CT, R6_C>(ex, D, blockIdx.x, smem_roll6);
+    rollout_group6<DM, CT, R6_C, RoleExec, RK4>(ex, D, blockIdx.x, smem_roll6);
   else
-    rollout_group6<DM, CT, R6_D>(ex, D, blockIdx.x, smem_roll6);
+    rollout_group6<DM, CT, R6_D, RoleExec, RK4>(ex, D, blockIdx.x, smem_roll6);
 }
 
 // constraint rows of the contact of knot t (3 when the knot has none)
@@ -416,7 +416,7 @@ __global__ void __launch_bounds__(64) k_rk4_stages(DevBuffers D, Rk4Buffers R) {
 template <class DM>
 __global__ void __launch_bounds__(64) k_rk4_assemble(DevBuffers D, Rk4Buffers R) {
   extern __shared__ double smem_rk4[];
-  LaneExec ex{(int)threadIdx.x};
+  BlockExec ex{(int)threadIdx.x};  // one wavefront per node; the products run on the matrix cores
   const int u = blockIdx.x;
   rk4_assemble_unit<DM>(ex, D, R, u % D.B, u / D.B, 64, smem_rk4);
 }
@@ -454,17 +454,21 @@ static void launch_rollout(DevBuffers D, hipStream_t s) {
     const char* e = getenv("EMPC_ROLLOUT");  // 6 = packed role-split form (default), 1 = per-lane form
     return e ? atoi(e) : 6;
   }();
-  if (version == 1 || D.NA > MAX_ALPHAS || D.integrator != EMPC_INTEGRATOR_EULER) {  // RK4 nodes, > 16 step lengths: the per-lane form
+  if (version == 1 || D.NA > MAX_ALPHAS) {  // > 16 step lengths: the per-lane form
     hipLaunchKernelGGL((k_rollout<DM, CT>), dim3((n + 63) / 64), dim3(64), 0, s, D);
   } else {
     const size_t smem = sizeof(double) * Roll6Smem<DM>::SIZE;
     static const bool once = [&] {  // more than 64 KB of dynamic LDS needs the opt-in
-      (void)hipFuncSetAttribute((const void*)k_rollout6<DM, CT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      (void)hipFuncSetAttribute((const void*)k_rollout6<DM, CT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      (void)hipFuncSetAttribute((const void*)k_rollout6<DM, CT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       return true;
     }();
     (void)once;
     const int G = roll6_group_size(D.NA);
-    hipLaunchKernelGGL((k_rollout6<DM, CT>), dim3((D.B + G - 1) / G), dim3(64 * R6_WAVES), smem, s, D);
+    if (D.integrator == EMPC_INTEGRATOR_RK4)
+      hipLaunchKernelGGL((k_rollout6<DM, CT, true>), dim3((D.B + G - 1) / G), dim3(64 * R6_WAVES), smem, s, D);
+    else
+      hipLaunchKernelGGL((k_rollout6<DM, CT, false>), dim3((D.B + G - 1) / G), dim3(64 * R6_WAVES), smem, s, D);
   }
 }
 template <class DM>

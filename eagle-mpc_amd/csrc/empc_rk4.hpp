@@ -75,49 +75,35 @@ EMPC_HD void rk4_stage_thread(const DevBuffers& D, const Rk4Buffers& R, int b, i
 }
 
 // ---- step 3 -----------------------------------------------------------------------------------------------------------
+// The chain rule through the four stages is dense n x n / n x (n + m) algebra per node: every product runs on the matrix
+// cores (v_mfma_f64_16x16x4_f64, the operand conventions of the backward pass), its operands in zero-padded LDS arrays with
+// an odd row stride.  Per stage i, with DY = [dy_i/dx | dy_i/du] (n x nm):
+//   DK rows nv..   = A_i DY (+ B_i on the control columns)          A_i = da/dy, B_i = da/du of the stage's raw record
+//   Z              = w_i (lxx_i DY + [0 | lxu_i])
+//   [Lxx Lxu; . Luu] += DY^T Z,   Luu += w_i (luu_i + lxu_i^T DYU)  (the transposed term that DY^T Z lacks)
+// Before: every element of every product one dot product out of LDS (two LDS reads per multiply-add, 39 KB of LDS per
+// wavefront = one wavefront per SIMD): 7.7 ms per launch at B = 1024, the longest kernel of an RK4 sweep.
 template <class DM>
 struct Rk4Smem {
-  static constexpr int n = DM::NDX, m = DM::NU, nv = DM::NV;
-  static constexpr int OFF_J = 0;                      // 4 x (J1 36 | J2 36): stages 1..3 and the final step
-  static constexpr int OFF_DYX = OFF_J + 4 * 72;       // dy_i/dx      n x n
-  static constexpr int OFF_DYU = OFF_DYX + n * n;      // dy_i/du      n x m
-  static constexpr int OFF_DKX = OFF_DYU + n * m;      // dk_{i}/dx    n x n
-  static constexpr int OFF_DKU = OFF_DKX + n * n;      // dk_{i}/du    n x m
-  static constexpr int OFF_XX = OFF_DKU + n * m;       // lxx_i dy_i/dx
-  static constexpr int OFF_XU = OFF_XX + n * n;        // lxx_i dy_i/du
-  static constexpr int OFF_RAW = OFF_XU + n * m;       // the stage's raw record
-  static constexpr int OFF_SKX = OFF_RAW + (DM::REC + 63) / 64 * 64;  // sum w_i dk_i/dx, then Fx
-  static constexpr int OFF_SKU = OFF_SKX + n * n;
-  static constexpr int OFF_LXX = OFF_SKU + n * m;      // accumulators of the node's cost derivatives
-  static constexpr int OFF_LXU = OFF_LXX + n * n;
-  static constexpr int OFF_LUU = OFF_LXU + n * m;
-  static constexpr int OFF_LX = OFF_LUU + m * m;
-  static constexpr int OFF_LU = OFF_LX + n;
-  static constexpr int OFF_K = OFF_LU + m;             // k_0..k_3 (4 x n), dx (n), cost parts (4)
-  static constexpr int SIZE = (OFF_K + 5 * n + 4 + 1) / 2 * 2;
+  static constexpr int n = DM::NDX, m = DM::NU, nv = DM::NV, nm = n + m;
+  static constexpr int NT = (nm + 15) / 16;   // column tiles of [x | u]
+  static constexpr int MTX = (n + 15) / 16;   // row tiles of an n-row product
+  static constexpr int MTA = (nv + 15) / 16;  // row tiles of the acceleration rows
+  static constexpr int MTU = (m + 15) / 16;
+  static constexpr int KS = (n + 3) / 4;      // k steps over the state dimension
+  static constexpr int KR = 4 * KS;           // rows of DY / Z / DK (rows >= n stay zero)
+  static constexpr int LD = 16 * NT + 1;      // their row stride (columns >= nm stay zero)
+  static constexpr int PLD = 16 * MTU + 1;
+  static constexpr int OFF_J = 0;                       // 4 x (J1 36 | J2 36): stages 1..3 and the final step
+  static constexpr int OFF_DY = OFF_J + 4 * 72;
+  static constexpr int OFF_Z = OFF_DY + KR * LD;
+  static constexpr int OFF_DK = OFF_Z + KR * LD;
+  static constexpr int OFF_P = OFF_DK + KR * LD;        // the Luu tile that is not part of DY^T Z, for the store
+  static constexpr int OFF_K = OFF_P + 16 * MTU * PLD;  // k_0..k_3 (4 x n), dx (n), cost parts (4)
+  static constexpr int OFF_RAW = (OFF_K + 5 * n + 4 + 1) / 2 * 2;  // the stage's raw record
+  static constexpr int SIZE = (OFF_RAW + (DM::REC + 63) / 64 * 64 + 1) / 2 * 2;
+  static constexpr int NSK = (n * nm + 63) / 64;        // elements of sum w_i dk_i per lane
 };
-
-// blkdiag(J (6 x 6), I) from the left on an n x cols matrix held in LDS, in place; all lanes cooperate (one column each)
-template <class Exec>
-EMPC_HD void rk4_apply_block(Exec& ex, const double* J6, double* M, int cols, int nl) {
-  ex.each([&](int lane, int sl) {
-    for (int j = lane; j < cols; j += nl) {
-      double col[6], out[6];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) col[i] = M[i * cols + j];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        double a_ = 0;
-#pragma unroll
-        for (int l = 0; l < 6; ++l) a_ += J6[i * 6 + l] * col[l];
-        out[i] = a_;
-      }
-#pragma unroll
-      for (int i = 0; i < 6; ++i) M[i * cols + j] = out[i];
-    }
-  });
-  ex.sync();
-}
 
 // Jintegrate blocks of StateMultibody at step d: J1 = Ad(exp6(d)^-1) (derivative w.r.t. x), J2 = Jexp6(d) (w.r.t. d)
 EMPC_HD void rk4_jint_blocks(const double* d, double* J1, double* J2) {
@@ -138,12 +124,14 @@ EMPC_HD void rk4_jint_blocks(const double* d, double* J1, double* J2) {
     }
 }
 
-// One (trajectory, knot) unit, nl lanes (one wavefront).  Raw records: da/dy in rows nv.. of the Fx block, da/du in rows
+// One (trajectory, knot) unit on one wavefront (nl = 64 lanes).  Raw records: da/dy in rows nv.. of the Fx block, da/du in rows
 // nv.. of the Fu block, cost blocks unscaled (linearize in RAW mode).
 template <class DM, class Exec>
 EMPC_HD void rk4_assemble_unit(Exec& ex, const DevBuffers& D, const Rk4Buffers& R, int b, int t, int nl, double* N) {
   typedef Rk4Smem<DM> SM;
-  constexpr int n = DM::NDX, m = DM::NU, nv = DM::NV, NX = DM::NX, NQ = DM::NQ, REC = DM::REC, NM = DM::NM;
+  constexpr int n = DM::NDX, m = DM::NU, nv = DM::NV, nm = n + m, NX = DM::NX, NQ = DM::NQ, REC = DM::REC, NM = DM::NM;
+  constexpr int NT = SM::NT, MTX = SM::MTX, MTA = SM::MTA, MTU = SM::MTU, KS = SM::KS, LD = SM::LD, PLD = SM::PLD;
+  static_assert(NM == nm, "the record's row stride is n + m");
   const TrajState& st = D.st[b];
   if (st.phase == PHASE_DONE || !st.need_lin) return;
   const EMPC_K DevProblem& P = EMPC_KREF(DevProblem, D.P);
@@ -153,42 +141,40 @@ EMPC_HD void rk4_assemble_unit(Exec& ex, const DevBuffers& D, const Rk4Buffers& 
   const double dt = P.dt;
   const double rk4_c[4] = {0.0, 0.5, 0.5, 1.0};
   double* Jb = N + SM::OFF_J;
-  double* DYX = N + SM::OFF_DYX;
-  double* DYU = N + SM::OFF_DYU;
-  double* DKX = N + SM::OFF_DKX;
-  double* DKU = N + SM::OFF_DKU;
-  double* XX = N + SM::OFF_XX;
-  double* XU = N + SM::OFF_XU;
-  double* RAW = N + SM::OFF_RAW;
-  double* SKX = N + SM::OFF_SKX;
-  double* SKU = N + SM::OFF_SKU;
-  double* LXX = N + SM::OFF_LXX;
-  double* LXU = N + SM::OFF_LXU;
-  double* LUU = N + SM::OFF_LUU;
-  double* LX = N + SM::OFF_LX;
-  double* LU = N + SM::OFF_LU;
+  double* DY = N + SM::OFF_DY;
+  double* Z = N + SM::OFF_Z;
+  double* DK = N + SM::OFF_DK;
+  double* PT = N + SM::OFF_P;
   double* KK = N + SM::OFF_K;
+  double* RAW = N + SM::OFF_RAW;
   const double* xg = D.xs + ((size_t)b * (T + 1) + t) * NX;
   double* out = D.tape + ((size_t)b * (T + 1) + t) * REC;
 
-  // k_i = [v(y_i); a_i], dx = dt/6 (k0 + 2 k1 + 2 k2 + k3); zero the accumulators
+  // accumulators that live across the stages: the cost Hessian tiles, the extra Luu tile, Lx | Lu (lane = column), sum w dk
+  double accL[Exec::SLOTS][NT][NT][4], accP[Exec::SLOTS][MTU][MTU][4], lxu[Exec::SLOTS], sk[Exec::SLOTS][SM::NSK];
   ex.each([&](int lane, int sl) {
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+      for (int c = 0; c < NT; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) accL[sl][a][c][r] = 0.0;
+#pragma unroll
+    for (int a = 0; a < MTU; ++a)
+#pragma unroll
+      for (int c = 0; c < MTU; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) accP[sl][a][c][r] = 0.0;
+    lxu[sl] = 0.0;
+#pragma unroll
+    for (int q = 0; q < SM::NSK; ++q) sk[sl][q] = 0.0;
+    // k_i = [v(y_i); a_i]; the padded operand arrays start from zero (rows >= n and columns >= nm are never written)
     for (int e = lane; e < 4 * n; e += nl) {
       const int i = e / n, j = e % n;
       const size_t bs = (size_t)4 * b + i;
       KK[e] = (j < nv) ? R.ys[(bs * (T + 1) + t) * NX + NQ + j] : R.accs[(bs * (T + 1) + t) * DM::NACC + (j - nv)];
     }
-    for (int e = lane; e < n * n; e += nl) {
-      SKX[e] = 0.0;
-      LXX[e] = 0.0;
-    }
-    for (int e = lane; e < n * m; e += nl) {
-      SKU[e] = 0.0;
-      LXU[e] = 0.0;
-    }
-    for (int e = lane; e < m * m; e += nl) LUU[e] = 0.0;
-    if (lane < n) LX[lane] = 0.0;
-    if (lane < m) LU[lane] = 0.0;
+    for (int e = lane; e < 3 * SM::KR * LD; e += nl) DY[e] = 0.0;  // DY, Z, DK are contiguous
   });
   ex.sync();
   ex.each([&](int lane, int sl) {
@@ -206,143 +192,227 @@ EMPC_HD void rk4_assemble_unit(Exec& ex, const DevBuffers& D, const Rk4Buffers& 
   });
   ex.sync();
 
+  // the raw record of the next stage travels in registers while the current stage is worked on (one memory latency per
+  // stage would otherwise sit in front of every stage of this one-wavefront-per-SIMD kernel)
+  constexpr int NPRE = (REC + 63) / 64;
+  double pre[Exec::SLOTS][NPRE];
+  auto fetch_raw = [&](int sg, int lane, int sl) {
+    const double* rr = R.tape4 + (((size_t)4 * b + sg) * (T + 1) + t) * REC;
+#pragma unroll
+    for (int q = 0; q < NPRE; ++q) {
+      const int e = lane + q * nl;
+      pre[sl][q] = rr[e < REC ? e : REC - 1];
+    }
+  };
+  ex.each([&](int lane, int sl) { fetch_raw(0, lane, sl); });
   for (int sg = 0; sg < 4; ++sg) {
     const double w = (sg == 0 || sg == 3) ? 1.0 : 2.0;
-    // raw record of the stage -> LDS
+    // raw record of the stage -> LDS;  DY of the stage, one column per lane: blkdiag(J2, I) (c dt DK) + blkdiag(J1, I) | 0
     {
-      const double* rr = R.tape4 + (((size_t)4 * b + sg) * (T + 1) + t) * REC;
-      ex.each([&](int lane, int sl) {
-        for (int e = lane; e < REC; e += nl) RAW[e] = rr[e];
-      });
-    }
-    // dy_i/dx, dy_i/du
-    if (sg == 0) {
-      ex.each([&](int lane, int sl) {
-        for (int e = lane; e < n * n; e += nl) DYX[e] = ((e / n) == (e % n)) ? 1.0 : 0.0;
-        for (int e = lane; e < n * m; e += nl) DYU[e] = 0.0;
-      });
-      ex.sync();
-    } else {
       const double cdt = rk4_c[sg] * dt;
-      ex.each([&](int lane, int sl) {
-        for (int e = lane; e < n * n; e += nl) DYX[e] = cdt * DKX[e];
-        for (int e = lane; e < n * m; e += nl) DYU[e] = cdt * DKU[e];
-      });
-      ex.sync();
-      const double* J1 = Jb + (sg - 1) * 72;
+      const double* J1 = Jb + (sg > 0 ? sg - 1 : 0) * 72;
       const double* J2 = J1 + 36;
-      rk4_apply_block(ex, J2, DYX, n, nl);
-      rk4_apply_block(ex, J2, DYU, m, nl);
       ex.each([&](int lane, int sl) {
-        for (int e = lane; e < n * n; e += nl) {
-          const int r = e / n, q = e % n;
-          DYX[e] += (r < 6 && q < 6) ? J1[r * 6 + q] : ((r >= 6 && r == q) ? 1.0 : 0.0);
+#pragma unroll
+        for (int q = 0; q < NPRE; ++q) {
+          const int e = lane + q * nl;
+          if (e < REC) RAW[e] = pre[sl][q];
+        }
+        if (sg < 3) fetch_raw(sg + 1, lane, sl);
+        if (lane >= nm) return;
+        const int c = lane;
+        if (sg == 0) {
+          for (int i = 0; i < n; ++i) DY[i * LD + c] = (i == c) ? 1.0 : 0.0;
+        } else {
+          double col[6];
+#pragma unroll
+          for (int i = 0; i < 6; ++i) col[i] = cdt * DK[i * LD + c];
+#pragma unroll
+          for (int i = 0; i < 6; ++i) {
+            double a_ = 0;
+#pragma unroll
+            for (int l = 0; l < 6; ++l) a_ += J2[i * 6 + l] * col[l];
+            DY[i * LD + c] = a_ + ((c < 6) ? J1[i * 6 + c] : 0.0);
+          }
+          for (int i = 6; i < n; ++i) DY[i * LD + c] = cdt * DK[i * LD + c] + ((i == c) ? 1.0 : 0.0);
         }
       });
-      ex.sync();
     }
-    // dk_i/dx, dk_i/du: velocity rows are rows of dy_i, acceleration rows A_i dy_i (+ B_i)
-    ex.each([&](int lane, int sl) {
-      for (int e = lane; e < n * n; e += nl) {
-        const int r = e / n, q = e % n;
-        double v_;
-        if (r < nv) {
-          v_ = DYX[(nv + r) * n + q];
-        } else {
-          v_ = 0;
-          for (int l = 0; l < n; ++l) v_ += RAW[DM::OFF_FX + r * NM + l] * DYX[l * n + q];
-        }
-        DKX[e] = v_;
-      }
-      for (int e = lane; e < n * m; e += nl) {
-        const int r = e / m, q = e % m;
-        double v_;
-        if (r < nv) {
-          v_ = DYU[(nv + r) * m + q];
-        } else {
-          v_ = RAW[DM::OFF_FU + r * NM + q];
-          for (int l = 0; l < n; ++l) v_ += RAW[DM::OFF_FX + r * NM + l] * DYU[l * m + q];
-        }
-        DKU[e] = v_;
-      }
-      // lxx_i dy_i/dx, lxx_i dy_i/du
-      for (int e = lane; e < n * n; e += nl) {
-        const int r = e / n, q = e % n;
-        double v_ = 0;
-        for (int l = 0; l < n; ++l) v_ += RAW[DM::OFF_LXX + r * NM + l] * DYX[l * n + q];
-        XX[e] = v_;
-      }
-      for (int e = lane; e < n * m; e += nl) {
-        const int r = e / m, q = e % m;
-        double v_ = 0;
-        for (int l = 0; l < n; ++l) v_ += RAW[DM::OFF_LXX + r * NM + l] * DYU[l * m + q];
-        XU[e] = v_;
-      }
-    });
     ex.sync();
-    // accumulate
+    // A_i DY and lxx_i DY
+    double accA[Exec::SLOTS][MTA][NT][4], accB[Exec::SLOTS][MTX][NT][4];
     ex.each([&](int lane, int sl) {
-      for (int e = lane; e < n * n; e += nl) {
-        const int r = e / n, q = e % n;
-        SKX[e] += w * DKX[e];
-        double v_ = 0;
-        for (int l = 0; l < n; ++l) v_ += DYX[l * n + r] * XX[l * n + q];
-        LXX[e] += w * v_;
+#pragma unroll
+      for (int a = 0; a < MTA; ++a)
+#pragma unroll
+        for (int c = 0; c < NT; ++c)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) accA[sl][a][c][r] = 0.0;
+#pragma unroll
+      for (int a = 0; a < MTX; ++a)
+#pragma unroll
+        for (int c = 0; c < NT; ++c)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) accB[sl][a][c][r] = 0.0;
+    });
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      // (columns 4 ks + lq >= n of the A operands meet the zero rows of DY; rows beyond the block are clamped: their products
+      //  land in rows nobody stores)
+      double aA[Exec::SLOTS][MTA], aB[Exec::SLOTS][MTX], bY[Exec::SLOTS][NT];
+      ex.each([&](int lane, int sl) {
+        const int li = lane % 16, lq = lane / 16;
+#pragma unroll
+        for (int a = 0; a < MTA; ++a) {
+          const int row = nv + 16 * a + li;
+          aA[sl][a] = RAW[DM::OFF_FX + (row < n ? row : n - 1) * NM + 4 * ks + lq];
+        }
+#pragma unroll
+        for (int a = 0; a < MTX; ++a) {
+          const int row = 16 * a + li;
+          aB[sl][a] = RAW[DM::OFF_LXX + (row < n ? row : n - 1) * NM + 4 * ks + lq];
+        }
+#pragma unroll
+        for (int c = 0; c < NT; ++c) bY[sl][c] = DY[(4 * ks + lq) * LD + 16 * c + li];
+      });
+#pragma unroll
+      for (int c = 0; c < NT; ++c) {
+#pragma unroll
+        for (int a = 0; a < MTA; ++a) ex.mfma(aA, a, bY, c, accA, a, c);
+#pragma unroll
+        for (int a = 0; a < MTX; ++a) ex.mfma(aB, a, bY, c, accB, a, c);
       }
-      for (int e = lane; e < n * m; e += nl) {
-        const int r = e / m, q = e % m;
-        SKU[e] += w * DKU[e];
-        double v_ = 0;
-        for (int l = 0; l < n; ++l) v_ += DYX[l * n + r] * (RAW[DM::OFF_LXU + l * NM + q] + XU[l * m + q]);
-        LXU[e] += w * v_;
+    }
+    // DK = [velocity rows of DY; A_i DY + B_i],  Z = w (lxx_i DY + [0 | lxu_i]),  Lx | Lu,  the raw Luu
+    ex.each([&](int lane, int sl) {
+      const int lj = lane % 16, lq = lane / 16;
+#pragma unroll
+      for (int c = 0; c < NT; ++c) {
+        const int col = 16 * c + lj;
+        if (col >= nm) continue;
+#pragma unroll
+        for (int a = 0; a < MTA; ++a)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * a + 4 * r + lq;
+            if (row < nv)
+              DK[(nv + row) * LD + col] = accA[sl][a][c][r] + ((col >= n) ? RAW[DM::OFF_FU + (nv + row) * NM + col - n] : 0.0);
+          }
+#pragma unroll
+        for (int a = 0; a < MTX; ++a)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * a + 4 * r + lq;
+            if (row < n) Z[row * LD + col] = w * (accB[sl][a][c][r] + ((col >= n) ? RAW[DM::OFF_LXU + row * NM + col - n] : 0.0));
+          }
       }
-      for (int e = lane; e < m * m; e += nl) {
-        const int r = e / m, q = e % m;
-        double v_ = RAW[DM::OFF_LUU + r * m + q];
-        for (int l = 0; l < n; ++l)
-          v_ += RAW[DM::OFF_LXU + l * NM + r] * DYU[l * m + q] + DYU[l * m + r] * RAW[DM::OFF_LXU + l * NM + q] + DYU[l * m + r] * XU[l * m + q];
-        LUU[e] += w * v_;
+      for (int e = lane; e < nv * nm; e += nl) {
+        const int r = e / nm, c = e % nm;
+        DK[r * LD + c] = DY[(nv + r) * LD + c];
       }
-      if (lane < n) {
-        double v_ = 0;
-        for (int l = 0; l < n; ++l) v_ += DYX[l * n + lane] * RAW[DM::OFF_LX + l];
-        LX[lane] += w * v_;
-      } else if (lane - n < m && lane >= n) {
-        const int q = lane - n;
-        double v_ = RAW[DM::OFF_LU + q];
-        for (int l = 0; l < n; ++l) v_ += DYU[l * m + q] * RAW[DM::OFF_LX + l];
-        LU[q] += w * v_;
+#pragma unroll
+      for (int a = 0; a < MTU; ++a)
+#pragma unroll
+        for (int c = 0; c < MTU; ++c)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = 16 * a + 4 * r + lq, j = 16 * c + lj;
+            if (i < m && j < m) accP[sl][a][c][r] += w * RAW[DM::OFF_LUU + i * m + j];
+          }
+      if (lane < nm) {
+        double v_ = (lane >= n) ? RAW[DM::OFF_LU + lane - n] : 0.0;
+        for (int l = 0; l < n; ++l) v_ += DY[l * LD + lane] * RAW[DM::OFF_LX + l];
+        lxu[sl] += w * v_;
       }
       if (lane == nl - 1) KK[5 * n + sg] = RAW[DM::OFF_COST];
     });
     ex.sync();
+    // DY^T Z on the Hessian tiles; lxu_i^T (w DYU) on the extra Luu tile; sum w dk
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      double aY[Exec::SLOTS][NT], bZ[Exec::SLOTS][NT], aX[Exec::SLOTS][MTU], bU[Exec::SLOTS][MTU];
+      ex.each([&](int lane, int sl) {
+        const int li = lane % 16, lq = lane / 16;
+        const int kr = 4 * ks + lq;
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+          aY[sl][c] = DY[kr * LD + 16 * c + li];
+          bZ[sl][c] = Z[kr * LD + 16 * c + li];
+        }
+#pragma unroll
+        for (int c = 0; c < MTU; ++c) {
+          const int u = 16 * c + li;
+          aX[sl][c] = RAW[DM::OFF_LXU + (kr < n ? kr : n - 1) * NM + (u < m ? u : m - 1)];
+          bU[sl][c] = w * DY[kr * LD + n + (u < m ? u : m - 1)];
+        }
+      });
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int c = 0; c < NT; ++c) ex.mfma(aY, a, bZ, c, accL, a, c);
+#pragma unroll
+      for (int a = 0; a < MTU; ++a)
+#pragma unroll
+        for (int c = 0; c < MTU; ++c) ex.mfma(aX, a, bU, c, accP, a, c);
+    }
+    ex.each([&](int lane, int sl) {
+#pragma unroll
+      for (int q = 0; q < SM::NSK; ++q) {
+        const int e = lane + q * nl;
+        if (e < n * nm) sk[sl][q] += w * DK[(e / nm) * LD + e % nm];
+      }
+    });
+    ex.sync();
   }
-  // Fx = blk(J2) (dt/6 sum w dk/dx) + blk(J1, I), Fu = blk(J2) (dt/6 sum w dk/du)
+  // Fx = blk(J2) (dt/6 sum w dk/dx) + blk(J1, I), Fu = blk(J2) (dt/6 sum w dk/du); the extra Luu tile -> LDS
   ex.each([&](int lane, int sl) {
-    for (int e = lane; e < n * n; e += nl) SKX[e] = SKX[e] * dt / 6.0;
-    for (int e = lane; e < n * m; e += nl) SKU[e] = SKU[e] * dt / 6.0;
+    const int lj = lane % 16, lq = lane / 16;
+#pragma unroll
+    for (int q = 0; q < SM::NSK; ++q) {
+      const int e = lane + q * nl;
+      if (e < n * nm) DK[(e / nm) * LD + e % nm] = sk[sl][q] * dt / 6.0;
+    }
+#pragma unroll
+    for (int a = 0; a < MTU; ++a)
+#pragma unroll
+      for (int c = 0; c < MTU; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) PT[(16 * a + 4 * r + lq) * PLD + 16 * c + lj] = accP[sl][a][c][r];
   });
   ex.sync();
   {
     const double* J1 = Jb + 3 * 72;
     const double* J2 = J1 + 36;
-    rk4_apply_block(ex, J2, SKX, n, nl);
-    rk4_apply_block(ex, J2, SKU, m, nl);
     const double cscale = (terminal && !P.prm.terminal_dt_scaling) ? 1.0 / 6.0 : dt / 6.0;
     ex.each([&](int lane, int sl) {
-      for (int e = lane; e < n * n; e += nl) {
-        const int r = e / n, q = e % n;
-        out[DM::OFF_FX + r * NM + q] = SKX[e] + ((r < 6 && q < 6) ? J1[r * 6 + q] : ((r >= 6 && r == q) ? 1.0 : 0.0));
-        out[DM::OFF_LXX + r * NM + q] = LXX[e] * cscale;
+      const int lj = lane % 16, lq = lane / 16;
+      if (lane < nm) {
+        const int c = lane;
+        double col[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) col[i] = DK[i * LD + c];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          double a_ = 0;
+#pragma unroll
+          for (int l = 0; l < 6; ++l) a_ += J2[i * 6 + l] * col[l];
+          out[DM::OFF_FX + i * NM + c] = a_ + ((c < 6) ? J1[i * 6 + c] : 0.0);
+        }
+        for (int i = 6; i < n; ++i) out[DM::OFF_FX + i * NM + c] = DK[i * LD + c] + ((i == c) ? 1.0 : 0.0);
+        out[DM::OFF_LX + c] = lxu[sl] * cscale;  // Lx | Lu are contiguous
       }
-      for (int e = lane; e < n * m; e += nl) {
-        const int r = e / m, q = e % m;
-        out[DM::OFF_FU + r * NM + q] = SKU[e];
-        out[DM::OFF_LXU + r * NM + q] = LXU[e] * cscale;
-      }
-      for (int e = lane; e < m * m; e += nl) out[DM::OFF_LUU + e] = LUU[e] * cscale;
-      if (lane < n) out[DM::OFF_LX + lane] = LX[lane] * cscale;
-      if (lane < m) out[DM::OFF_LU + lane] = LU[lane] * cscale;
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int c = 0; c < NT; ++c)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * a + 4 * r + lq, col = 16 * c + lj;
+            const double v_ = accL[sl][a][c][r];
+            if (row < n && col < nm) out[DM::OFF_HX + row * NM + col] = v_ * cscale;  // [Lxx Lxu], row-interleaved
+            if (row >= n && row < nm && col >= n && col < nm)
+              out[DM::OFF_LUU + (row - n) * m + col - n] = (v_ + PT[(row - n) * PLD + col - n]) * cscale;
+          }
       if (lane == 0) out[DM::OFF_COST] = (KK[5 * n] + 2.0 * KK[5 * n + 1] + 2.0 * KK[5 * n + 2] + KK[5 * n + 3]) * cscale;
       // gaps: fs[t+1] = xnext (-) xs[t+1];  fs[0] = x0 (-) xs[0]
       if (lane == 1 && !terminal) {

@@ -116,7 +116,11 @@ EMPC_HD Roll6Lane roll6_lane(const DevBuffers& D, const int* TB, int lane, int G
 // One instantiation per role: a wavefront runs the whole rollout of ITS role (warp specialisation), so the registers of a
 // role hold that role's state only; the four instantiations execute the same sequence of workgroup barriers.
 // Exec concept: ex.each(f) runs f(lane, slot) on the lanes of the calling wavefront; ex.sync() is the workgroup barrier.
-template <class DM, int CT, int ROLE, class Exec>
+// RK4 = true: IntegratedActionModelRK4 nodes (src/factory/int-action.cpp:29-31).  A knot becomes four stages of the same two
+// phases -- the differential model at y_i = x (+) c_i dt k_{i-1}: bias forces, inertia, acceleration, costs -- with the
+// feedback control, the squashing and the generalized force of stage 0 kept for all four; role C carries the knot's state and
+// the weighted sum of the k_i, role D the weighted sum of the stage costs (node_nominal_rk4, operation for operation).
+template <class DM, int CT, int ROLE, class Exec, bool RK4 = false>
 EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N) {
   typedef Roll6Smem<DM> SM;
   constexpr int NX = DM::NX, NU = DM::NU, NV = DM::NV, NQ = DM::NQ, NDX = DM::NDX, REC = DM::REC, NB = DM::NB, NROT = DM::NROT;
@@ -275,6 +279,9 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
   int ncC[Exec::SLOTS], ncD[Exec::SLOTS];     // C / D: running nodes reached before the first failure (T: none)
   double costD[Exec::SLOTS];                  // D: cost of the trial
   int okD[Exec::SLOTS];
+  double xkC[Exec::SLOTS][RK4 ? NX : 1], ksC[Exec::SLOTS][RK4 ? NDX : 1];  // C, RK4 nodes: state of the knot, sum w_i k_i
+  double ellD[Exec::SLOTS];                   // D, RK4 nodes: sum w_i l_i of the knot being finished
+  constexpr int NST = RK4 ? 4 : 1;
 
   // x_try of knot 0 (C): x0, contracted towards the nominal start by the gap when the pass keeps gaps
   if constexpr (ROLE == R6_C) ex.each([&](int lane, int sl) {
@@ -307,7 +314,8 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
   ex.sync();
 
   // cost of knot tp for D's lane, from the values D left in VAL, the contact force in ACC and B's frame-cost sum
-  auto finish_cost = [&](int tp, int lane, int sl, const Roll6Lane& L) {
+  // (RK4 nodes: stage stp of knot tp; the knot's cost closes with its last stage)
+  auto finish_cost = [&](int tp, int stp, int lane, int sl, const Roll6Lane& L) {
     const int kset = EMPC_KPTR(int, D.knot_set)[tp];
     const EMPC_K EmpcCostSet& set = EMPC_KPTR(EmpcCostSet, D.sets)[kset];
     const EMPC_K SetInfo& si = EMPC_KPTR(SetInfo, D.set_info)[kset];
@@ -328,17 +336,30 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
         r[i] = use_contact ? (c.ref[4 + 3 * i] * lam[0] + c.ref[5 + 3 * i] * lam[1] + c.ref[6 + 3 * i] * lam[2]) : 0.0;
       ell += c.weight * activation_value<6>(c, r, 5);
     }
-    ell += ELLF[(tp & 1) * NL + lane];
-    const double cscale = (terminal && !P.prm.terminal_dt_scaling) ? 1.0 : dt;
-    costD[sl] += cscale * ell;
-    if (bad_number(costD[sl])) {
+    ell += ELLF[((RK4 ? 4 * tp + stp : tp) & 1) * NL + lane];
+    bool closes = true;
+    if constexpr (RK4) {
+      const double w = (stp == 0 || stp == 3) ? 1.0 : 2.0;
+      ellD[sl] = (stp == 0) ? ell : ellD[sl] + w * ell;
+      closes = (stp == 3);
+      if (closes) {
+        const double cscale = (terminal && !P.prm.terminal_dt_scaling) ? 1.0 / 6.0 : dt / 6.0;
+        costD[sl] += ellD[sl] * cscale;
+      }
+    } else {
+      const double cscale = (terminal && !P.prm.terminal_dt_scaling) ? 1.0 : dt;
+      costD[sl] += cscale * ell;
+    }
+    if (closes && bad_number(costD[sl])) {
       if (okD[sl]) ncD[sl] = (tp + 1 < T) ? tp + 1 : T;
       okD[sl] = 0;
     }
-    // acceleration | contact force of the knot -> acc_try (linearize reuses them for the accepted trial)
-    double* ac_o = D.acc_try + ((size_t)L.b * NA + L.ai) * (T + 1) * DM::NACC + (size_t)tp * DM::NACC;
+    // acceleration | contact force of the knot (RK4: of its stage 0) -> acc_try (linearize reuses them for the accepted trial)
+    if (stp == 0) {
+      double* ac_o = D.acc_try + ((size_t)L.b * NA + L.ai) * (T + 1) * DM::NACC + (size_t)tp * DM::NACC;
 #pragma unroll
-    for (int i = 0; i < DM::NACC; ++i) ac_o[i] = ACC[i * NL + lane];
+      for (int i = 0; i < DM::NACC; ++i) ac_o[i] = ACC[i * NL + lane];
+    }
   };
 
 #if defined(EMPC_STAMPS) && defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
@@ -373,11 +394,14 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
     const EMPC_K SetInfo& si = EMPC_KPTR(SetInfo, D.set_info)[kset];
     const bool terminal = (t == T);
     const bool use_contact = CT && P.has_contact && set.ncontacts > 0;
+    for (int st = 0; st < NST; ++st) {
+    const int stepq = RK4 ? 4 * t + st : t;  // step: what B's frame-cost slot and D's one-step-behind bookkeeping count in
+    const bool last_stage = (st == NST - 1);
     // =============================================== phase I ===========================================================
     // ---- A: state difference to the nominal trajectory, feedback, squashing, generalized force ----------------------------
     if constexpr (ROLE == R6_A) ex.each([&](int lane, int sl) {
       const Roll6Lane& L = LL[sl];
-      if (!L.live) return;
+      if (!L.live || st > 0) return;
       const double* nom = NOM + (size_t)(t & 1) * SM::NOMSZ;
       const double* n_x = nom + SM::NOM_X + L.g * SM::XS;
       const double* n_vf = nom + SM::NOM_VF + L.g * SM::GS;
@@ -525,7 +549,7 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
         }
         ell_frames += c.weight * cval;
       }
-      ELLF[(t & 1) * NL + lane] = ell_frames;
+      ELLF[(stepq & 1) * NL + lane] = ell_frames;
       R6_SUB(4);
       }
     });
@@ -542,16 +566,18 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
     // ---- D: cost of the previous knot, State costs of this one, stores, staging of the next knot's nominal data ----------------
     if constexpr (ROLE == R6_D) ex.each([&](int lane, int sl) {
       const Roll6Lane& L = LL[sl];
-      if (t < T) fetch_gap(t + 1, sl);  // in flight behind the State costs
+      if (t < T && last_stage) fetch_gap(t + 1, sl);  // in flight behind the State costs
       R6_SCHED_FENCE();
       if (L.live) {
-        if (t > 0) finish_cost(t - 1, lane, sl, L);
+        if (stepq > 0) finish_cost(st > 0 ? t : t - 1, st > 0 ? st - 1 : NST - 1, lane, sl, L);
         double x[NX];
 #pragma unroll
         for (int i = 0; i < NX; ++i) x[i] = XT[i * NL + lane];
-        double* xs_o = D.xs_try + ((size_t)L.b * NA + L.ai) * (T + 1) * NX + (size_t)t * NX;
+        if (st == 0) {
+          double* xs_o = D.xs_try + ((size_t)L.b * NA + L.ai) * (T + 1) * NX + (size_t)t * NX;
 #pragma unroll
-        for (int i = 0; i < NX; ++i) xs_o[i] = x[i];
+          for (int i = 0; i < NX; ++i) xs_o[i] = x[i];
+        }
         double rstate[NDX];
         int rstate_of = -1;
         for (int ks = 0; ks < si.n_state; ++ks) {
@@ -565,7 +591,7 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
         }
       }
       R6_SCHED_FENCE();
-      if (t < T) put_gap(t + 1, lane, sl);
+      if (t < T && last_stage) put_gap(t + 1, lane, sl);
     });
     R6_STAMP(0);
     ex.sync();
@@ -614,15 +640,52 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
       for (int i = 0; i < NV; ++i) ACC[i * NL + lane] = a[i];
 #pragma unroll
       for (int i = 0; i < 6; ++i) ACC[(NV + i) * NL + lane] = lam[i];
-      if (!terminal) {
-        const double* v = x + NQ;
-        double dxe[NDX], xn[NX], xt[NX];
+      bool final_step = !terminal;
+      if constexpr (RK4) {
+        // k_i = [v(y_i); a_i]; sum w_i k_i; the next stage state y_{i+1} = x (+) c_{i+1} dt k_i (the terminal node evaluates its
+        // four stages too: its cost is their weighted sum)
+        const double rk4_c[4] = {0.0, 0.5, 0.5, 1.0};
+        const double w = (st == 0 || st == 3) ? 1.0 : 2.0;
+        double kst[NDX];
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-          dxe[i] = v[i] * dt + a[i] * dt * dt;
-          dxe[NV + i] = a[i] * dt;
+          kst[i] = x[NQ + i];
+          kst[NV + i] = a[i];
         }
-        state_integrate<DM>(x, dxe, xn, nullptr);
+        if (st == 0) {
+#pragma unroll
+          for (int i = 0; i < NX; ++i) xkC[sl][i] = x[i];
+#pragma unroll
+          for (int i = 0; i < NDX; ++i) ksC[sl][i] = kst[i];
+        } else {
+#pragma unroll
+          for (int i = 0; i < NDX; ++i) ksC[sl][i] = ksC[sl][i] + w * kst[i];
+        }
+        if (st < 3) {
+          double dxr[NDX], y[NX];
+#pragma unroll
+          for (int i = 0; i < NDX; ++i) dxr[i] = rk4_c[st + 1] * dt * kst[i];
+          state_integrate<DM>(xkC[sl], dxr, y, nullptr);
+#pragma unroll
+          for (int i = 0; i < NX; ++i) XT[i * NL + lane] = y[i];
+          final_step = false;
+        }
+      }
+      if (final_step) {
+        const double* v = x + NQ;
+        double dxe[NDX], xn[NX], xt[NX];
+        if constexpr (RK4) {
+#pragma unroll
+          for (int i = 0; i < NDX; ++i) dxe[i] = ksC[sl][i] * dt / 6.0;
+          state_integrate<DM>(xkC[sl], dxe, xn, nullptr);
+        } else {
+#pragma unroll
+          for (int i = 0; i < NV; ++i) {
+            dxe[i] = v[i] * dt + a[i] * dt * dt;
+            dxe[NV + i] = a[i] * dt;
+          }
+          state_integrate<DM>(x, dxe, xn, nullptr);
+        }
         double mx = 0;
         bool isn = false;
 #pragma unroll
@@ -650,7 +713,7 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
     });
     // ---- B: next knot's gain rows into the staging buffer (A reads them in phase I of the next knot) ---------------------------
     if constexpr (ROLE == R6_B) ex.each([&](int lane, int sl) {
-      if (t + 1 < T) {
+      if (t + 1 < T && last_stage) {
         fetch_gains(t + 1, sl);
         R6_SCHED_FENCE();
         put_gains(t + 1, lane, sl);
@@ -658,7 +721,7 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
     });
     // ---- A: the rest of the next knot's nominal data (xs, Vxx f, us, k) -------------------------------------------------------
     if constexpr (ROLE == R6_A) ex.each([&](int lane, int sl) {
-      if (t < T) {
+      if (t < T && last_stage) {
         fetch_nom(t + 1, sl);
         R6_SCHED_FENCE();
         put_nom(t + 1, lane, sl);
@@ -667,7 +730,7 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
     // ---- D: Control costs of this knot, control of the trial to memory -----------------------------------------------------------
     if constexpr (ROLE == R6_D) ex.each([&](int lane, int sl) {
       const Roll6Lane& L = LL[sl];
-      if (!L.live) return;
+      if (!L.live || st > 0) return;  // (RK4 nodes: the control and its cost values are those of stage 0 for all four stages)
       double s[NU];
 #pragma unroll
       for (int i = 0; i < NU; ++i) s[i] = terminal ? 0.0 : UT[i * NL + lane];
@@ -684,6 +747,7 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
     R6_STAMP(2);
     ex.sync();
     R6_STAMP(3);
+    }  // stages of the knot
   }
 #if defined(EMPC_STAMPS) && defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
   if (group == 0 && D.dbg)
@@ -705,7 +769,7 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
   if constexpr (ROLE == R6_D) ex.each([&](int lane, int sl) {
     const Roll6Lane& L = LL[sl];
     if (!L.live) return;
-    finish_cost(T, lane, sl, L);
+    finish_cost(T, NST - 1, lane, sl, L);
     const size_t slot = (size_t)L.b * NA + L.ai;
     D.try_cost[slot] = costD[sl];
     const int ncc = (int)FLAG[lane];

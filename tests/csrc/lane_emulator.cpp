@@ -61,15 +61,22 @@ struct CpuRoleExec {
   }
   void sync() { bar->arrive_and_wait(); }
 };
-template <class DM, int CT>
-static void emu_rollout_group6(const DevBuffers& D, int grp, double* smem) {
+template <class DM, int CT, bool RK4>
+static void emu_rollout_group6_i(const DevBuffers& D, int grp, double* smem) {
   std::barrier<> bar(R6_WAVES);
   std::thread th[R6_WAVES];
-  th[0] = std::thread([&] { CpuRoleExec ex{&bar}; rollout_group6<DM, CT, R6_A>(ex, D, grp, smem); });
-  th[1] = std::thread([&] { CpuRoleExec ex{&bar}; rollout_group6<DM, CT, R6_B>(ex, D, grp, smem); });
-  th[2] = std::thread([&] { CpuRoleExec ex{&bar}; rollout_group6<DM, CT, R6_C>(ex, D, grp, smem); });
-  th[3] = std::thread([&] { CpuRoleExec ex{&bar}; rollout_group6<DM, CT, R6_D>(ex, D, grp, smem); });
+  th[0] = std::thread([&] { CpuRoleExec ex{&bar}; rollout_group6<DM, CT, R6_A, CpuRoleExec, RK4>(ex, D, grp, smem); });
+  th[1] = std::thread([&] { CpuRoleExec ex{&bar}; rollout_group6<DM, CT, R6_B, CpuRoleExec, RK4>(ex, D, grp, smem); });
+  th[2] = std::thread([&] { CpuRoleExec ex{&bar}; rollout_group6<DM, CT, R6_C, CpuRoleExec, RK4>(ex, D, grp, smem); });
+  th[3] = std::thread([&] { CpuRoleExec ex{&bar}; rollout_group6<DM, CT, R6_D, CpuRoleExec, RK4>(ex, D, grp, smem); });
   for (auto& t : th) t.join();
+}
+template <class DM, int CT>
+static void emu_rollout_group6(const DevBuffers& D, int grp, double* smem) {
+  if (D.integrator == EMPC_INTEGRATOR_RK4)
+    emu_rollout_group6_i<DM, CT, true>(D, grp, smem);
+  else
+    emu_rollout_group6_i<DM, CT, false>(D, grp, smem);
 }
 
 struct Emu {
@@ -135,6 +142,7 @@ static void emu_alloc(Emu& e) {
   D.try_ncalc = e.try_ncalc.data();
   D.us_last = e.us_last.data();
   D.n_active = &e.n_active;
+  D.integrator = e.H.P.integrator;
   D.dbg = nullptr;
   D.B = B;
   D.T = T;
@@ -286,8 +294,8 @@ static int g_roll_version = 6;
 template <class DM>
 static void emu_rollout(Emu& e) {
   const bool ct = e.H.P.has_contact != 0;
-  if ((g_roll_version == 6 || (g_roll_version == 5 && e.H.P.prm.solver_type != EMPC_SOLVER_SBFDDP)) && e.NA <= MAX_ALPHAS &&
-      e.H.P.integrator == EMPC_INTEGRATOR_EULER) {  // the shipped form: packed trajectories, role wavefronts (Euler nodes)
+  if ((g_roll_version == 6 || (g_roll_version == 5 && e.H.P.prm.solver_type != EMPC_SOLVER_SBFDDP)) && e.NA <= MAX_ALPHAS) {
+    // the shipped form: packed trajectories, role wavefronts (Euler nodes, and RK4 nodes as four stages per knot)
     const int G = roll6_group_size(e.NA);
     std::vector<double> smem6(Roll6Smem<DM>::SIZE);
     for (int grp = 0; grp * G < e.B; ++grp) {
