@@ -255,32 +255,39 @@ EMPC_HD void rk4_assemble_unit(Exec& ex, const DevBuffers& D, const Rk4Buffers& 
 #pragma unroll
           for (int r = 0; r < 4; ++r) accB[sl][a][c][r] = 0.0;
     });
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
+    {
       // (columns 4 ks + lq >= n of the A operands meet the zero rows of DY; rows beyond the block are clamped: their products
-      //  land in rows nobody stores)
-      double aA[Exec::SLOTS][MTA], aB[Exec::SLOTS][MTX], bY[Exec::SLOTS][NT];
-      ex.each([&](int lane, int sl) {
-        const int li = lane % 16, lq = lane / 16;
+      //  land in rows nobody stores.  Operands of k step ks + 1 are requested from LDS before the matrix-core instructions of
+      //  step ks are issued: the stage fences of `each` would otherwise expose one LDS round trip per k step)
+      double aA[2][Exec::SLOTS][MTA], aB[2][Exec::SLOTS][MTX], bY[2][Exec::SLOTS][NT];
+      auto load1 = [&](int ks, int buf) {
+        ex.each([&](int lane, int sl) {
+          const int li = lane % 16, lq = lane / 16;
 #pragma unroll
-        for (int a = 0; a < MTA; ++a) {
-          const int row = nv + 16 * a + li;
-          aA[sl][a] = RAW[DM::OFF_FX + (row < n ? row : n - 1) * NM + 4 * ks + lq];
+          for (int a = 0; a < MTA; ++a) {
+            const int row = nv + 16 * a + li;
+            aA[buf][sl][a] = RAW[DM::OFF_FX + (row < n ? row : n - 1) * NM + 4 * ks + lq];
+          }
+#pragma unroll
+          for (int a = 0; a < MTX; ++a) {
+            const int row = 16 * a + li;
+            aB[buf][sl][a] = RAW[DM::OFF_LXX + (row < n ? row : n - 1) * NM + 4 * ks + lq];
+          }
+#pragma unroll
+          for (int c = 0; c < NT; ++c) bY[buf][sl][c] = DY[(4 * ks + lq) * LD + 16 * c + li];
+        });
+      };
+      load1(0, 0);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        if (ks + 1 < KS) load1(ks + 1, (ks + 1) & 1);
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+#pragma unroll
+          for (int a = 0; a < MTA; ++a) ex.mfma(aA[ks & 1], a, bY[ks & 1], c, accA, a, c);
+#pragma unroll
+          for (int a = 0; a < MTX; ++a) ex.mfma(aB[ks & 1], a, bY[ks & 1], c, accB, a, c);
         }
-#pragma unroll
-        for (int a = 0; a < MTX; ++a) {
-          const int row = 16 * a + li;
-          aB[sl][a] = RAW[DM::OFF_LXX + (row < n ? row : n - 1) * NM + 4 * ks + lq];
-        }
-#pragma unroll
-        for (int c = 0; c < NT; ++c) bY[sl][c] = DY[(4 * ks + lq) * LD + 16 * c + li];
-      });
-#pragma unroll
-      for (int c = 0; c < NT; ++c) {
-#pragma unroll
-        for (int a = 0; a < MTA; ++a) ex.mfma(aA, a, bY, c, accA, a, c);
-#pragma unroll
-        for (int a = 0; a < MTX; ++a) ex.mfma(aB, a, bY, c, accB, a, c);
       }
     }
     // DK = [velocity rows of DY; A_i DY + B_i],  Z = w (lxx_i DY + [0 | lxu_i]),  Lx | Lu,  the raw Luu
@@ -321,39 +328,52 @@ EMPC_HD void rk4_assemble_unit(Exec& ex, const DevBuffers& D, const Rk4Buffers& 
           }
       if (lane < nm) {
         double v_ = (lane >= n) ? RAW[DM::OFF_LU + lane - n] : 0.0;
-        for (int l = 0; l < n; ++l) v_ += DY[l * LD + lane] * RAW[DM::OFF_LX + l];
+        double dy_[n], lx_[n];
+#pragma unroll
+        for (int l = 0; l < n; ++l) {
+          dy_[l] = DY[l * LD + lane];
+          lx_[l] = RAW[DM::OFF_LX + l];
+        }
+#pragma unroll
+        for (int l = 0; l < n; ++l) v_ += dy_[l] * lx_[l];
         lxu[sl] += w * v_;
       }
       if (lane == nl - 1) KK[5 * n + sg] = RAW[DM::OFF_COST];
     });
     ex.sync();
     // DY^T Z on the Hessian tiles; lxu_i^T (w DYU) on the extra Luu tile; sum w dk
+    {
+      double aY[2][Exec::SLOTS][NT], bZ[2][Exec::SLOTS][NT], aX[2][Exec::SLOTS][MTU], bU[2][Exec::SLOTS][MTU];
+      auto load2 = [&](int ks, int buf) {
+        ex.each([&](int lane, int sl) {
+          const int li = lane % 16, lq = lane / 16;
+          const int kr = 4 * ks + lq;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      double aY[Exec::SLOTS][NT], bZ[Exec::SLOTS][NT], aX[Exec::SLOTS][MTU], bU[Exec::SLOTS][MTU];
-      ex.each([&](int lane, int sl) {
-        const int li = lane % 16, lq = lane / 16;
-        const int kr = 4 * ks + lq;
+          for (int c = 0; c < NT; ++c) {
+            aY[buf][sl][c] = DY[kr * LD + 16 * c + li];
+            bZ[buf][sl][c] = Z[kr * LD + 16 * c + li];
+          }
 #pragma unroll
-        for (int c = 0; c < NT; ++c) {
-          aY[sl][c] = DY[kr * LD + 16 * c + li];
-          bZ[sl][c] = Z[kr * LD + 16 * c + li];
-        }
+          for (int c = 0; c < MTU; ++c) {
+            const int u = 16 * c + li;
+            aX[buf][sl][c] = RAW[DM::OFF_LXU + (kr < n ? kr : n - 1) * NM + (u < m ? u : m - 1)];
+            bU[buf][sl][c] = w * DY[kr * LD + n + (u < m ? u : m - 1)];
+          }
+        });
+      };
+      load2(0, 0);
 #pragma unroll
-        for (int c = 0; c < MTU; ++c) {
-          const int u = 16 * c + li;
-          aX[sl][c] = RAW[DM::OFF_LXU + (kr < n ? kr : n - 1) * NM + (u < m ? u : m - 1)];
-          bU[sl][c] = w * DY[kr * LD + n + (u < m ? u : m - 1)];
-        }
-      });
+      for (int ks = 0; ks < KS; ++ks) {
+        if (ks + 1 < KS) load2(ks + 1, (ks + 1) & 1);
 #pragma unroll
-      for (int a = 0; a < NT; ++a)
+        for (int a = 0; a < NT; ++a)
 #pragma unroll
-        for (int c = 0; c < NT; ++c) ex.mfma(aY, a, bZ, c, accL, a, c);
+          for (int c = 0; c < NT; ++c) ex.mfma(aY[ks & 1], a, bZ[ks & 1], c, accL, a, c);
 #pragma unroll
-      for (int a = 0; a < MTU; ++a)
+        for (int a = 0; a < MTU; ++a)
 #pragma unroll
-        for (int c = 0; c < MTU; ++c) ex.mfma(aX, a, bU, c, accP, a, c);
+          for (int c = 0; c < MTU; ++c) ex.mfma(aX[ks & 1], a, bU[ks & 1], c, accP, a, c);
+      }
     }
     ex.each([&](int lane, int sl) {
 #pragma unroll
