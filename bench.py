@@ -245,8 +245,8 @@ def golden_rank_check(empc, device, maxiter):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=None, help="rollouts in flight per GPU (default 1024; 256 for the *_mpc configs)")
     ap.add_argument("--config", default="eagle_catch", choices=sorted(CONFIGS))
     ap.add_argument("--mode", default="stream", choices=["stream", "batch"],

@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 O="$ROOT/gpurun_out/r3prof"
 rm -rf "$O"; mkdir -p "$O"
 for CFG in eagle_catch displacement push_slide; do
-  STEPS=5; [ "$CFG" = push_slide ] && STEPS=2
+  STEPS=20; [ "$CFG" = push_slide ] && STEPS=5
   timeout 900 python3 bench.py --config $CFG --steps $STEPS --warmup 1 --no-secondary > $O/bench_$CFG.json 2> $O/bench_$CFG.err
   tail -c 600 $O/bench_$CFG.json; echo
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$CFG -- python3 bench.py --config $CFG --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-single-batch > $O/bench_under_rocprof_$CFG.json 2> $O/stats_$CFG.err
