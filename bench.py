@@ -242,6 +242,20 @@ def golden_rank_check(empc, device, maxiter):
                 np.abs(s.us_batch[0] - g["us"][0]).max() < 1e-4)
 
 
+# what bounds each hot kernel (SQ counters of these kernels: profiles/r03_pmc_sq_*.csv)
+LIMITERS = {
+    "linearize": "not HBM: two register-bound wavefronts per SIMD (256 VGPRs each; a third one spills: measured 1.8x slower); "
+                 "VALU active 23 % of a wavefront's cycles = ~47 % of a SIMD's issue slots, a wavefront waits 48 % of its life at "
+                 "stage barriers, single-lane sections (nominal chain, Cholesky) and LDS round trips",
+    "backward": "not HBM: one wavefront per trajectory and SIMD walking the knots backwards (dependent chain); per knot 52 FP64 "
+                "MFMAs keep the matrix pipe busy 36 % of the time (the gfx950 FP64 MFMA rate equals the vector rate), the rest is "
+                "the LLT + triangular solves, the symmetrisation and the gap terms on the vector unit",
+    "rollout": "not HBM: FP64 instruction issue of one wavefront per SIMD along the knot chain (a wave64 FP64 instruction "
+               "occupies its SIMD for 4 cycles whatever the number of useful lanes); four role wavefronts per 6 trajectories, "
+               "two LDS barriers per knot, 60 of 64 lanes busy",
+}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -510,9 +524,7 @@ def main():
                          "unit_definition": "(trajectory, step length, knot): one launch rolls out all %d step lengths of "
                                             "the line search" % solver.stats_na() if dom == "rollout" else "(trajectory, knot)",
                          "avg_launch_ms": avg_ms,
-                         "limiter": "not HBM: FP64 instruction issue of one wavefront per SIMD along the knot chain (a wave64 FP64 "
-                                    "instruction occupies its SIMD for 4 cycles whatever the number of useful lanes) -- DESIGN.md "
-                                    "section 3.1, SQ counters in profiles/"},
+                         "limiter": LIMITERS[dom]},
             "kernels": per_launch,
             "iteration_roofline": {"algorithmic_bytes_per_traj_knot_iter": words["iteration"] * 8,
                                    "achieved_GBs": iters_total * d.T * words["iteration"] * 8 / elapsed / 1e9 / world,
