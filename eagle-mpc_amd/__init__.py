@@ -75,6 +75,8 @@ def lib():
     L.empc_solver_supported.argtypes = [C.POINTER(T.ProblemDesc), C.POINTER(T.SolverParams)]
     L.empc_solver_set_cost_refs.argtypes = [C.c_void_p, C.c_int, C.c_char_p, _dp, C.c_int, C.c_int, C.c_double]
     L.empc_solver_update_problem.argtypes = [C.c_void_p, C.POINTER(T.ProblemDesc)]
+    L.empc_solver_kernel_family.restype = C.c_char_p
+    L.empc_solver_kernel_family.argtypes = [C.c_void_p]
     L.empc_solver_set_x0.argtypes = [C.c_void_p, _dp]
     L.empc_solver_set_warmstart.argtypes = [C.c_void_p, _dp, _dp]
     L.empc_solver_set_convergence_init.argtypes = [C.c_void_p, C.c_double]
@@ -460,6 +462,11 @@ class SolverSbFDDP:
     def convergence_init(self, v):
         _check(lib().empc_solver_set_convergence_init(self._h, float(v)))
         self._convergence_init = float(v)
+
+    @property
+    def kernel_family(self):
+        """'runtime model' or 'baked <robot>...': which kernel instantiation serves this solver (include/empc.h)."""
+        return lib().empc_solver_kernel_family(self._h).decode()
 
     def update_problem(self):
         _check(lib().empc_solver_update_problem(self._h, C.byref(self.problem.desc)))

@@ -485,6 +485,16 @@ EMPC_HD void Jexp6(const double* xi, const double* p, double* J) {
     }
 }
 
-EMPC_HD bool bad_number(double v) { return !(fabs(v) < 1e30); }  // NaN, inf or >= 1e30 (crocoddyl::raiseIfNaN)
+// NaN / overflow guards on the bit pattern: the same answers as `v != v` and `!(fabs(v) < 1e30)`, whatever the compiler is
+// told about NaNs (the baked-model instantiations are built with -fno-honor-nans -fno-signed-zeros so that products with
+// the structural zeros of a robot fold away; a floating-point self-comparison would fold away with them)
+EMPC_HD unsigned long long double_bits(double v) {
+  unsigned long long u;
+  __builtin_memcpy(&u, &v, sizeof(u));
+  return u;
+}
+EMPC_HD bool is_nan(double v) { return (double_bits(v) & 0x7fffffffffffffffull) > 0x7ff0000000000000ull; }
+// NaN, inf or >= 1e30 (crocoddyl::raiseIfNaN); 0x46293e5939a08cea = 1e30
+EMPC_HD bool bad_number(double v) { return (double_bits(v) & 0x7fffffffffffffffull) >= 0x46293e5939a08ceaull; }
 
 }  // namespace empc

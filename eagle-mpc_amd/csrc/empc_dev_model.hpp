@@ -10,6 +10,8 @@
 #pragma once
 #include "../../include/empc_types.h"
 #include "empc_dev_math.hpp"
+#include <type_traits>
+#include "baked/empc_baked_models.hpp"
 
 namespace empc {
 
@@ -26,8 +28,13 @@ struct DevProblem {
   EmpcSolverParams prm;
 };
 
-template <int NB_, int NROT_>
+// Model constants of a kernel instantiation: RuntimeModel reads the robot from the problem image (constant address space,
+// scalar loads) -- any serial-chain robot of the class; a baked model (csrc/baked/) is a struct of constexpr tables with
+// the same member names, so that the structural zeros / ones of a known robot fold at compile time.
+struct RuntimeModel {};
+template <int NB_, int NROT_, class MODEL_ = RuntimeModel>
 struct Dims {
+  typedef MODEL_ Model;
   static constexpr int NB = NB_;
   static constexpr int NROT = NROT_;
   static constexpr int NJ = NB_ - 1;
@@ -58,6 +65,54 @@ struct Dims {
   static constexpr int REC = (REC_RAW + 15) / 16 * 16;   // padded to 128 B
 };
 
+// view of a baked model: the tree constants are the static members of B; the operational frames a problem selects (cost
+// and contact frames, EmpcModelDesc::frame_*) stay in the problem image
+struct BakedView {
+  const double (&jplace_R)[8][9];
+  const double (&jplace_p)[8][3];
+  const double (&axis)[8][3];
+  const double (&mass)[8];
+  const double (&com)[8][3];
+  const double (&inertia)[8][9];
+  const double (&gravity)[3];
+  const EMPC_K int32_t (&frame_body)[EMPC_MAX_FRAMES];
+  const EMPC_K double (&frame_R)[EMPC_MAX_FRAMES][9];
+  const EMPC_K double (&frame_p)[EMPC_MAX_FRAMES][3];
+};
+template <class DM>
+EMPC_HD decltype(auto) model_of(const EMPC_K DevProblem& P) {
+  if constexpr (std::is_same<typename DM::Model, RuntimeModel>::value)
+    return (P.model);
+  else
+  {
+    constexpr const BakedTree& t = DM::Model::tree();
+    return BakedView{t.jplace_R, t.jplace_p, t.axis, t.mass, t.com, t.inertia, t.gravity, P.model.frame_body, P.model.frame_R, P.model.frame_p};
+  }
+}
+
+// platform constants (MultiCopterBaseParams: actuation matrix, control limits) of a kernel instantiation: from the problem
+// image, or literals of the baked robot
+struct RuntimePlatform {
+  const EMPC_K double (&tau_f)[6 * EMPC_MAX_ROTORS];
+  const EMPC_K double (&u_lb)[EMPC_MAX_NU];
+  const EMPC_K double (&u_ub)[EMPC_MAX_NU];
+};
+struct BakedPlatform {
+  const double (&tau_f)[48];
+  const double (&u_lb)[16];
+  const double (&u_ub)[16];
+};
+static_assert(6 * EMPC_MAX_ROTORS == 48 && EMPC_MAX_NU == 16 && EMPC_MAX_BODIES == 8, "layout of BakedTree");
+template <class DM>
+EMPC_HD auto platform_of(const EMPC_K DevProblem& P) {
+  if constexpr (std::is_same<typename DM::Model, RuntimeModel>::value)
+    return RuntimePlatform{P.tau_f, P.u_lb, P.u_ub};
+  else {
+    constexpr const BakedTree& t = DM::Model::tree();
+    return BakedPlatform{t.tau_f, t.u_lb, t.u_ub};
+  }
+}
+
 // Rodrigues rotation about a unit axis from cos/sin
 template <class S>
 EMPC_HD void axis_rot(const double* ax, const S& c, const S& s, S* R) {
@@ -78,8 +133,8 @@ EMPC_HD void axis_rot(const double* ax, const S& c, const S& s, S* R) {
 }
 
 // spatial inertia of body b applied to a motion (body frame): [m (v + w x c); Ic w + c x m (v + w x c)]
-template <class S>
-EMPC_HD void inertia_apply(const EMPC_K EmpcModelDesc& m, int b, const S* mot, S* out) {
+template <class S, class MT>
+EMPC_HD void inertia_apply(const MT& m, int b, const S* mot, S* out) {
   S wxc[3], lin[3], Iw[3], cxl[3];
   cross3<S>(mot + 3, m.com[b], wxc);
 #pragma unroll
@@ -105,8 +160,8 @@ struct FrameCap {
   S v[6];        // LOCAL spatial velocity
   S a[6];        // LOCAL spatial acceleration (of the recursion's a, i.e. including the gravity offset if enabled)
 };
-template <class S>
-EMPC_HD void frame_capture(const EMPC_K EmpcModelDesc& m, int f, const S* Rb, const S* pb, const S* vb, const S* ab,
+template <class S, class MT>
+EMPC_HD void frame_capture(const MT& m, int f, const S* Rb, const S* pb, const S* vb, const S* ab,
                            FrameCap<S>& fk) {
   matmul3<S>(Rb, m.frame_R[f], fk.R);
   S Rp[3];
@@ -133,8 +188,8 @@ EMPC_HD void frame_capture(const EMPC_K EmpcModelDesc& m, int f, const S* Rb, co
 //   cap_frames[ncap]: operational frames to capture (indices into the model's frame table)
 // Register discipline: only the per-body forces survive the forward sweep; joint rotations are rebuilt from cs/sn
 // in the backward sweep.
-template <int NB, class S>
-EMPC_HD void rnea_chain(const EMPC_K EmpcModelDesc& m, const S* R0, const S* p0, const S* cs, const S* sn, const S* v,
+template <int NB, class S, class MT>
+EMPC_HD void rnea_chain(const MT& m, const S* R0, const S* p0, const S* cs, const S* sn, const S* v,
                         const S* a, bool gravity, int fext_b, const S* fext, S* tau, int ncap, const int* cap_frames,
                         FrameCap<S>* caps) {
   S f[NB][6];
@@ -245,8 +300,8 @@ EMPC_HD void rnea_chain(const EMPC_K EmpcModelDesc& m, const S* R0, const S* p0,
 
 // Composite-rigid-body algorithm on a serial chain; output: packed lower triangle of M (idx(i,j) = i(i+1)/2 + j).
 // Composite inertias are carried as (mass, COM, rotational inertia about the COM) in body axes.
-template <int NB>
-EMPC_HD void crba_chain(const EMPC_K EmpcModelDesc& m, const double* cs, const double* sn, double* Mp) {
+template <int NB, class MT>
+EMPC_HD void crba_chain(const MT& m, const double* cs, const double* sn, double* Mp) {
   constexpr int NV = 6 + NB - 1;
   double XR[NB][9];
   double cm[NB], cc[NB][3], cI[NB][9];
@@ -357,7 +412,7 @@ EMPC_HD bool chol_packed(double* L) {
     double s = L[j * (j + 1) / 2 + j];
 #pragma unroll
     for (int k = 0; k < j; ++k) s -= L[j * (j + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
-    if (!(s > 0.0)) ok = false;
+    if (!(s > 0.0) || is_nan(s)) ok = false;
     const double inv = frsqrt(s);
     L[j * (j + 1) / 2 + j] = inv;
 #pragma unroll
@@ -434,8 +489,8 @@ EMPC_HD void activation_sel(int act, double r, double w, double lb, double ub, d
 }
 // weight of component i of cost c, with the barrier cost's weights derived from the trajectory's current smooth
 // (SolverSbFDDP::barrierUpdate, src/sbfddp.cpp:464-477)
-template <class CostT>
-EMPC_HD double act_weight(const CostT& c, int i, double smooth, const EMPC_K DevProblem& P) {
+template <class CostT, class PlatT>
+EMPC_HD double act_weight(const CostT& c, int i, double smooth, const PlatT& P) {
   if (c.is_barrier) {
     const double aux = smooth * (P.u_ub[i] - P.u_lb[i]);
     return frcp(aux * aux);
@@ -489,8 +544,8 @@ EMPC_HD double activation_value(const CostT& c, const double* r, int nr) {
   return cval;
 }
 // Control cost value: residual s - ref with the barrier cost's weights derived from the current smoothness
-template <int NU, class CostT>
-EMPC_HD double control_cost_value(const CostT& c, const double* s, double smooth, const EMPC_K DevProblem& P) {
+template <int NU, class CostT, class PlatT>
+EMPC_HD double control_cost_value(const CostT& c, const double* s, double smooth, const PlatT& P) {
   double r[NU];
 #pragma unroll
   for (int i = 0; i < NU; ++i) r[i] = s[i] - c.ref[i];
@@ -602,8 +657,8 @@ EMPC_HD void cone_rows(const double* nsurf, double mu, double AR[5][3]) {
 // fixed at compile time (one kernel instantiation per contact type): every loop unrolls and Jc / M^-1 Jc^T stay in registers.
 //   3D: a0 = a_lin + w x v_lin + g0 (p_f - xref) + g1 v_lin          (classical acceleration of the contact point)
 //   6D: a0 = a (spatial, LOCAL) + g0 log6(Mref^-1 oMf) + g1 v
-template <class DM, int NC, class ContactT>
-EMPC_HD void contact_forward(const EMPC_K EmpcModelDesc& m, const ContactT& ct, const FrameCap<double>& ck, const double* R0,
+template <class DM, int NC, class ContactT, class MT>
+EMPC_HD void contact_forward(const MT& m, const ContactT& ct, const FrameCap<double>& ck, const double* R0,
                              const double* q, const double* cs, const double* sn, const double* L, double* a, double* lam) {
   if constexpr (NC == CT_MIXED) {
     // a problem with stages of both contact types: the type of this node's contact picks the body (uniform over the
@@ -768,7 +823,8 @@ EMPC_HD void dam_nominal(const EMPC_K DevProblem& P, const SetT& set, double smo
                          bool terminal, double* euler_xnext, double* acc, double& ell_out, double* usq, double* lam_out,
                          unsigned long long* stp = nullptr) {
   constexpr int NB = DM::NB, NV = DM::NV, NQ = DM::NQ, NU = DM::NU, NROT = DM::NROT;
-  const EMPC_K EmpcModelDesc& m = P.model;
+  const auto& m = model_of<DM>(P);
+  const auto PL = platform_of<DM>(P);
   const double dt = P.dt;
   double s[NU], u[NU];
 #pragma unroll
@@ -778,8 +834,8 @@ EMPC_HD void dam_nominal(const EMPC_K DevProblem& P, const SetT& set, double smo
     const int power = P.prm.smoothsat_power;
 #pragma unroll
     for (int i = 0; i < NU; ++i) {
-      lbv[i] = P.u_lb[i];
-      ubv[i] = P.u_ub[i];
+      lbv[i] = PL.u_lb[i];
+      ubv[i] = PL.u_ub[i];
     }
 #pragma unroll
     for (int i = 0; i < NU; ++i) {
@@ -797,7 +853,7 @@ EMPC_HD void dam_nominal(const EMPC_K DevProblem& P, const SetT& set, double smo
   for (int r = 0; r < 6; ++r) {
     double a_ = 0;
 #pragma unroll
-    for (int c = 0; c < NROT; ++c) a_ += P.tau_f[r * NROT + c] * u[c];
+    for (int c = 0; c < NROT; ++c) a_ += PL.tau_f[r * NROT + c] * u[c];
     tau[r] = a_;
   }
 #pragma unroll
@@ -843,7 +899,7 @@ EMPC_HD void dam_nominal(const EMPC_K DevProblem& P, const SetT& set, double smo
         }
         ell += c.weight * activation_value<DM::NDX>(c, rstate, DM::NDX);
       } else if (c.type == EMPC_COST_CONTROL) {
-        ell += c.weight * control_cost_value<NU>(c, s, smooth, P);
+        ell += c.weight * control_cost_value<NU>(c, s, smooth, PL);
       }
     }
   }
@@ -1044,13 +1100,14 @@ EMPC_HD void node_nominal(const EMPC_K DevProblem& P, const SetT& set, double sm
 template <class DM>
 EMPC_HD void free_fwd_acc(const EMPC_K DevProblem& P, const double* x, const double* u, double* a) {
   constexpr int NB = DM::NB, NV = DM::NV, NQ = DM::NQ, NROT = DM::NROT;
-  const EMPC_K EmpcModelDesc& m = P.model;
+  const auto& m = model_of<DM>(P);
+  const auto PL = platform_of<DM>(P);
   double tau[NV];
 #pragma unroll
   for (int r = 0; r < 6; ++r) {
     double s = 0;
 #pragma unroll
-    for (int c = 0; c < NROT; ++c) s += P.tau_f[r * NROT + c] * u[c];
+    for (int c = 0; c < NROT; ++c) s += PL.tau_f[r * NROT + c] * u[c];
     tau[r] = s;
   }
 #pragma unroll

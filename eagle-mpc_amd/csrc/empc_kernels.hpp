@@ -227,7 +227,7 @@ EMPC_HD bool rollout_knot(const EMPC_K DevProblem& P, const SetT& set, RollLane<
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       mx = fmax(mx, fabs(L.xnext[i]));
-      isn = isn || (L.xnext[i] != L.xnext[i]);
+      isn = isn || is_nan(L.xnext[i]);
     }
     if (isn || bad_number(mx)) {
       L.ok = 0;

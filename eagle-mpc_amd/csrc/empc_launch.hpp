@@ -50,6 +50,10 @@ KernelTable empc_table_4_6_contact_mixed();
 KernelTable empc_table_6_6();
 KernelTable empc_table_6_6_contact();
 KernelTable empc_table_6_6_contact6();
+// instantiations over the baked constants of a shipped robot (csrc/baked/, tools/bake_models.py): picked by find_table when
+// the problem's model and platform equal the baked tables bit for bit
+KernelTable empc_table_baked_arm3();
+KernelTable empc_table_baked_arm3_contact();
 
 #ifdef EMPC_INSTANTIATE
 // --------------------------------------------------------------------------------------------------------------------
@@ -511,6 +515,19 @@ static KernelTable make_table() {
   std::memcpy(k.off, off, sizeof(off));
   const int ld[5] = {DM::NM, DM::NM, DM::NM, DM::NM, DM::NU};  // Fx, Fu, Lxx, Lxu, Luu leading dimensions
   std::memcpy(k.ld, ld, sizeof(ld));
+  return k;
+}
+// Table of a BAKED robot: the launchers whose kernels touch the rigid-body model (calc, linearize, rollout, the RK4 stage
+// kernels, the plant) come from the instantiation over the baked constants; everything else (backward, select, packing:
+// no model inside) is the robot class's own table, passed in.  The baked translation units are the only ones built with
+// -fno-honor-nans -fno-signed-zeros (Makefile), so the solver's NaN-driven control flow keeps strict IEEE semantics.
+template <class DM, int CT>
+static KernelTable make_baked_table(KernelTable k) {
+  k.calc = launch_calc<DM, CT>;
+  k.linearize = launch_linearize<DM, CT>;
+  k.rollout = launch_rollout<DM, CT>;
+  k.rk4_linearize = launch_rk4_linearize<DM, CT>;
+  k.plant = launch_plant<DM>;
   return k;
 }
 #endif  // EMPC_INSTANTIATE

@@ -62,8 +62,8 @@ struct Lin2Smem {
 };
 
 // forward kinematics + nominal Newton-Euler quantities of one unit, executed by ONE lane
-template <class DM>
-EMPC_HD void lin2_nominal_chain(const EMPC_K EmpcModelDesc& m, double* N, int cbody = -1) {
+template <class DM, class MT>
+EMPC_HD void lin2_nominal_chain(const MT& m, double* N, int cbody = -1) {
   typedef Lin2Smem<DM> SM;
   constexpr int NB = DM::NB, NQ = DM::NQ, NX = DM::NX;
   const double* x = N + SM::OFF_X;
@@ -216,8 +216,8 @@ EMPC_HD void lin2_nominal_chain(const EMPC_K EmpcModelDesc& m, double* N, int cb
 }
 
 // tangent of the inertia-weighted force: dF = I da + dv x* (I v) + v x* (I dv)
-template <class DM>
-EMPC_HD void lin2_dforce(const EMPC_K EmpcModelDesc& m, int b, const double* Bb, const double* dv, const double* da,
+template <class DM, class MT>
+EMPC_HD void lin2_dforce(const MT& m, int b, const double* Bb, const double* dv, const double* da,
                          double* df) {
   typedef Lin2Smem<DM> SM;
   double Ida[6], Idv[6], c1[3], c2[3], c3[3], e1[3], e2[3], e3[3];
@@ -240,8 +240,8 @@ EMPC_HD void lin2_dforce(const EMPC_K EmpcModelDesc& m, int b, const double* Bb,
 
 // Tangent recursion of RNEA(q, v, a) for the direction owned by `lane`. Outputs dtau[NV]; capdv[c] = d(body velocity)
 // of the body carrying captured frame c.
-template <class DM>
-EMPC_HD void lin2_tangent(const EMPC_K EmpcModelDesc& m, const double* N, int lane, double* dtau, int ncap,
+template <class DM, class MT>
+EMPC_HD void lin2_tangent(const MT& m, const double* N, int lane, double* dtau, int ncap,
                           const int* capf, double (*capdv)[6], int cbody = -1, double* capda = nullptr) {
   typedef Lin2Smem<DM> SM;
   constexpr int NB = DM::NB, NV = DM::NV, NQ = DM::NQ, NX = DM::NX;
@@ -367,8 +367,8 @@ EMPC_HD void lin2_tangent(const EMPC_K EmpcModelDesc& m, const double* N, int la
 }
 
 // LOCAL frame Jacobian column of generalized velocity `j` for a frame with world placement (Rf, pf) on body bf
-template <class DM>
-EMPC_HD void lin2_frame_jcol(const EMPC_K EmpcModelDesc& m, const double* N, int j, int bf, const double* Rf,
+template <class DM, class MT>
+EMPC_HD void lin2_frame_jcol(const MT& m, const double* N, int j, int bf, const double* Rf,
                              const double* pf, double* col) {
   typedef Lin2Smem<DM> SM;
   constexpr int NB = DM::NB, NV = DM::NV;
@@ -454,7 +454,7 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
   constexpr int REC = DM::REC;
   static_assert(NU <= NV, "control columns reuse the NV inertia-column lanes");
   const EMPC_K DevProblem& P = EMPC_KREF(DevProblem, D.P);
-  const EMPC_K EmpcModelDesc& m = P.model;
+  const auto& m = model_of<DM>(P);
   const TrajState& st = D.st[b];
   const int T = D.T;
   const bool terminal = (t == T);
@@ -1130,7 +1130,7 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
       const EMPC_K EmpcCost& c = set.costs[ci];
       if (!c.active || c.type != EMPC_COST_CONTROL) continue;
       double av, Ar, Arr;
-      activation1(c.activation, N[SM::OFF_S + k] - c.ref[k], act_weight(c, k, smooth, P), c.lb[k], c.ub[k], av, Ar, Arr);
+      activation1(c.activation, N[SM::OFF_S + k] - c.ref[k], act_weight(c, k, smooth, platform_of<DM>(P)), c.lb[k], c.ub[k], av, Ar, Arr);
       cv += c.weight * av;
       lx_l[sl] += c.weight * Ar;
 #pragma unroll

@@ -126,7 +126,8 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
   constexpr int NX = DM::NX, NU = DM::NU, NV = DM::NV, NQ = DM::NQ, NDX = DM::NDX, REC = DM::REC, NB = DM::NB, NROT = DM::NROT;
   constexpr int NL = SM::NL;
   const EMPC_K DevProblem& P = EMPC_KREF(DevProblem, D.P);
-  const EMPC_K EmpcModelDesc& m = P.model;
+  const auto& m = model_of<DM>(P);
+  const auto PL = platform_of<DM>(P);
   const int T = D.T, NA = D.NA;
   const int G = roll6_group_size(NA);
   const int nlist = D.act_list ? *D.act_count : D.B;
@@ -425,7 +426,7 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
 #pragma unroll
           for (int j = 0; j < NDX; ++j) a_ -= n_K[i * NDX + j] * dx[j];
           // SolverBox{DDP,FDDP}::forwardPass clamp the trial control to the limits of the model
-          s[i] = (P.prm.solver_type != EMPC_SOLVER_SBFDDP) ? fmin(fmax(a_, P.u_lb[i]), P.u_ub[i]) : a_;
+          s[i] = (P.prm.solver_type != EMPC_SOLVER_SBFDDP) ? fmin(fmax(a_, PL.u_lb[i]), PL.u_ub[i]) : a_;
         }
       } else {
 #pragma unroll
@@ -436,8 +437,8 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
         const int power = P.prm.smoothsat_power;
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
-          lbv[i] = P.u_lb[i];
-          ubv[i] = P.u_ub[i];
+          lbv[i] = PL.u_lb[i];
+          ubv[i] = PL.u_ub[i];
         }
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
@@ -452,7 +453,7 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
       for (int r = 0; r < 6; ++r) {
         double a_ = 0;
 #pragma unroll
-        for (int c = 0; c < NROT; ++c) a_ += P.tau_f[r * NROT + c] * u[c];
+        for (int c = 0; c < NROT; ++c) a_ += PL.tau_f[r * NROT + c] * u[c];
         tau[r] = a_;
       }
 #pragma unroll
@@ -691,7 +692,7 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
           mx = fmax(mx, fabs(xn[i]));
-          isn = isn || (xn[i] != xn[i]);
+          isn = isn || is_nan(xn[i]);
         }
         if (isn || bad_number(mx)) {
           if (okC[sl]) ncC[sl] = (t + 1 < T) ? t + 1 : T;
@@ -736,7 +737,7 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
       for (int i = 0; i < NU; ++i) s[i] = terminal ? 0.0 : UT[i * NL + lane];
       for (int kc = 0; kc < si.n_ctrl; ++kc) {
         const int ci = si.ctrl_ci[kc];
-        VAL[ci * NL + lane] = control_cost_value<NU>(set.costs[ci], s, L.smooth, P);
+        VAL[ci * NL + lane] = control_cost_value<NU>(set.costs[ci], s, L.smooth, PL);
       }
       if (!terminal) {
         double* us_o = D.us_try + ((size_t)L.b * NA + L.ai) * T * NU + (size_t)t * NU;

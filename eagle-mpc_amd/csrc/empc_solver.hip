@@ -34,7 +34,42 @@ using namespace empc;
 // --------------------------------------------------------------------------------------------------------------------
 // contact_rows: 0 for problems built on the free dynamics; 3 / 6 for Contact dynamics (DifferentialActionModelContactFwdDynamics
 // on every node) whose contact stages hold a ContactModel3D / ContactModel6D
-static bool find_table(int nb, int nrot, bool contact, int contact_rows, KernelTable& k) {
+// Does the problem's robot equal a baked table (tree + platform) bit for bit?  Only then may the instantiation over the
+// baked constants stand in for the runtime-model one.
+static bool baked_matches(const empc::BakedTree& t, const DevProblem& P) {
+  const EmpcModelDesc& m = P.model;
+  if (m.nbodies != t.nbodies || m.nq != t.nq || m.nv != t.nv || P.n_rotors != t.n_rotors) return false;
+  auto same = [](const double* a, const double* b, int n) { return std::memcmp(a, b, sizeof(double) * n) == 0; };
+  for (int b = 0; b < m.nbodies; ++b) {
+    if (m.parent[b] != t.parent[b]) return false;
+    if (!same(m.jplace_R[b], t.jplace_R[b], 9) || !same(m.jplace_p[b], t.jplace_p[b], 3) || !same(m.axis[b], t.axis[b], 3) ||
+        !same(&m.mass[b], &t.mass[b], 1) || !same(m.com[b], t.com[b], 3) || !same(m.inertia[b], t.inertia[b], 9))
+      return false;
+  }
+  return same(m.gravity, t.gravity, 3) && same(P.tau_f, t.tau_f, 6 * P.n_rotors) && same(P.u_lb, t.u_lb, P.nu) &&
+         same(P.u_ub, t.u_ub, P.nu);
+}
+// EMPC_BAKED=0 keeps every problem on the runtime-model instantiations (tests compare the two)
+static bool baked_enabled() {
+  const char* e = std::getenv("EMPC_BAKED");
+  return !(e && std::atoi(e) == 0);
+}
+static bool find_table(const DevProblem& P, int nb, int nrot, bool contact, int contact_rows, KernelTable& k, const char** which = nullptr) {
+  if (which) *which = "runtime model";
+  if (baked_enabled() && !(contact && nb == 4 && std::getenv("EMPC_FORCE_MIXED_CONTACT"))) {
+    if (nb == 4 && nrot == 6 && baked_matches(empc::kBakedHex370Arm3, P)) {
+      if (!contact) {
+        k = empc_table_baked_arm3();
+        if (which) *which = "baked hexacopter370_flying_arm_3";
+        return true;
+      }
+      if (contact_rows == 3) {
+        k = empc_table_baked_arm3_contact();
+        if (which) *which = "baked hexacopter370_flying_arm_3, ContactModel3D";
+        return true;
+      }
+    }
+  }
   // diagnostic: run a single-type contact problem through the mixed instantiation (tests: bitwise the same results)
   if (contact && nb == 4 && std::getenv("EMPC_FORCE_MIXED_CONTACT")) contact_rows = empc::CT_MIXED;
   if (nb == 1 && nrot == 4 && !contact) k = empc_table_1_4();
@@ -58,6 +93,7 @@ static void check_device_support(const EmpcProblemDesc& d) {
 struct EmpcSolver {
   HostProblem H;
   KernelTable kt;
+  const char* kernel_family = "runtime model";  // which instantiation find_table picked (empc_solver_kernel_family)
   int device = 0, B = 0, T = 0, NA = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev[8] = {};
@@ -212,7 +248,7 @@ int empc_solver_supported(const EmpcProblemDesc* problem, const EmpcSolverParams
     prepare_problem(*problem, prm, H);  // dimension / chain / integrator / contact-type limits of the kernels
     check_device_support(*problem);
     KernelTable kt;
-    if (!find_table(problem->model.nbodies, problem->n_rotors, problem->has_contact != 0, H.contact_rows, kt))
+    if (!find_table(H.P, problem->model.nbodies, problem->n_rotors, problem->has_contact != 0, H.contact_rows, kt))
       throw std::runtime_error("no kernel instantiation for this (bodies, rotors, contact) combination");
     return 1;
   } catch (const std::exception& e) {
@@ -240,7 +276,7 @@ EmpcSolver* empc_solver_create(const EmpcProblemDesc* problem, const EmpcSolverP
   prepare_problem(*problem, prm, s->H);
   remember_problem(s, *problem);
   check_device_support(*problem);
-  if (!find_table(problem->model.nbodies, problem->n_rotors, problem->has_contact != 0, s->H.contact_rows, s->kt)) {
+  if (!find_table(s->H.P, problem->model.nbodies, problem->n_rotors, problem->has_contact != 0, s->H.contact_rows, s->kt, &s->kernel_family)) {
     delete s;
     empc::set_last_error("no kernel instantiation for this (bodies, rotors, contact) combination");
     return nullptr;
@@ -396,6 +432,8 @@ static void check_same_class(const EmpcSolver* s, const HostProblem& N) {
   if (N.P.model.nbodies != O.P.model.nbodies || N.P.n_rotors != O.P.n_rotors) fail("its robot class (bodies, rotors)");
 }
 
+const char* empc_solver_kernel_family(const EmpcSolver* s) { return s ? s->kernel_family : ""; }
+
 int empc_solver_update_problem(EmpcSolver* s, const EmpcProblemDesc* problem) {
   EMPC_TRY
   if (!s || !problem) throw std::invalid_argument("NULL argument");
@@ -404,6 +442,13 @@ int empc_solver_update_problem(EmpcSolver* s, const EmpcProblemDesc* problem) {
   HostProblem N;  // prepared aside: s->H keeps matching the device image if anything below throws
   prepare_problem(*problem, prm, N);
   check_same_class(s, N);
+  // same class, possibly another robot of it: the instantiation over baked constants serves only the robot it was baked from
+  KernelTable kt;
+  const char* family = nullptr;
+  if (!find_table(N.P, N.P.model.nbodies, N.P.n_rotors, N.P.has_contact != 0, N.contact_rows, kt, &family))
+    throw std::runtime_error("update_problem: no kernel instantiation for the new problem");
+  s->kt = kt;
+  s->kernel_family = family;
   s->H = std::move(N);
   remember_problem(s, *problem);
   upload_problem(s);

@@ -88,6 +88,11 @@ void empc_solver_params_default(EmpcSolverParams* p);
 EmpcSolver* empc_solver_create(const EmpcProblemDesc* problem, const EmpcSolverParams* params, int batch, int device);
 void empc_solver_destroy(EmpcSolver* s);
 int empc_solver_update_problem(EmpcSolver* s, const EmpcProblemDesc* problem); /* same shapes; new cost tables / x0 */
+/* which kernel instantiation serves this solver: "runtime model" (any serial-chain robot of the class; the robot is read from
+ * the problem image) or "baked <robot>[, <contact>]" (the robot equals, bit for bit, one of the tables compiled into the
+ * library, eagle-mpc_amd/csrc/baked/: its constants are literals of the kernels).  EMPC_BAKED=0 in the environment keeps
+ * every solver on the runtime-model kernels.  The string lives as long as the library. */
+const char* empc_solver_kernel_family(const EmpcSolver* s);
 int empc_solver_set_x0(EmpcSolver* s, const double* x0s /* batch x nx, NULL = problem x0 for every trajectory */);
 int empc_solver_set_warmstart(EmpcSolver* s, const double* xs /* batch x (T+1) x nx or NULL = zero state */,
                               const double* us /* batch x T x nu or NULL = zeros */);

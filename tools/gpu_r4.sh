@@ -1,0 +1,53 @@
+# GPU box, round 4: ONE script for everything this round measures.  Usage (through gpurun, from the repo root):
+#   tools/gpu_r4.sh check        whole GPU suite, then the default bench line
+#   tools/gpu_r4.sh ab           bench lines with the baked-robot kernels on (default) and off (EMPC_BAKED=0), eagle_catch +
+#                                displacement + push_slide, no CPU baseline (kernel comparison only)
+#   tools/gpu_r4.sh tests        GPU suite only
+#   tools/gpu_r4.sh profiles     rocprofv3 kernel stats + PMC passes behind profiles/r04_*
+#   tools/gpu_r4.sh stamps       in-kernel cycle stamps (libempc_stamps.so)
+set -uo pipefail
+ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)}"
+cd "$ROOT"
+mkdir -p gpurun_out
+MODE="${1:-check}"
+TAG="${2:-r04}"
+nproc; lscpu | grep -E "Model name" | head -2
+
+bench_line() {  # name, env, args...
+  local name="$1"; shift
+  local envs="$1"; shift
+  env $envs timeout 900 python3 bench.py "$@" > "gpurun_out/${TAG}_bench_${name}.json" 2> "gpurun_out/${TAG}_bench_${name}.err"
+  echo "bench ${name} rc $?"
+  python3 - "gpurun_out/${TAG}_bench_${name}.json" <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+except Exception as e:
+    print("  no bench line:", e); sys.exit(0)
+k = d.get("kernels_ms_per_launch") or d.get("kernel_ms") or {}
+print("  value %.1f %s ms/step %.2f" % (d["value"], d["unit"], d["ms_per_step"]), "single_batch", (d.get("single_batch") or {}).get("value"),
+      "secondary", (d.get("secondary") or {}).get("value"))
+for key in ("roofline", "kernels"):
+    if key in d: print("  ", key, json.dumps(d[key])[:600])
+PY
+}
+
+case "$MODE" in
+  tests)
+    timeout 1700 python -m pytest tests -q -m gpu -x --durations=10 2>&1 | tail -40 | tee "gpurun_out/${TAG}_pytest.log"
+    ;;
+  check)
+    timeout 1700 python -m pytest tests -q -m gpu --durations=10 2>&1 | tail -40 | tee "gpurun_out/${TAG}_pytest.log"
+    bench_line default "EMPC_X=0"
+    tail -c 6000 "gpurun_out/${TAG}_bench_default.json"
+    ;;
+  ab)
+    for cfg in eagle_catch displacement push_slide; do
+      bench_line "${cfg}_baked" "EMPC_BAKED=1" --config $cfg --no-cpu-baseline --no-secondary --steps 10
+      bench_line "${cfg}_generic" "EMPC_BAKED=0" --config $cfg --no-cpu-baseline --no-secondary --steps 10
+    done
+    ;;
+  *)
+    echo "unknown mode $MODE"; exit 2
+    ;;
+esac
