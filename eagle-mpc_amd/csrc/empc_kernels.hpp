@@ -88,7 +88,7 @@ struct DevBuffers {
   int* counters_next = nullptr;   // {n_active, lin_count} of the other sweep slot
   int* done_ticket = nullptr;     // workgroups of this select that have finished
   int* host_active = nullptr;     // host-visible copy of n_active of this sweep
-  unsigned long long* dbg;  // [64] cycle stamps of diagnostic builds (EMPC_STAMPS); unused otherwise
+  unsigned long long* dbg;  // [128] cycle stamps of diagnostic builds (EMPC_STAMPS); unused otherwise
   // optional per-iteration record (the reference's callback hook, src/sbfddp.cpp:303-307,381-385): ring of trace_cap
   // records of EMPC_TRACE_WORDS doubles per trajectory, written by select; nullptr = off
   double* trace = nullptr;  // [B][trace_cap][EMPC_TRACE_WORDS]

@@ -54,6 +54,12 @@ KernelTable empc_table_6_6_contact6();
 // the problem's model and platform equal the baked tables bit for bit
 KernelTable empc_table_baked_arm3();
 KernelTable empc_table_baked_arm3_contact();
+KernelTable empc_table_baked_arm5();
+KernelTable empc_table_baked_arm2();
+KernelTable empc_table_baked_hex370();
+KernelTable empc_table_baked_hextilt();
+KernelTable empc_table_baked_iris();
+KernelTable empc_table_baked_iris_px4();
 
 #ifdef EMPC_INSTANTIATE
 // --------------------------------------------------------------------------------------------------------------------

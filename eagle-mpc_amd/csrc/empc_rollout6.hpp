@@ -409,29 +409,62 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
       const double* n_us = nom + SM::NOM_US + L.g * SM::US;
       const double* n_kf = nom + SM::NOM_KF + L.g * SM::US;
       const double* n_K = nom + SM::NOM_K + L.g * SM::KS;
-      double x[NX], dx[NDX], s[NU], u[NU], tau[NV];
+      // Every LDS operand of this role is requested in blocks ahead of its use (one wait per block): left to itself the
+      // compiler walks the 180 gain entries as read, wait, multiply-add, read, wait, ... with one read in flight -- one LDS
+      // round trip per entry, ~7k of the role's 8.5k cycles per knot.  Same operations in the same order.
+      double x[NX], xn[NX], dx[NDX], s[NU], u[NU], tau[NV];
+      R6_SUB(6);
 #pragma unroll
-      for (int i = 0; i < NX; ++i) x[i] = XT[i * NL + lane];
-      state_diff<DM>(n_x, x, dx, nullptr);
-      if (L.need_dv) {
-        double dv = dvA[sl];
-#pragma unroll
-        for (int i = 0; i < NDX; ++i) dv += n_vf[i] * dx[i];  // +(Vxx f).(xs_try (-) xs)
-        dvA[sl] = dv;
+      for (int i = 0; i < NX; ++i) {
+        x[i] = XT[i * NL + lane];
+        xn[i] = n_x[i];
       }
+      R6Pair kr[2][NDX / 2];  // rows of K[t], two in flight
+      auto load_row = [&](int i, int buf) {
+#pragma unroll
+        for (int j = 0; j < NDX / 2; ++j) kr[buf][j] = *reinterpret_cast<const R6Pair*>(n_K + i * NDX + 2 * j);
+      };
+      double usv[NU], kfv[NU];
       if (!terminal) {
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
-          double a_ = n_us[i] - n_kf[i] * L.alpha;
+          usv[i] = n_us[i];
+          kfv[i] = n_kf[i];
+        }
+        load_row(0, 0);
+      }
+      R6_SCHED_FENCE();
+      R6_SUB(0);
+      state_diff<DM>(xn, x, dx, nullptr);
+      R6_SUB(1);
+      if (L.need_dv) {
+        double vf[NDX];
 #pragma unroll
-          for (int j = 0; j < NDX; ++j) a_ -= n_K[i * NDX + j] * dx[j];
+        for (int i = 0; i < NDX; ++i) vf[i] = n_vf[i];
+        R6_SCHED_FENCE();
+        double dv = dvA[sl];
+#pragma unroll
+        for (int i = 0; i < NDX; ++i) dv += vf[i] * dx[i];  // +(Vxx f).(xs_try (-) xs)
+        dvA[sl] = dv;
+      }
+      R6_SUB(2);
+      if (!terminal) {
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+          if (i + 1 < NU) load_row(i + 1, (i + 1) & 1);
+          R6_SCHED_FENCE();
+          double a_ = usv[i] - kfv[i] * L.alpha;
+#pragma unroll
+          for (int j = 0; j < NDX; ++j) a_ -= kr[i & 1][j / 2][j % 2] * dx[j];
           // SolverBox{DDP,FDDP}::forwardPass clamp the trial control to the limits of the model
           s[i] = (P.prm.solver_type != EMPC_SOLVER_SBFDDP) ? fmin(fmax(a_, PL.u_lb[i]), PL.u_ub[i]) : a_;
+          R6_SCHED_FENCE();
         }
       } else {
 #pragma unroll
         for (int i = 0; i < NU; ++i) s[i] = 0.0;
       }
+      R6_SUB(3);
       if (P.use_squash) {
         double lbv[NU], ubv[NU];
         const int power = P.prm.smoothsat_power;
@@ -462,6 +495,7 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
       for (int i = 0; i < NV; ++i) TAU[i * NL + lane] = tau[i];
 #pragma unroll
       for (int i = 0; i < NU; ++i) UT[i * NL + lane] = s[i];
+      R6_SUB(4);
     });
     // ---- B: bias forces with the frame captures; frame costs; contact frame for C ------------------------------------------
     if constexpr (ROLE == R6_B) ex.each([&](int lane, int sl) {
@@ -558,11 +592,13 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
     if constexpr (ROLE == R6_C) ex.each([&](int lane, int sl) {
       const Roll6Lane& L = LL[sl];
       if (!L.live) return;
+      R6_SUB(6);
       double cs[NB], sn[NB];
 #pragma unroll
       for (int b = 1; b < NB; ++b) fsincos(XT[(7 + b - 1) * NL + lane], &sn[b - 1], &cs[b - 1]);
       crba_chain<NB>(m, cs, sn, Lc[sl]);
       chol_packed<NV>(Lc[sl]);
+      R6_SUB(5);
     });
     // ---- D: cost of the previous knot, State costs of this one, stores, staging of the next knot's nominal data ----------------
     if constexpr (ROLE == R6_D) ex.each([&](int lane, int sl) {
@@ -570,7 +606,9 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
       if (t < T && last_stage) fetch_gap(t + 1, sl);  // in flight behind the State costs
       R6_SCHED_FENCE();
       if (L.live) {
+        R6_SUB(6);
         if (stepq > 0) finish_cost(st > 0 ? t : t - 1, st > 0 ? st - 1 : NST - 1, lane, sl, L);
+        R6_SUB(0);
         double x[NX];
 #pragma unroll
         for (int i = 0; i < NX; ++i) x[i] = XT[i * NL + lane];
@@ -579,6 +617,7 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
 #pragma unroll
           for (int i = 0; i < NX; ++i) xs_o[i] = x[i];
         }
+        R6_SUB(1);
         double rstate[NDX];
         int rstate_of = -1;
         for (int ks = 0; ks < si.n_state; ++ks) {
@@ -590,6 +629,7 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
           }
           VAL[ci * NL + lane] = activation_value<NDX>(c, rstate, NDX);
         }
+        R6_SUB(2);
       }
       R6_SCHED_FENCE();
       if (t < T && last_stage) put_gap(t + 1, lane, sl);
@@ -602,6 +642,7 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
     if constexpr (ROLE == R6_C) ex.each([&](int lane, int sl) {
       const Roll6Lane& L = LL[sl];
       if (!L.live) return;
+      R6_SUB(6);
       double x[NX], a[NV], lam[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
       for (int i = 0; i < NX; ++i) x[i] = XT[i * NL + lane];
@@ -618,7 +659,9 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
 #pragma unroll
         for (int i = 0; i < NV; ++i) a[i] = tv[i] - hv[i];
       }
+      R6_SUB(0);
       chol_solve_packed<NV>(Lc[sl], a);
+      R6_SUB(1);
       if constexpr (CT) {
         if (use_contact) {
           FrameCap<double> ck;
@@ -637,6 +680,7 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
           contact_forward<DM, CT>(m, set.contacts[0], ck, R0, x, cs, sn, Lc[sl], a, lam);
         }
       }
+      R6_SUB(2);
 #pragma unroll
       for (int i = 0; i < NV; ++i) ACC[i * NL + lane] = a[i];
 #pragma unroll
@@ -698,6 +742,7 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
           if (okC[sl]) ncC[sl] = (t + 1 < T) ? t + 1 : T;
           okC[sl] = 0;
         }
+        R6_SUB(3);
         if (L.plain) {
 #pragma unroll
           for (int i = 0; i < NX; ++i) xt[i] = xn[i];
@@ -711,6 +756,7 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
 #pragma unroll
         for (int i = 0; i < NX; ++i) XT[i * NL + lane] = xt[i];
       }
+      R6_SUB(4);
     });
     // ---- B: next knot's gain rows into the staging buffer (A reads them in phase I of the next knot) ---------------------------
     if constexpr (ROLE == R6_B) ex.each([&](int lane, int sl) {
@@ -732,6 +778,7 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
     if constexpr (ROLE == R6_D) ex.each([&](int lane, int sl) {
       const Roll6Lane& L = LL[sl];
       if (!L.live || st > 0) return;  // (RK4 nodes: the control and its cost values are those of stage 0 for all four stages)
+      R6_SUB(6);
       double s[NU];
 #pragma unroll
       for (int i = 0; i < NU; ++i) s[i] = terminal ? 0.0 : UT[i * NL + lane];
@@ -744,6 +791,7 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
 #pragma unroll
         for (int i = 0; i < NU; ++i) us_o[i] = s[i];
       }
+      R6_SUB(3);
     });
     R6_STAMP(2);
     ex.sync();
@@ -757,6 +805,8 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
         for (int i = 0; i < 4; ++i) D.dbg[48 + ROLE * 4 + i] = r6st[i];
       if (lane == 0 && ROLE == R6_B)
         for (int i = 0; i < 7; ++i) D.dbg[i] = r6b[i];
+      if (lane == 0)
+        for (int i = 0; i < 7; ++i) D.dbg[64 + ROLE * 8 + i] = r6b[i];
     });
 #endif
   // ---- results of the trials -------------------------------------------------------------------------------------------------------

@@ -57,15 +57,34 @@ static bool baked_enabled() {
 static bool find_table(const DevProblem& P, int nb, int nrot, bool contact, int contact_rows, KernelTable& k, const char** which = nullptr) {
   if (which) *which = "runtime model";
   if (baked_enabled() && !(contact && nb == 4 && std::getenv("EMPC_FORCE_MIXED_CONTACT"))) {
-    if (nb == 4 && nrot == 6 && baked_matches(empc::kBakedHex370Arm3, P)) {
-      if (!contact) {
-        k = empc_table_baked_arm3();
-        if (which) *which = "baked hexacopter370_flying_arm_3";
+    // the robots the library carries as compile-time tables (tools/bake_models.py), each with the dynamics it is instantiated for
+    struct Baked {
+      const empc::BakedTree* tree;
+      KernelTable (*free_dynamics)();
+      KernelTable (*contact3)();
+      const char* free_name;
+      const char* contact3_name;
+    };
+    static const Baked baked[] = {
+        {&empc::kBakedHex370Arm3, empc_table_baked_arm3, empc_table_baked_arm3_contact, "baked hexacopter370_flying_arm_3",
+         "baked hexacopter370_flying_arm_3, ContactModel3D"},
+        {&empc::kBakedHextiltArm5, empc_table_baked_arm5, nullptr, "baked hextilt_flying_arm_5", nullptr},
+        {&empc::kBakedHex680Arm2, empc_table_baked_arm2, nullptr, "baked hexacopter680_flying_arm_2", nullptr},
+        {&empc::kBakedHex370, empc_table_baked_hex370, nullptr, "baked hexacopter370", nullptr},
+        {&empc::kBakedHextilt, empc_table_baked_hextilt, nullptr, "baked hextilt", nullptr},
+        {&empc::kBakedIris, empc_table_baked_iris, nullptr, "baked iris", nullptr},
+        {&empc::kBakedIrisPx4, empc_table_baked_iris_px4, nullptr, "baked iris_px4", nullptr},
+    };
+    for (const Baked& e : baked) {
+      if (!baked_matches(*e.tree, P)) continue;
+      if (!contact && e.free_dynamics) {
+        k = e.free_dynamics();
+        if (which) *which = e.free_name;
         return true;
       }
-      if (contact_rows == 3) {
-        k = empc_table_baked_arm3_contact();
-        if (which) *which = "baked hexacopter370_flying_arm_3, ContactModel3D";
+      if (contact && contact_rows == 3 && e.contact3) {
+        k = e.contact3();
+        if (which) *which = e.contact3_name;
         return true;
       }
     }
@@ -342,8 +361,8 @@ EmpcSolver* empc_solver_create(const EmpcProblemDesc* problem, const EmpcSolverP
   s->dlin_list = s->dalloc<int>(2 * (size_t)batch);          // per sweep slot: the linearize list of every chunk, chunk after chunk
   s->dact_list = s->dalloc<int>(2 * (size_t)batch);
   s->dcalc_list = s->dalloc<int>(2 * (size_t)batch);
-  D.dbg = s->dalloc<unsigned long long>(64);
-  HIP_CHECK(hipMemsetAsync(D.dbg, 0, 64 * sizeof(unsigned long long), s->stream));
+  D.dbg = s->dalloc<unsigned long long>(128);
+  HIP_CHECK(hipMemsetAsync(D.dbg, 0, 128 * sizeof(unsigned long long), s->stream));
   D.B = batch;
   D.T = s->T;
   D.NA = s->NA;
@@ -1107,7 +1126,7 @@ int empc_solver_get_trace(EmpcSolver* s, int b, double* records, int max_records
 }
 // diagnostic builds only (-DEMPC_STAMPS): per-stage cycle counters written by trajectory 0
 int empc_solver_debug_counters(EmpcSolver* s, unsigned long long* out, int n) {
-  if (!s || !out || n > 64) return EMPC_ERR_INVALID;
+  if (!s || !out || n > 128) return EMPC_ERR_INVALID;
   if (hipMemcpy(out, s->D.dbg, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost) != hipSuccess) return EMPC_ERR_RUNTIME;
   return EMPC_OK;
 }

@@ -1,0 +1,115 @@
+"""Baked-robot kernel instantiations (eagle-mpc_amd/csrc/baked/, tools/bake_models.py, include/empc.h:
+empc_solver_kernel_family) against the runtime-model instantiations of the same robot class.
+
+The two are compilations of ONE source: in the baked one the robot's constants are literals, products with its structural
+zeros are gone and the compiler contracts the remaining multiply-adds differently, so the results differ at rounding level.
+Checked here, per shipped robot: (1) the solver picks the baked family for the shipped YAMLs and the runtime family when told
+to (EMPC_BAKED=0) or when the robot differs from the table by one bit; (2) every record of the tape, the gains and the trial
+rollouts of the two families agree to 1e-10 relative on a random candidate; (3) on the well-conditioned workloads whole solves
+take the same iterations and end within 1e-7.  Both families are also held to the oracle by the rest of the suite: every
+shipped YAML runs the baked kernels by default, the contact6 / mixed / perturbed-robot cases the runtime-model ones."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import CONFIGS
+from test_gpu_parity import random_candidate, rel
+
+pytestmark = pytest.mark.gpu
+
+ROBOTS = [
+    # (trajectory file, dt ms, family)
+    ("hexacopter370_flying_arm_3/trajectories/displacement.yaml", 80, "baked hexacopter370_flying_arm_3"),
+    ("hexacopter370_flying_arm_3/trajectories/eagle_catch.yaml", 32, "baked hexacopter370_flying_arm_3, ContactModel3D"),
+    ("hextilt_flying_arm_5/trajectories/push_slide.yaml", 13, "baked hextilt_flying_arm_5"),
+    ("hexacopter680_flying_arm_2/trajectories/hover.yaml", 40, "baked hexacopter680_flying_arm_2"),
+    ("hexacopter370/trajectories/hover.yaml", 40, "baked hexacopter370"),
+    ("hextilt/trajectories/hover.yaml", 40, "baked hextilt"),
+    ("iris/trajectories/hover.yaml", 40, "baked iris"),
+    ("iris_px4/trajectories/hover.yaml", 40, "baked iris_px4"),
+]
+
+
+def runtime_solver(empc, problem, batch):
+    os.environ["EMPC_BAKED"] = "0"
+    try:
+        return empc.SolverSbFDDP(problem, batch=batch)
+    finally:
+        del os.environ["EMPC_BAKED"]
+
+
+@pytest.mark.parametrize("relpath,dt,family", ROBOTS)
+def test_family_and_phase_agreement(empc, relpath, dt, family):
+    t = empc.Trajectory()
+    t.autoSetup(empc.yaml_path(relpath))
+    problem = t.createProblem(dt, True, "IntegratedActionModelEuler")
+    d = problem.desc
+    B = 4
+    a = empc.SolverSbFDDP(problem, batch=B)
+    b = runtime_solver(empc, problem, B)
+    assert a.kernel_family == family and b.kernel_family == "runtime model"
+    xs, us = random_candidate(d, B, seed=3)
+    x0s = empc.perturbed_x0s(problem.x0, B, nq=d.model.nq, seed=4)
+    ta = a.linearize(xs, us, smooth=0.1, is_feasible=False, x0s=x0s)
+    tb = b.linearize(xs, us, smooth=0.1, is_feasible=False, x0s=x0s)
+    for bi in range(B):
+        for tk in range(d.T + 1):
+            ga, gb = a.tape_blocks(ta[bi, tk]), b.tape_blocks(tb[bi, tk])
+            for key in ga:
+                assert rel(np.asarray(ga[key]).ravel(), np.asarray(gb[key]).ravel()) < 1e-9, (key, bi, tk)
+    Ka, ka, Vxa, dga, oka = a.backward(xreg=1e-9, is_feasible=False)
+    Kb, kb, Vxb, dgb, okb = b.backward(xreg=1e-9, is_feasible=False)
+    assert np.array_equal(oka, okb)
+    assert rel(Ka, Kb) < 1e-6 and rel(ka, kb) < 1e-6 and rel(Vxa, Vxb) < 1e-7  # LLT of Quu at xreg 1e-9 amplifies the last bit
+    # one set of gains for both rollouts, so that only the rollout arithmetic differs
+    b.set_gains(Ka, ka)
+    for alpha in (0.25, 0.0625):
+        xa, ua, ca, ra = a.rollout(alpha, ddp=False, is_feasible=False)
+        xb, ub, cb, rb = b.rollout(alpha, ddp=False, is_feasible=False)
+        assert np.array_equal(ra, rb)
+        for bi in range(B):
+            if ra[bi] and np.isfinite(ca[bi]) and abs(ca[bi]) < 1e10:
+                assert rel(xa[bi], xb[bi]) < 1e-8 and rel(ua[bi], ub[bi]) < 1e-8, (alpha, bi)
+                assert abs(ca[bi] - cb[bi]) < 1e-8 * (1 + abs(cb[bi]))
+
+
+@pytest.mark.parametrize("name", ["displacement", "push_slide"])
+def test_solves_agree_on_well_conditioned_workloads(empc, problems, name):
+    _, problem = problems[name]
+    d = problem.desc
+    B = 8
+    x0s = empc.perturbed_x0s(problem.x0, B, nq=d.model.nq, seed=9)
+    a = empc.SolverSbFDDP(problem, batch=B)
+    b = runtime_solver(empc, problem, B)
+    assert a.kernel_family.startswith("baked") and b.kernel_family == "runtime model"
+    a.solve([], [], 100, x0s=x0s)
+    b.solve([], [], 100, x0s=x0s)
+    assert np.array_equal(a.iter_batch, b.iter_batch) and np.array_equal(a.status_batch, b.status_batch)
+    assert np.abs(a.xs_batch - b.xs_batch).max() < 1e-7 and np.abs(a.us_squash_batch - b.us_squash_batch).max() < 1e-6
+    assert np.all(np.abs(a.cost_batch - b.cost_batch) < 1e-9 * (1 + np.abs(b.cost_batch)))
+
+
+def test_one_bit_off_the_table_falls_back_and_update_problem_repicks(empc, problems):
+    """A robot that differs from the baked table in the last bit of one mass must run the runtime-model kernels, at creation
+    and when it arrives through empc_solver_update_problem; results of the fallback equal the runtime family's bit for bit."""
+    _, problem = problems["displacement"]
+    d = problem.desc
+    s = empc.SolverSbFDDP(problem, batch=2)
+    assert s.kernel_family.startswith("baked")
+    mass = d.model.mass[1]
+    try:
+        d.model.mass[1] = np.nextafter(mass, 2.0)
+        s.update_problem()
+        assert s.kernel_family == "runtime model"
+        s2 = empc.SolverSbFDDP(problem, batch=2)
+        assert s2.kernel_family == "runtime model"
+        x0s = empc.perturbed_x0s(problem.x0, 2, nq=d.model.nq, seed=1)
+        s.solve([], [], 20, x0s=x0s)
+        s2.solve([], [], 20, x0s=x0s)
+        assert np.array_equal(s.xs_batch, s2.xs_batch) and np.array_equal(s.iter_batch, s2.iter_batch)
+    finally:
+        d.model.mass[1] = mass
+    s.update_problem()
+    assert s.kernel_family.startswith("baked")

@@ -34,7 +34,7 @@ PY
 
 case "$MODE" in
   tests)
-    timeout 1700 python -m pytest tests -q -m gpu -x --durations=10 2>&1 | tail -40 | tee "gpurun_out/${TAG}_pytest.log"
+    timeout 1700 python -m pytest tests -q -m gpu --durations=10 ${PYTEST_ARGS:-} 2>&1 | tail -${TAIL:-60} | tee "gpurun_out/${TAG}_pytest.log"
     ;;
   check)
     timeout 1700 python -m pytest tests -q -m gpu --durations=10 2>&1 | tail -40 | tee "gpurun_out/${TAG}_pytest.log"
@@ -46,6 +46,13 @@ case "$MODE" in
       bench_line "${cfg}_baked" "EMPC_BAKED=1" --config $cfg --no-cpu-baseline --no-secondary --steps 10
       bench_line "${cfg}_generic" "EMPC_BAKED=0" --config $cfg --no-cpu-baseline --no-secondary --steps 10
     done
+    ;;
+  stamps)
+    # phase-level launches: product library first (ms per launch), then the diagnostic build with in-kernel cycle stamps
+    for c in displacement eagle_catch; do
+      echo "== $c (product)"; python3 tools/phase_bench.py --config $c --reps 3 2>&1 | grep -E "^\{"
+      echo "== $c (stamps build)"; EMPC_LIB_PATH="$ROOT/eagle-mpc_amd/libempc_stamps.so" python3 tools/phase_bench.py --config $c --reps 3 2>&1 | grep -E "^\{|stage|role"
+    done 2>&1 | tee "gpurun_out/${TAG}_stamps.log"
     ;;
   *)
     echo "unknown mode $MODE"; exit 2

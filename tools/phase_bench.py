@@ -38,9 +38,9 @@ units = {"linearize": B * (d.T + 1), "backward": B * d.T, "rollout": B * 10 * (d
 out = {k: {"ms": v, "GBs": units[k] * w[k] * 8 / (v * 1e-3) / 1e9} for k, v in res.items()}
 print(json.dumps(out))
 import ctypes as C
-cnt = (C.c_ulonglong * 64)()
+cnt = (C.c_ulonglong * 128)()
 empc.lib().empc_solver_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
-empc.lib().empc_solver_debug_counters(s._h, cnt, 64)
+empc.lib().empc_solver_debug_counters(s._h, cnt, 128)
 print('stage cycles (EMPC_STAMPS builds; rollout v1, trajectory 0, alpha 1/2): feedback|prep|rnea|crba|chol|kkt|euler|costs|-|tail', list(cnt)[:10])
 
 
@@ -50,3 +50,6 @@ print('backward sub-stages: chol+solves|sync|Quu k+sync|Vx partial|Vxx MFMA + W 
 print('rollout6 role cycles per rollout (EMPC_STAMPS builds; workgroup 0): role A|B|C|D x {phase I work, wait 1, phase II work, wait 2}',
       [list(cnt)[48 + 4 * r:52 + 4 * r] for r in range(4)])
 print('rollout6 role B sub-stages (cycles per rollout): fetch issue|quat,trig,scan|rnea|H,CAP writes|frame costs|-|outside', list(cnt)[0:7])
+print('rollout6 role A sub-stages: operand loads|state diff|dv|K dx|squash,tau,stores|-|outside', list(cnt)[64:71])
+print('rollout6 role C sub-stages: II operands|II solve|II contact|II ACC,Euler,check|II gap,XT|I crba+chol|outside', list(cnt)[80:87])
+print('rollout6 role D sub-stages: I finish_cost|I x,xs store|I state costs|II control costs,us store|-|-|outside', list(cnt)[88:95])
