@@ -63,6 +63,8 @@ def lib():
     L.empc_trajectory_create_problem.restype = C.c_void_p
     L.empc_trajectory_create_problem.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p]
     L.empc_trajectory_get_param.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int]
+    L.empc_trajectory_remove_stage.argtypes = [C.c_void_p, C.c_int]
+    L.empc_trajectory_robot_model_path.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     L.empc_problem_destroy.argtypes = [C.c_void_p]
     L.empc_problem_desc.restype = C.POINTER(T.ProblemDesc)
     L.empc_problem_desc.argtypes = [C.c_void_p]
@@ -228,6 +230,19 @@ class RobotModel:
         self.name, self.nq, self.nv, self._owner = name, nq, nv, owner
 
 
+class StageInfo:
+    """One entry of Trajectory.stages: the read-only view of a Stage (bindings/python/eagle_mpc/stage.hpp: name, duration,
+    is_transition, t_ini, costs, contacts)."""
+
+    def __init__(self, name, duration, is_transition, n_costs, n_contacts, t_ini, costs):
+        self.name, self.duration, self.is_transition, self.t_ini = name, duration, is_transition, t_ini
+        self.n_costs, self.n_contacts, self.costs = n_costs, n_contacts, costs
+
+    def __repr__(self):
+        return "StageInfo(%r, duration=%d ms, t_ini=%d ms, costs=%d, contacts=%d%s)" % (
+            self.name, self.duration, self.t_ini, self.n_costs, self.n_contacts, ", transition" if self.is_transition else "")
+
+
 class Trajectory:
     """Mirror of eagle_mpc.Trajectory (bindings/python/eagle_mpc/trajectory.hpp:24-63)."""
 
@@ -241,8 +256,37 @@ class Trajectory:
         self._h = C.c_void_p(h)
         v = [C.c_int() for _ in range(6)]
         _check(lib().empc_trajectory_dims(self._h, *[C.byref(x) for x in v]))
-        self.nx, self.ndx, self.nu, _, hc, self.duration = [x.value for x in v]
+        self.nx, self.ndx, self.nu, _, hc, _ = [x.value for x in v]
         self.has_contact = bool(hc)
+
+    @property
+    def duration(self):
+        """get_duration(): total duration in ms, as autoSetup summed it (src/trajectory.cpp:90-99)"""
+        n = C.c_int()
+        _check(lib().empc_trajectory_dims(self._h, None, None, None, None, None, C.byref(n)))
+        return n.value
+
+    @property
+    def stages(self):
+        """get_stages() by value: one StageInfo per stage, in order (name, duration, is_transition, t_ini, the names / weights /
+        active flags of its costs, the number of its contacts).  A snapshot: edit the trajectory through its own methods."""
+        return [StageInfo(**self.stage_info(i)) for i in range(self.n_stages)]
+
+    @property
+    def robot_model_path(self):
+        """get_robot_model_path(): the URDF file the robot model was built from"""
+        n = lib().empc_trajectory_robot_model_path(self._h, None, 0)
+        if n < 0:
+            raise EmpcError(lib().empc_last_error().decode())
+        buf = C.create_string_buffer(n + 1)
+        lib().empc_trajectory_robot_model_path(self._h, buf, n + 1)
+        return buf.value.decode()
+
+    def removeStage(self, idx_stage):
+        """Trajectory::removeStage (src/trajectory.cpp:145-150): erases stage `idx_stage`; durations and start times of the
+        other stages stay as they are, as in the reference"""
+        if lib().empc_trajectory_remove_stage(self._h, int(idx_stage)) != 0:
+            raise IndexError(lib().empc_last_error().decode())
 
     @property
     def n_stages(self):
@@ -348,8 +392,8 @@ class CallbackVerbose:
         self.lines = []
 
     def __call__(self, rec):
-        if rec.iter % 10 == 0 and (not self.lines or rec.iter == 0):
-            self._emit("iter \t cost \t      stop \t    grad \t  xreg \t      ureg \t step \t feas")
+        if rec.iter % 10 == 0:  # crocoddyl reprints the header every ten iterations (as host/sbfddp.cpp does)
+            print("iter \t cost \t      stop \t    grad \t  xreg \t      ureg \t step \t feas", file=self.stream)
         self._emit("%4d  %0.5e  %0.5e  %0.5e  %10.5e  %10.5e   %0.4f     %d" %
                    (rec.iter, rec.cost, rec.stop, -rec.d[1], rec.x_reg, rec.u_reg, rec.stepLength, int(rec.is_feasible)))
 
@@ -374,6 +418,9 @@ class SolverSbFDDP:
         self.problem = problem
         self.batch = int(batch)
         if squashing_model is not None:
+            if isinstance(squashing_model, (int, np.integer)) and not isinstance(squashing_model, bool):
+                raise TypeError("the second argument of SolverSbFDDP is the squashing model (trajectory.squash), as in the "
+                                "reference; rounds 1-2 of this mirror took the batch there: pass batch=%d by keyword" % squashing_model)
             if not isinstance(squashing_model, SquashingModelSmoothSat):
                 raise TypeError("squashing_model must be a SquashingModelSmoothSat (e.g. trajectory.squash)")
             d = problem.desc

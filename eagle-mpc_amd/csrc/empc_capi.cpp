@@ -70,6 +70,29 @@ int empc_trajectory_dims(const EmpcTrajectory* t, int* nx, int* ndx, int* nu, in
   EMPC_CATCH(EMPC_ERR_INVALID)
 }
 
+/* Trajectory::removeStage (src/trajectory.cpp:145-150): erases the stage; like the reference it leaves duration_ and the
+ * t_ini of the other stages alone (WeightedMpc merges the durations itself before it removes a transition stage) */
+int empc_trajectory_remove_stage(EmpcTrajectory* t, int stage) {
+  EMPC_TRY
+  if (!t) throw std::invalid_argument("trajectory is NULL");
+  if (stage < 0 || (size_t)stage >= t->t->get_stages().size()) throw std::out_of_range("removeStage: no such stage");
+  t->t->removeStage((size_t)stage);
+  return EMPC_OK;
+  EMPC_CATCH(EMPC_ERR_INVALID)
+}
+/* Trajectory::get_robot_model_path (src/trajectory.cpp:160): the URDF file the robot was built from; returns its length */
+int empc_trajectory_robot_model_path(const EmpcTrajectory* t, char* path, int path_len) {
+  EMPC_TRY
+  if (!t) throw std::invalid_argument("trajectory is NULL");
+  const std::string& p = t->t->get_robot_model_path();
+  if (path && path_len > 0) {
+    std::strncpy(path, p.c_str(), (size_t)path_len - 1);
+    path[path_len - 1] = 0;
+  }
+  return (int)p.size();
+  EMPC_CATCH(EMPC_ERR_INVALID)
+}
+
 int empc_trajectory_stage_info(const EmpcTrajectory* t, int stage, char* name, int name_len, int* duration_ms,
                                int* is_transition, int* n_costs, int* n_contacts) {
   EMPC_TRY

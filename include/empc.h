@@ -69,6 +69,10 @@ long long empc_trajectory_stage_t_ini(const EmpcTrajectory* t, int stage);
 /* Stage::get_costs()->get_costs(): the cost-th entry in name order, with its weight and active flag */
 int empc_trajectory_stage_cost(const EmpcTrajectory* t, int stage, int cost, char* name, int name_len, double* weight,
                                int* active);
+/* Trajectory::removeStage(idx_stage) (src/trajectory.cpp:145-150; bindings/python/eagle_mpc/trajectory.hpp:62) */
+int empc_trajectory_remove_stage(EmpcTrajectory* t, int stage);
+/* Trajectory::get_robot_model_path() (src/trajectory.cpp:160; bindings .../trajectory.hpp:42-43); returns the length */
+int empc_trajectory_robot_model_path(const EmpcTrajectory* t, char* path, int path_len);
 int empc_trajectory_get_initial_state(const EmpcTrajectory* t, double* x0 /* nx */);
 int empc_trajectory_set_initial_state(EmpcTrajectory* t, const double* x0 /* nx */);
 int empc_trajectory_get_platform(const EmpcTrajectory* t, double* tau_f /* 6 x n_rotors */, double* u_lb, double* u_ub,

