@@ -52,6 +52,7 @@ MPC_YAML = os.path.join(ROOT, "eagle-mpc_amd", "data", "mpc", "carrot_50knots.ya
 MPC_CYCLES_PER_STEP = 20   # one bench step of the *_mpc configs = 20 controller cycles (updateProblem, solve, plant)
 MPC_DT_SIM = 2             # ms, examples/python/mpc.py:41
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_PEAK_TFLOPS = 78.6  # FP64 vector: 256 CUs x 4 SIMDs x 16 FMA lanes/clk x 2 flop x 2.4 GHz
 
 
 def algorithmic_words(nx, ndx, nu):
@@ -153,24 +154,36 @@ def cpu_baseline_and_parity(empc, solver, problem, d, x0s, B, maxiter, unit):
     threads = host_threads()
     # all-core leg: a bounded sample of the batch (whole batch on a box with >= 64 cores), OpenMP over rollouts
     n_sample = int(min(B, max(64, threads * 16)))
+    # Two builds of the same sources (oracle/Makefile): the CHECKER (contraction-free, -march=x86-64-v3: parity below runs
+    # against it) and the TIMED one (-O3 -march=native, FMA on, compiled on this box: SURVEY.md section 8(d)) -- the baseline
+    # numbers come from the timed build only; its rounding differs, so nothing is compared against it.
     ref = ob.solve_batch(d, x0s[:n_sample], maxiter, nthreads=threads, want_traj=True)
-    cpu_iters = float((ref["iter"] + 1).sum())
+    try:
+        timed = ob.solve_batch(d, x0s[:n_sample], maxiter, nthreads=threads, want_traj=False, variant="native")
+        timed_build = "oracle/liboracle_native.so: g++ -O3 -march=native -ffp-contract=fast, built on this host"
+        variant = "native"
+    except Exception as e:  # no compiler on the box: fall back to the checker build and say so
+        timed, variant = ref, None
+        timed_build = "oracle/liboracle.so (checker build, -march=x86-64-v3 -ffp-contract=off): native build failed: %s" % str(e)[:120]
+    cpu_iters = float((timed["iter"] + 1).sum())
     # single-thread leg (how the reference itself runs): three rollouts, one at a time, us per DDP iteration
     us_per_it, it_single, t_single = [], 0.0, 0.0
     for b in range(min(3, n_sample)):
-        r1 = ob.solve_batch(d, x0s[b:b + 1], maxiter, nthreads=1, want_traj=False)
+        r1 = ob.solve_batch(d, x0s[b:b + 1], maxiter, nthreads=1, want_traj=False, variant=variant)
         n_it = float(r1["iter"][0] + 1)
         us_per_it.append(r1["seconds"] * 1e6 / n_it)
         it_single += n_it
         t_single += r1["seconds"]
     us_per_it = np.array(us_per_it)
     out = {"cpu_baseline": {
-        "value": cpu_iters / B / ref["seconds"], "unit": unit, "cores": threads, "kind": "port",
+        "value": cpu_iters / B / timed["seconds"], "unit": unit, "cores": threads, "kind": "port",
         "sample": "%d of the %d rollouts of rank 0 (mean %.1f iterations each), OpenMP over rollouts on %d threads = physical "
-                  "cores available to the process; oracle/liboracle.so (FP64 C++ restatement of the Crocoddyl/Pinocchio "
-                  "arithmetic, not the reference binary: it cannot be built here)" % (n_sample, B, cpu_iters / n_sample, threads),
+                  "cores available to the process; FP64 C++ restatement of the Crocoddyl/Pinocchio arithmetic (oracle/), not the "
+                  "reference binary: it cannot be built here" % (n_sample, B, cpu_iters / n_sample, threads),
+        "build": timed_build,
+        "checker_build_value": float((ref["iter"] + 1).sum()) / B / ref["seconds"],
         "cpu_model": cpu_model(), "logical_cpus": os.cpu_count(),
-        "trajectory_iters_per_s": cpu_iters / ref["seconds"], "seconds": ref["seconds"],
+        "trajectory_iters_per_s": cpu_iters / timed["seconds"], "seconds": timed["seconds"],
         "single_thread": {"trajectory_iters_per_s": it_single / t_single, "rollouts": int(len(us_per_it)),
                           "us_per_iteration": {"AVG": float(us_per_it.mean()), "STDDEV": float(us_per_it.std()),
                                                "MAX": float(us_per_it.max()), "MIN": float(us_per_it.min())},
@@ -407,7 +420,13 @@ def main():
         if args.warmup > 0:
             solver.stream_begin(np.ascontiguousarray(np.resize(x0s, (args.warmup * B, d.nx))))
             solver.stream_run(args.maxiter)
+        # (queue set-up -- allocation, upload of the initial states, zeroing of the result rows -- is timed on its own: `value`
+        #  starts with the inputs resident in HBM, `value_including_queue_setup` charges the set-up as well)
+        torch.cuda.synchronize()
+        tq = time.perf_counter()
         solver.stream_begin(x0s)
+        torch.cuda.synchronize()
+        queue_setup_s = time.perf_counter() - tq
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -437,7 +456,14 @@ def main():
         elapsed = time.perf_counter() - t0
     iters_rank = float(agg["total_iters"])
     ranks_seen, ranks_golden_ok = 1, None
+    per_rank = None
     if dist is not None:
+        # per-rank view (each rank's own iterations over its own clock), so that one line shows a slow or idle GPU
+        mine = torch.tensor([iters_rank, elapsed], dtype=torch.float64, device=coll_dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [{"rank": r, "value": float(e[0].item()) / B / float(e[1].item()), "seconds": float(e[1].item())}
+                    for r, e in enumerate(every)]
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -467,22 +493,34 @@ def main():
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         # HBM bytes per launch of the dominant kernel from the committed PMC passes of this workload at a full batch
         # (FETCH_SIZE / WRITE_SIZE, tools/run_profiles.sh): read from profiles/, not measured in this run
-        traffic = None
-        for prof in (os.path.join(ROOT, "profiles", "traffic_%s_%s.json" % (args.config, dom)),):
-            if not os.path.exists(prof) or B != 1024:
-                continue
+        # (tools/gpu_r4.sh profiles: separate --pmc passes over THIS command line in stream mode, summarised over the
+        #  launches with a full grid only; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md).  No file for the
+        #  workload / batch at hand: null.
+        pmc = {}
+        prof = os.path.join(ROOT, "profiles", "r04_pmc_%s.json" % args.config)
+        if os.path.exists(prof) and B == 1024 and not is_mpc:
             try:
-                j = json.load(open(prof))
+                pmc = json.load(open(prof)).get("kernels", {})
             except Exception:
-                continue
-            if j.get("config", "displacement") == args.config:
-                traffic = j.get("hbm_bytes_per_launch")
-                break
+                pmc = {}
+        traffic = (pmc.get(dom) or {}).get("hbm_bytes_per_launch")
         per_launch = {k: {"avg_ms": kern[k][0] / max(kern[k][1], 1), "launches": kern[k][1],
                           "algorithmic_GBs": (kern[k][2] / max(kern[k][1], 1) * words[k] * 8.0) / (kern[k][0] / max(kern[k][1], 1) * 1e-3) / 1e9
                           if kern[k][0] > 0 else 0.0} for k in kern}
         for k in per_launch:
             per_launch[k]["frac_of_8TBs"] = per_launch[k]["algorithmic_GBs"] / HBM_PEAK_GBS
+            # compute side (the memory side binds only by ~2x): FP64 vector instructions per full-batch
+            # launch counted by the SQ (profiles/r04_pmc_<config>.json), x 64 lanes x (2 for an FMA) / this run's launch time
+            # against the 78.6 TFLOP/s FP64 vector peak; valu_busy = SQ_ACTIVE_INST_VALU x 4 / SQ_BUSY_CYCLES of that pass
+            c_ = pmc.get(k) or {}
+            if c_.get("fp64_flop_per_launch") and per_launch[k]["avg_ms"] > 0 and c_.get("units_per_launch"):
+                scale = (kern[k][2] / max(kern[k][1], 1)) / c_["units_per_launch"]  # this run's launches may be less full
+                fl = c_["fp64_flop_per_launch"] * scale
+                per_launch[k]["fp64_TFLOPs"] = fl / (per_launch[k]["avg_ms"] * 1e-3) / 1e12
+                per_launch[k]["fp64_frac_of_78.6TF"] = per_launch[k]["fp64_TFLOPs"] / FP64_PEAK_TFLOPS
+                per_launch[k]["fp64_flop_per_unit"] = c_["fp64_flop_per_launch"] / c_["units_per_launch"]
+                per_launch[k]["valu_active_frac_of_wave_cycles"] = c_.get("valu_active_frac")
+                per_launch[k]["hbm_bytes_per_launch_measured"] = c_.get("hbm_bytes_per_launch")
         if is_mpc:
             workload = ("%s closed loop on %s: %d-knot horizon dt=%dms, %d plants/GPU (RK4, %d ms), %d cycles/step, "
                         "%d iterations/cycle, warm start and plant states device-resident" %
@@ -518,7 +556,7 @@ def main():
             "ms_per_sweep": elapsed * 1e3 / max(agg["sweeps"], 1),
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": "profiles/traffic_%s_%s.json (committed PMC pass, full batch)" % (args.config, dom) if traffic else None,
+                         "traffic_source": "profiles/r04_pmc_%s.json (committed PMC passes over a stream run, full-batch launches only)" % args.config if traffic else None,
                          "achieved_from_counter_bytes_GBs": (traffic / (avg_ms * 1e-3) / 1e9) if (traffic and avg_ms > 0) else None,
                          "algorithmic_bytes_per_unit": words[dom] * 8, "units_per_launch": units / max(nlaunch, 1),
                          "unit_definition": "(trajectory, step length, knot): one launch rolls out all %d step lengths of "
@@ -533,20 +571,47 @@ def main():
         if dist is not None:
             out["ranks_seen"] = ranks_seen
             out["ranks_matching_golden_vector"] = ranks_golden_ok
+            out["per_rank"] = per_rank
         if is_mpc:
             out["mpc_cycles_per_s"] = args.steps * MPC_CYCLES_PER_STEP / elapsed
             out["plant_controller_cycles_per_s"] = args.steps * MPC_CYCLES_PER_STEP * B * world / elapsed
+        if stream:
+            out["value_including_queue_setup"] = iters_total / B / (elapsed + queue_setup_s)
+            out["queue_setup_ms"] = queue_setup_s * 1e3
+            # the line checks its own product: every job of rank 0's queue must have handed over a finished row
+            res = solver.stream_results()
+            done = (res["status"] & 7) != 0
+            out["stream_rows_checked"] = {"rows": int(len(done)), "rows_with_a_final_status": int(done.sum()),
+                                          "rows_converged": int(((res["status"] & 1) != 0).sum()),
+                                          "rows_finite": int(np.isfinite(res["xs"]).all(axis=(1, 2)).sum()),
+                                          "iterations_in_rows": int((res["iter"] + 1).sum()),
+                                          "iterations_counted_by_the_device": int(iters_rank)}
+            if not done.all():
+                raise SystemExit("stream self-check failed: %s" % json.dumps(out["stream_rows_checked"]))
         if stream and world == 1 and not args.no_single_batch:
-            # the same rollouts as plain batched solves (the latency view: one batch at a time, stragglers included)
+            # the same rollouts as plain batched solves (the latency view: one batch at a time, stragglers included); rows of
+            # the stream against the plain solve of the same initial state: bit for bit (continuous batching changes the
+            # schedule, not the arithmetic) -- the comparisons run outside the timed part
             nb = min(2, args.steps)
-            tb = time.perf_counter()
-            aggb = {}
+            aggb, elb, bitwise = {}, 0.0, []
             for k_ in range(nb):
+                torch.cuda.synchronize()
+                tb = time.perf_counter()
                 solver.solve([], [], args.maxiter, x0s=x0s[k_ * B:(k_ + 1) * B])
+                torch.cuda.synchronize()
+                elb += time.perf_counter() - tb
                 for k, v in solver.stats().items():
                     aggb[k] = aggb.get(k, 0) + v
-            torch.cuda.synchronize()
-            elb = time.perf_counter() - tb
+                pxs, pus, pc, pit = solver.xs_batch, solver.us_squash_batch, solver.cost_batch, solver.iter_batch
+                for i in ([0, 1, 17 % B, B // 2, B - 1] if k_ == 0 else [0, 5 % B, B - 1]):
+                    j = k_ * B + i
+                    bitwise.append(bool(np.array_equal(res["xs"][j], pxs[i]) and np.array_equal(res["us_squash"][j], pus[i]) and
+                                        res["cost"][j] == pc[i] and res["iter"][j] == pit[i]))
+            out["stream_rows_checked"]["rows_compared_bitwise_with_plain_solves"] = len(bitwise)
+            out["stream_rows_checked"]["rows_bitwise_equal"] = int(sum(bitwise))
+            if not all(bitwise):
+                raise SystemExit("stream self-check failed: a streamed row differs from the plain solve of its initial state: %s" %
+                                 json.dumps(out["stream_rows_checked"]))
             out["single_batch"] = {"value": aggb["total_iters"] / B / elb, "ms_per_solve": elb / nb * 1e3, "solves": nb,
                                    "sweeps_per_solve": aggb["sweeps"] / nb,
                                    "note": "plain empc_solver_solve of one batch at a time: ~3/4 of its sweeps run on the few "

@@ -455,6 +455,14 @@ class SolverSbFDDP:
     def getCallbacks(self):
         return list(self._callbacks)
 
+    def _size_callback_trace(self, maxiter):
+        """callbacks replay the device trace: the ring must hold every iteration of the solve (two FDDP passes + the DDP
+        clean-up, maxiter + 1 records each at most), or the first records of a long solve would be lost"""
+        if self._callbacks:
+            need = 3 * (int(maxiter) + 1) + 8
+            if getattr(self, "_trace_cap", 0) < need:
+                self.enable_trace(need)
+
     def _replay_callbacks(self):
         if not self._callbacks:
             return
@@ -482,6 +490,7 @@ class SolverSbFDDP:
         if isinstance(init_xs, str) or isinstance(init_us, str):
             if init_xs != "previous" or init_us != "previous":
                 raise ValueError("init_xs / init_us must both be 'previous' to reuse the last solution")
+            self._size_callback_trace(maxiter)
             _check(lib().empc_solver_solve(self._h, int(maxiter), int(bool(is_feasible))))
             self._replay_callbacks()
             return True
@@ -497,6 +506,7 @@ class SolverSbFDDP:
                 us = np.ascontiguousarray(np.broadcast_to(us, (B, T_, nu)))
             assert us.shape == (B, T_, nu)
         _check(lib().empc_solver_set_warmstart(self._h, _ptr(xs), _ptr(us)))
+        self._size_callback_trace(maxiter)
         _check(lib().empc_solver_solve(self._h, int(maxiter), int(bool(is_feasible))))
         self._replay_callbacks()
         return True

@@ -257,6 +257,7 @@ __global__ void __launch_bounds__(256) k_select(DevBuffers D) {
       stream_write_row<DM>(D, b, threadIdx.x, blockDim.x);
       if (threadIdx.x == 0) {
         atomicAdd(D.q_iters, (unsigned long long)st.total_iters);
+        atomicMax(D.q_head + 1, st.total_iters);  // largest iteration count of any job (EmpcSolveStats::max_iters of a stream)
         const int j = atomicAdd(D.q_head, 1);
         sh[2] = j < D.q_njobs ? j : -1;
       }
@@ -279,7 +280,8 @@ __global__ void __launch_bounds__(256) k_select(DevBuffers D) {
     if (D.host_active) {
       __threadfence();
       if (atomicAdd(D.done_ticket, 1) == (int)gridDim.x - 1) {  // last workgroup: all counts are in
-        *D.host_active = atomicAdd(D.n_active, 0);
+        D.host_active[0] = atomicAdd(D.n_active, 0);
+        D.host_active[1] = D.lin_count_out ? atomicAdd(D.lin_count_out, 0) : 0;
         *D.done_ticket = 0;
         __threadfence_system();
       }

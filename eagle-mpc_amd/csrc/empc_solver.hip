@@ -308,7 +308,7 @@ EmpcSolver* empc_solver_create(const EmpcProblemDesc* problem, const EmpcSolverP
   for (auto& e : s->ev) HIP_CHECK(hipEventCreate(&e));
   HIP_CHECK(hipEventCreate(&s->t_begin));
   HIP_CHECK(hipEventCreate(&s->t_end));
-  HIP_CHECK(hipHostMalloc((void**)&s->h_active, sizeof(int) * 2 * EmpcSolver::MAX_STREAMS, hipHostMallocMapped));
+  HIP_CHECK(hipHostMalloc((void**)&s->h_active, sizeof(int) * 4 * EmpcSolver::MAX_STREAMS, hipHostMallocMapped));  // per chunk and sweep slot: {active, re-linearizing}
   HIP_CHECK(hipHostGetDevicePointer((void**)&s->h_active_dev, s->h_active, 0));
   {
     // independent chunks of the batch run on separate streams (EMPC_STREAMS overrides; 1 = single stream)
@@ -611,6 +611,7 @@ struct Chunk {
   hipStream_t stream;
   hipEvent_t ev[2][7];
   int b0, nb, active, idx;
+  int lin;  // trajectories on the linearize list of the chunk's oldest in-flight sweep
 };
 
 static DevBuffers chunk_view(const EmpcSolver* s, int b0, int nb, int idx) {
@@ -670,6 +671,7 @@ static void run_sweeps(EmpcSolver* s, int hard_cap) {
     chunks[c].nb = hi - lo;
     chunks[c].idx = c;
     chunks[c].active = hi - lo;
+    chunks[c].lin = hi - lo;  // the first sweep linearizes every trajectory
     chunks[c].D = chunk_view(s, lo, hi - lo, c);
     chunks[c].stream = s->streams[c];
     for (int q = 0; q < 2; ++q)
@@ -688,6 +690,7 @@ static void run_sweeps(EmpcSolver* s, int hard_cap) {
     const int v = e ? std::atoi(e) : 4;                 // are sums over the TIMED launches, n_* counts them
     return v < 1 ? 1 : v;
   }();
+  S.timing_every = timing_every;
   auto enqueue = [&](Chunk& c) {
     const int q = queued[c.idx] & 1;
     DevBuffers Dq = c.D;
@@ -708,7 +711,7 @@ static void run_sweeps(EmpcSolver* s, int hard_cap) {
     }
     Dq.counters_next = c.D.n_active + 3 * (1 - q);  // zeroed by this sweep's select for the next sweep
     Dq.done_ticket = s->dticket + c.idx;
-    Dq.host_active = s->h_active_dev + 2 * c.idx + q;
+    Dq.host_active = s->h_active_dev + 2 * (2 * c.idx + q);
     // kernel-boundary events only on the sweeps that are timed (every `timing_every`-th: each record is a command in the
     // stream, ~10 us of dead time between two kernels); the end-of-sweep event is always there (the host waits on it)
     const bool timed = (queued[c.idx] % timing_every) == 0;
@@ -749,9 +752,14 @@ static void run_sweeps(EmpcSolver* s, int hard_cap) {
       S.n_select++;
       S.backward_units += (long long)c.active * s->T;
       S.rollout_units += (long long)c.active * s->NA * (s->T + 1);
-      S.linearize_units += (long long)c.active * (s->T + 1);  // upper bound: trajectories that re-linearize this sweep
+      S.linearize_units += (long long)c.lin * (s->T + 1);  // the trajectories on this sweep's linearize list
     }
-    c.active = s->h_active[2 * c.idx + q];
+    // (units of EVERY sweep, timed or not: total work of the solve)
+    S.backward_units_all += (long long)c.active * s->T;
+    S.rollout_units_all += (long long)c.active * s->NA * (s->T + 1);
+    S.linearize_units_all += (long long)c.lin * (s->T + 1);
+    c.active = s->h_active[2 * (2 * c.idx + q)];
+    c.lin = s->h_active[2 * (2 * c.idx + q) + 1];  // what select put on the next sweep's linearize list
     retired[c.idx]++;
   };
   for (auto& c : chunks) {
@@ -781,10 +789,11 @@ static void run_sweeps(EmpcSolver* s, int hard_cap) {
     S.sweeps = std::max(S.sweeps, retired[c.idx]);
     HIP_CHECK(hipStreamSynchronize(c.stream));  // drains the surplus (empty) sweep ...
     while (retired[c.idx] < queued[c.idx]) {    // ... whose launches still count as launches (they are in any profile)
-      const int act = c.active;
-      c.active = 0;  // no units processed
+      const int act = c.active, lin = c.lin;
+      c.active = c.lin = 0;  // no units processed
       retire(c);
       c.active = act;
+      c.lin = lin;
     }
   }
   for (int c = 1; c < nchunks; ++c) HIP_CHECK(hipStreamSynchronize(chunks[c].stream));
@@ -840,10 +849,16 @@ int empc_solver_stream_begin(EmpcSolver* s, int n_jobs, const double* x0s) {
   if (!s || !x0s) throw std::invalid_argument("NULL argument");
   if (n_jobs < 1) throw std::invalid_argument("stream: n_jobs must be >= 1");
   s->use();
-  if (s->dq_x0) HIP_CHECK(hipFree(s->dq_x0));
-  if (s->dq_rows) HIP_CHECK(hipFree(s->dq_rows));
-  s->dq_x0 = s->dq_rows = nullptr;
+  // (each pointer is forgotten before anything else can throw: the destructor frees what is still set)
   s->q_njobs = 0;
+  if (double* p = s->dq_x0) {
+    s->dq_x0 = nullptr;
+    HIP_CHECK(hipFree(p));
+  }
+  if (double* p = s->dq_rows) {
+    s->dq_rows = nullptr;
+    HIP_CHECK(hipFree(p));
+  }
   if (!s->dq_head) {
     HIP_CHECK(hipMalloc((void**)&s->dq_head, 16));
     s->dq_iters = reinterpret_cast<unsigned long long*>(s->dq_head + 2);
@@ -862,7 +877,6 @@ int empc_solver_stream_run(EmpcSolver* s, int maxiter) {
   if (!s) throw std::invalid_argument("solver is NULL");
   if (maxiter < 1) throw std::invalid_argument("maxiter must be >= 1");
   if (s->q_njobs < 1) throw std::invalid_argument("stream: call empc_solver_stream_begin first");
-  if (s->D.trace) throw std::invalid_argument("stream: the iteration trace belongs to plain solves (switch it off first)");
   s->use();
   flush_problem(s);
   // the first jobs go to the slots directly: setCandidate([], []) + problem.x0 of the job
@@ -880,6 +894,8 @@ int empc_solver_stream_run(EmpcSolver* s, int maxiter) {
   HIP_CHECK(hipMemcpyAsync(s->dq_head, &nfirst, sizeof(int), hipMemcpyHostToDevice, s->stream));
   HIP_CHECK(hipStreamSynchronize(s->stream));
   const DevBuffers keep = s->D;
+  s->D.trace = nullptr;  // the iteration trace (callbacks of the mirrors) records plain solves: a slot of a stream works
+  s->D.trace_cap = 0;    // on many jobs in a row; it is switched off for the duration of the stream and back on after
   s->D.q_x0 = s->dq_x0;
   s->D.q_rows = s->dq_rows;
   s->D.q_head = s->dq_head;
@@ -898,6 +914,9 @@ int empc_solver_stream_run(EmpcSolver* s, int maxiter) {
   unsigned long long it = 0;
   HIP_CHECK(hipMemcpy(&it, s->dq_iters, sizeof(it), hipMemcpyDeviceToHost));
   s->stats.total_iters = (long long)it;
+  int mx = 0;  // largest iteration count of any JOB (select keeps it next to the queue head), not of the slots' last jobs
+  HIP_CHECK(hipMemcpy(&mx, s->dq_head + 1, sizeof(mx), hipMemcpyDeviceToHost));
+  s->stats.max_iters = mx;
   s->have_state = false;  // the slots hold the last jobs they worked on, not one solve of the batch
   return EMPC_OK;
   EMPC_CATCH(RET_INT)

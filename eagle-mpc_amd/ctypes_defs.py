@@ -103,7 +103,8 @@ class SolveStats(C.Structure):
         ("backward_units", C.c_longlong),
         ("ms_total", d), ("ms_linearize", d), ("ms_backward", d), ("ms_rollout", d), ("ms_select", d), ("ms_calc", d),
         ("n_linearize", C.c_int), ("n_backward", C.c_int), ("n_rollout", C.c_int), ("n_select", C.c_int),
-        ("n_calc", C.c_int),
+        ("n_calc", C.c_int), ("timing_every", C.c_int),
+        ("linearize_units_all", C.c_longlong), ("rollout_units_all", C.c_longlong), ("backward_units_all", C.c_longlong),
     ]
 
 

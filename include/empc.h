@@ -138,6 +138,9 @@ typedef struct EmpcSolveStats {
    * stream time.  n_* and *_units count the same timed launches, so ms / n and units / n are per-launch averages. */
   double ms_linearize, ms_backward, ms_rollout, ms_select, ms_calc;
   int n_linearize, n_backward, n_rollout, n_select, n_calc;
+  int timing_every;           /* the sampling stride of the event-timed sweeps of this solve (1 for the phase-level calls) */
+  /* units of EVERY sweep of the solve, timed or not: the total work (the *_units above cover the timed launches only) */
+  long long linearize_units_all, rollout_units_all, backward_units_all;
 } EmpcSolveStats;
 int empc_solver_get_stats(EmpcSolver* s, EmpcSolveStats* stats);
 /* diagnostic builds only (-DEMPC_STAMPS): in-kernel cycle stamps of the backward kernel, trajectory 0 */

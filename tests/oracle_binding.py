@@ -31,6 +31,19 @@ def orc(variant=None):
     """the oracle library; variant="fma" loads the same sources built with FMA contraction (the rounding-noise yardstick of
     the teacher-forced tests, never the reference value)"""
     global _orc
+    if variant == "native":
+        # -O3 -march=native build for the TIMED cpu baseline only (oracle/Makefile): compiled on the machine it runs on
+        if variant not in _orc_variants:
+            path = os.path.join(ORACLE_DIR, "liboracle_native.so")
+            try:
+                here = [l for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+            except (OSError, IndexError):
+                here = "unknown\n"
+            stamp = os.path.join(ORACLE_DIR, "liboracle_native.cpu")
+            if not os.path.exists(path) or not os.path.exists(stamp) or open(stamp).read() != here:
+                subprocess.check_call(["make", "-C", ORACLE_DIR, "-s", "-B", "native"])
+            _orc_variants[variant] = _bind(C.CDLL(path))
+        return _orc_variants[variant]
     if variant is not None:
         if variant not in _orc_variants:
             path = os.path.join(ORACLE_DIR, "liboracle_%s.so" % variant)
@@ -275,7 +288,7 @@ class OracleSolver:
         return bool(ok), xs, us, c.value, d01
 
 
-def solve_batch(desc, x0s, maxiter=100, nthreads=1, params=None, want_traj=True):
+def solve_batch(desc, x0s, maxiter=100, nthreads=1, params=None, want_traj=True, variant=None):
     prm = params if params is not None else default_params()
     x0s = np.ascontiguousarray(x0s, dtype=np.float64)
     B = x0s.shape[0]
@@ -286,7 +299,7 @@ def solve_batch(desc, x0s, maxiter=100, nthreads=1, params=None, want_traj=True)
     cost = np.zeros(B)
     iters = np.zeros(B, dtype=np.int32)
     status = np.zeros(B, dtype=np.int32)
-    secs = orc().oracle_solve_batch(C.byref(desc), C.byref(prm), B, P(x0s), int(maxiter), int(nthreads), P(xs), P(us), P(usq),
+    secs = orc(variant).oracle_solve_batch(C.byref(desc), C.byref(prm), B, P(x0s), int(maxiter), int(nthreads), P(xs), P(us), P(usq),
                                     P(cost), iters.ctypes.data_as(_ip), status.ctypes.data_as(_ip))
     return dict(xs=xs, us=us, us_squash=usq, cost=cost, iter=iters, status=status, seconds=secs)
 

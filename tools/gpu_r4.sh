@@ -47,6 +47,28 @@ case "$MODE" in
       bench_line "${cfg}_generic" "EMPC_BAKED=0" --config $cfg --no-cpu-baseline --no-secondary --steps 10
     done
     ;;
+  profiles)
+    # what is kept under profiles/r04_*: the bench line, the rocprofv3 kernel-trace summary of the same command and four
+    # --pmc passes (HBM reads, HBM writes, FP64 instruction mix, wavefront activity) over a short stream run
+    export TMPDIR=/tmp
+    O="$ROOT/gpurun_out/${TAG}_prof"; rm -rf "$O"; mkdir -p "$O"
+    for CFG in ${CONFIGS:-eagle_catch displacement push_slide}; do
+      T=$(python3 -c "import bench, empc_loader as l; e = l.load(); r, dt = bench.CONFIGS['$CFG']; t = e.Trajectory(); t.autoSetup(e.yaml_path(r)); print(t.createProblem(dt, True, 'IntegratedActionModelEuler').T)")
+      STEPS=20; [ "$CFG" = push_slide ] && STEPS=5
+      timeout 900 python3 bench.py --config $CFG --steps $STEPS --warmup 1 --no-secondary > $O/bench_$CFG.json 2> $O/bench_$CFG.err; echo "bench $CFG rc $?"
+      tail -c 400 $O/bench_$CFG.json; echo
+      ARGS="--config $CFG --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-single-batch"
+      rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$CFG -- python3 bench.py $ARGS > $O/bench_under_rocprof_$CFG.json 2> $O/stats_$CFG.err
+      python3 tools/profile_summarize.py stats $O/stats_$CFG $O/kernel_stats_$CFG.csv | head -12
+      PARGS="--config $CFG --steps 2 --warmup 0 --no-cpu-baseline --no-secondary --no-single-batch"
+      rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/p_fetch_$CFG -- python3 bench.py $PARGS > /dev/null 2> $O/p_fetch_$CFG.err
+      rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/p_write_$CFG -- python3 bench.py $PARGS > /dev/null 2> $O/p_write_$CFG.err
+      rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES --output-format csv -d $O/p_fp64_$CFG -- python3 bench.py $PARGS > /dev/null 2> $O/p_fp64_$CFG.err
+      rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_ANY --output-format csv -d $O/p_act_$CFG -- python3 bench.py $PARGS > /dev/null 2> $O/p_act_$CFG.err
+      python3 tools/profile_summarize.py pmc $CFG $O/pmc_$CFG.json 1024 $T 10 $O/p_fetch_$CFG $O/p_write_$CFG $O/p_fp64_$CFG $O/p_act_$CFG | cut -c1-1500
+    done
+    find $O -name "*.csv" -size +1M -delete; find $O -name "*.db" -delete; du -sh $O
+    ;;
   stamps)
     # phase-level launches: product library first (ms per launch), then the diagnostic build with in-kernel cycle stamps
     for c in displacement eagle_catch; do

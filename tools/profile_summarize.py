@@ -3,6 +3,7 @@
 
   python tools/profile_summarize.py stats   <rocprof dir> <out.csv>          # --kernel-trace --stats run
   python tools/profile_summarize.py traffic <fetch dir> <write dir> <tag> [config]  # two --pmc passes (FETCH_SIZE / WRITE_SIZE)
+  python tools/profile_summarize.py pmc <config> <out.json> <B> <T> <NA> <pass dir> ...  # round 4: FULL-BATCH launches only
 
 `traffic` writes profiles/traffic_<config>_<kernel>.json per hot kernel: HBM bytes per launch as /opt/skills/guides/
 MI355X_MICROARCH.md prescribes -- FETCH_SIZE and WRITE_SIZE are reported in KiB-sized units by rocprofv3 (x1024) and, on
@@ -114,8 +115,74 @@ def sq(dirs, out):
         print(k, {c: (("%.4g" % t[c]) if isinstance(t[c], float) else t[c]) for c in cols if c in t})
 
 
+def pmc(config, out, B, T, NA, dirs):
+    """profiles/r04_pmc_<config>.json: per hot kernel, means over the launches whose grid is the FULL batch (a stream run keeps
+    the slots full until its queue is dry; the drain sweeps at the end have smaller grids and are left out):
+      hbm_bytes_per_launch   2 x FETCH_SIZE x 1024 + WRITE_SIZE x 1024 (MI355X_MICROARCH.md, HBM section: gfx950 tallies 128-B
+                             read requests at 64 B; 8-B-per-lane accesses are outside the guide's calibrated pattern)
+      fp64_flop_per_launch   64 lanes x (ADD_F64 + MUL_F64 + TRANS_F64 + 2 FMA_F64) + 512 x MFMA_MOPS_F64: flops ISSUED, idle
+                             lanes included -- what the FP64 pipes were asked to do
+      valu_active_frac       SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES (both in quad-cycles): share of a wavefront's life with a
+                             vector instruction in execution; wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES
+    linearize = lean launch + full-body launch of one sweep (whichever exist)."""
+    rows = collections.defaultdict(lambda: collections.defaultdict(list))  # kernel -> counter -> values of full-grid launches
+    grids = collections.defaultdict(int)
+    recs = []
+    for d in dirs:
+        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        if not files:
+            print("no counter_collection.csv under", d)
+            continue
+        for r in csv.DictReader(open(max(files, key=os.path.getmtime))):
+            k = short(r["Kernel_Name"])
+            if k not in ("k_linearize", "k_linearize_full", "k_backward", "k_rollout"):
+                continue
+            g = int(r["Grid_Size"])
+            grids[k] = max(grids[k], g)
+            recs.append((k, g, r["Counter_Name"], float(r["Counter_Value"])))
+    for k, g, c, v in recs:
+        if g == grids[k]:
+            rows[k][c].append(v)
+    mean = lambda k, c: (sum(rows[k][c]) / len(rows[k][c])) if rows[k].get(c) else None
+    units = {"linearize": B * (T + 1), "backward": B * T, "rollout": B * NA * (T + 1)}
+    res = {"config": config, "B": B, "T": T, "NA": NA, "kernels": {},
+           "method": "rocprofv3 --kernel-trace --pmc <one counter group per pass> over `bench.py --mode stream`; launches with the full grid only"}
+    groups = {"linearize": [k for k in ("k_linearize", "k_linearize_full") if k in rows], "backward": ["k_backward"], "rollout": ["k_rollout"]}
+    for name, ks in groups.items():
+        ks = [k for k in ks if k in rows]
+        if not ks:
+            continue
+        tot = lambda c: (sum(mean(k, c) for k in ks) if all(mean(k, c) is not None for k in ks) else None)
+        e = {"launch_kinds": ks, "grid_sizes": {k: grids[k] for k in ks}, "units_per_launch": units[name],
+             "full_launches_seen": {k: max([len(v) for v in rows[k].values()] or [0]) for k in ks}}
+        f, w = tot("FETCH_SIZE"), tot("WRITE_SIZE")
+        if f is not None and w is not None:
+            e.update(fetch_raw_bytes=f * 1024.0, write_raw_bytes=w * 1024.0, hbm_bytes_per_launch=2.0 * f * 1024.0 + w * 1024.0)
+        a, m_, t_, fm, mo = (tot("SQ_INSTS_VALU_ADD_F64"), tot("SQ_INSTS_VALU_MUL_F64"), tot("SQ_INSTS_VALU_TRANS_F64"),
+                             tot("SQ_INSTS_VALU_FMA_F64"), tot("SQ_INSTS_VALU_MFMA_MOPS_F64"))
+        if None not in (a, m_, t_, fm):
+            e["fp64_insts_per_launch"] = {"add": a, "mul": m_, "trans": t_, "fma": fm, "mfma_mops": mo, "valu_all": tot("SQ_INSTS_VALU"),
+                                          "salu": tot("SQ_INSTS_SALU"), "waves": tot("SQ_WAVES")}
+            e["fp64_flop_per_launch"] = 64.0 * (a + m_ + t_ + 2.0 * fm) + 512.0 * (mo or 0.0)
+        wc = tot("SQ_WAVE_CYCLES")
+        if wc:
+            e["valu_active_frac"] = (tot("SQ_ACTIVE_INST_VALU") or 0.0) / wc
+            e["wait_frac"] = (tot("SQ_WAIT_ANY") or 0.0) / wc
+            e["issue_stall_frac"] = (tot("SQ_WAIT_INST_ANY") or 0.0) / wc
+            e["sq_busy_cycles"] = tot("SQ_BUSY_CYCLES")
+            e["wave_quad_cycles"] = wc
+            e["lds_insts"] = tot("SQ_INSTS_LDS")
+            e["lds_bank_conflict_cycles"] = tot("SQ_LDS_BANK_CONFLICT")
+        res["kernels"][name] = e
+    with open(out, "w") as fjs:
+        json.dump(res, fjs, indent=1)
+    print(json.dumps(res)[:3000])
+
+
 if __name__ == "__main__":
-    if len(sys.argv) >= 4 and sys.argv[1] == "sq":
+    if len(sys.argv) >= 8 and sys.argv[1] == "pmc":
+        pmc(sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), sys.argv[7:])
+    elif len(sys.argv) >= 4 and sys.argv[1] == "sq":
         sq(sys.argv[3:], sys.argv[2])
     elif len(sys.argv) >= 4 and sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
