@@ -37,6 +37,7 @@ TOL_COST = 1e-9
 # FMA-contracted build on that very trial)
 NOISE_FACTOR = 100.0
 CHAOTIC = 1e-4
+PREFIX_SPLIT = 1e-6  # an accepted chaotic trial is compared knot by knot up to where the oracle's own variants part by this much
 FAR_TRIAL = 100.0   # a rejected trial this many times costlier than the iterate ...
 TOL_COST_FAR = 1e-6  # ... is compared at this relative tolerance
 BLOWN_UP = 1e3       # positions / joint angles / rates beyond this (3 is normal) ...
@@ -338,6 +339,10 @@ def teacher_forced(backend_factory, desc, prm, x0s, paths, maxiter=100, chunk=10
                     step_noise = {key: max(abs(ra[key] - rb[key]) for rb, _ in res[1:]) for key in ("stop", "dV", "dVexp", "cost")}
                     step_noise["xs"] = max(float(np.abs(xa["xs"] - xb["xs"]).max() / (1.0 + np.abs(xa["xs"]).max())) for _, xb in res[1:])
                     step_noise["us"] = max(float(np.abs(xa["us"] - xb["us"]).max() / (1.0 + np.abs(xa["us"]).max())) for _, xb in res[1:])
+                    # knot by knot: how far the oracle's own variants lie apart on the accepted candidate (a rollout that is
+                    # about to blow up agrees to rounding over its first knots and parts ways exponentially after)
+                    step_noise["xs_knot"] = np.max([np.abs(xa["xs"] - xb["xs"]).max(axis=1) for _, xb in res[1:]], axis=0)
+                    step_noise["us_knot"] = np.max([np.abs(xa["us"] - xb["us"]).max(axis=1) for _, xb in res[1:]], axis=0)
             ref_tape = ref_gains = None
             if j in want_tape and p["direction_ok"]:
                 ref_tape = [o.phase_tape(t) for t in range(desc.T + 1)]
@@ -353,7 +358,7 @@ def teacher_forced(backend_factory, desc, prm, x0s, paths, maxiter=100, chunk=10
         for j, ((b, i), it) in enumerate(zip(sub, its)):
             ddp = it["phase"] == T.PHASE_DDP
             p, pv, ref_tape, ref_gains, sn = oracle[j]
-            sn = sn or dict(stop=np.inf, dV=np.inf, dVexp=np.inf, cost=np.inf, xs=np.inf, us=np.inf)  # the builds disagree on the step: no value bound
+            sn = sn or dict(stop=np.inf, dV=np.inf, dVexp=np.inf, cost=np.inf, xs=np.inf, us=np.inf, xs_knot=None, us_knot=None)  # the builds disagree on the step: no value bound
             pf = pv[0]
             pu = pv[1:]
             g = mid[j]
@@ -549,6 +554,28 @@ def teacher_forced(backend_factory, desc, prm, x0s, paths, maxiter=100, chunk=10
                 upd("xs_next", ex_)
                 upd("us_next", eu_)
                 assert ex_ <= max(1e-7 * amp, NOISE_FACTOR * sn["xs"]) and eu_ <= max(1e-7 * amp, NOISE_FACTOR * sn["us"]), (where, amp, ex_, eu_, sn)
+                if not np.isfinite(amp) and sn.get("xs_knot") is not None:
+                    # the accepted trial is one the oracle's builds differ on by more than CHAOTIC: its cost carries no bound,
+                    # but the candidate itself is comparable knot by knot up to the knot where the oracle's own variants part by
+                    # more than PREFIX_SPLIT -- that prefix is held to max(1e-9, NOISE_FACTOR x the variants' distance there)
+                    kx, ku = sn["xs_knot"], sn["us_knot"]
+                    split = np.nonzero(kx > PREFIX_SPLIT)[0]
+                    upto = int(split[0]) if len(split) else len(kx)
+                    if upto > 0:
+                        tx = np.maximum(1e-9 * (1.0 + np.abs(nxt["xs"][:upto]).max(axis=1)), NOISE_FACTOR * kx[:upto])
+                        exk = np.abs(xs_new[j][:upto] - nxt["xs"][:upto]).max(axis=1)
+                        assert (exk <= tx).all(), (where, "prefix xs", upto, exk.max(), tx.min())
+                        nu_ = min(upto, len(ku))
+                        if nu_ > 0:
+                            tu = np.maximum(1e-9 * (1.0 + np.abs(nxt["us"][:nu_]).max(axis=1)), NOISE_FACTOR * ku[:nu_])
+                            euk = np.abs(us_new[j][:nu_] - nxt["us"][:nu_]).max(axis=1)
+                            assert (euk <= tu).all(), (where, "prefix us", nu_, euk.max(), tu.min())
+                        rep["accepted_chaotic_prefix_checked"] = rep.get("accepted_chaotic_prefix_checked", 0) + 1
+                        rep["accepted_chaotic_prefix_knots"] = rep.get("accepted_chaotic_prefix_knots", 0) + upto
+                    else:
+                        rep["accepted_chaotic_no_prefix"] = rep.get("accepted_chaotic_no_prefix", 0) + 1
+                elif not np.isfinite(amp):
+                    rep["accepted_chaotic_variants_disagree_on_step"] = rep.get("accepted_chaotic_variants_disagree_on_step", 0) + 1
                 upd("amplification", amp)
             rep["decisions_checked"] += 1
             # margins of the inequalities that decided this iteration (for the near-tie study)

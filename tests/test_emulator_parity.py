@@ -313,7 +313,13 @@ def test_rk4_kernel_bodies_vs_oracle(empc, emu, name, dt):
     # (states equal to 2e-9 while that control differs by 1.4e-4 after 20 iterations; the matrix-core sums of the RK4 assembly
     # are ordered differently from the oracle's): the decisive statement for RK4 nodes is the step-wise one, every iteration
     # reproduced from the other side's iterate and the same minimiser to 5e-8 on us (tests/test_gpu_teacher_forced.py::test_rk4_nodes)
-    assert np.abs(xs_e - r["xs"]).max() < 1e-6 and np.abs(us_e - r["us"]).max() < 1e-3
+    assert np.abs(xs_e - r["xs"]).max() < 1e-6
+    # controls: the north-star 1e-4 everywhere except on that flat direction -- the controls of at most ONE knot may exceed it
+    # (measured: knot 75, four rotor commands, 1.5e-4), and stay within 3e-4; everywhere else 1e-4
+    du = np.abs(us_e - r["us"])
+    knots = np.unique(np.argwhere(du >= 1e-4)[:, 0])
+    print("RK4 solve: max |us - oracle|", du.max(), "entries beyond 1e-4:", int((du >= 1e-4).sum()), "at knots", knots)
+    assert len(knots) <= 1 and du.max() < 3e-4, (knots, du.max())
     emu.emu_destroy(e)
 
 

@@ -47,6 +47,22 @@ def test_eagle_catch_perturbed_batch_256(empc, problems):
     assert np.abs(gpu["xs"][0] - ref["xs"][0]).max() < 1e-4 and np.abs(gpu["us"][0] - ref["us"][0]).max() < 1e-4
     # nothing blows up on the rollouts neither side solves
     assert np.isfinite(gpu["xs"]).all() and np.isfinite(gpu["us"]).all()
+    # Tripwires on the free-running batch.  The step-wise suite carries the parity claim; these catch a DRIFT of the free-running
+    # behaviour that a harness with excuse paths could let through.  Yardstick: the oracle against its own FMA-contracted build
+    # on the same batch -- two correct implementations of one source.
+    d_ = problem.desc
+    fma = ob.solve_batch(d_, empc.perturbed_x0s(problem.x0, B, nq=d_.model.nq), 100, nthreads=min(os.cpu_count() or 1, 64), variant="fma")
+    floor = pc.batch_statistics(dict(xs=fma["xs"], us=fma["us"], cost=fma["cost"], iter=fma["iter"], status=fma["status"]), ref)
+    print("oracle vs its FMA build on the same batch:", floor)
+    # (a) agreement with the oracle no worse than the oracle's agreement with itself, minus a margin
+    assert stats["agreement_rate_among_oracle_solved"] >= floor["agreement_rate_among_oracle_solved"] - 0.12, (stats, floor)
+    # (b) as many rollouts solved as the oracle solves, within 5 % of the batch
+    assert abs(stats["solved_by_gpu"] - stats["solved_by_oracle"]) <= 0.05 * B, stats
+    # (c) where both converge the costs agree: median relative difference <= 1e-6
+    assert stats["cost_rel_err_median_solved_by_both"] <= 1e-6, stats
+    # (d) stationarity of the points the GPU calls converged: the next step's expected reduction stays below the bound the
+    #     stopping test implies (criterion E of round 2)
+    assert smp["expected_reduction_next_step_gpu_max"] <= smp["expected_reduction_bound"], smp
 
 
 def test_eagle_catch_batch_independence(empc, problems):

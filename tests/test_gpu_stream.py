@@ -39,10 +39,15 @@ def test_stream_argument_errors(empc, problems):
     s = empc.SolverSbFDDP(problem, batch=2)
     with pytest.raises(empc.EmpcError, match="stream_begin"):
         s.stream_run(10)
+    # an enabled iteration trace (what setCallbacks switches on) is no obstacle: it records plain solves and is off for the
+    # duration of a stream, back on afterwards
     s.enable_trace(8)
-    s.stream_begin(np.tile(problem.x0, (3, 1)))
-    with pytest.raises(empc.EmpcError, match="trace"):
-        s.stream_run(10)
+    r = s.solve_stream(np.tile(problem.x0, (3, 1)), 10)
+    plain = empc.SolverSbFDDP(problem, batch=1)
+    plain.solve([], [], 10)
+    assert np.array_equal(r["xs"][2], plain.xs_batch[0]) and r["iter"][0] == plain.iter_batch[0]
+    s.solve([], [], 10)
+    assert len(s.trace(0)) == min(8, s.iter_batch[0] + 1)
 
 
 @pytest.mark.parametrize("variant", ["SolverBoxFDDP", "SolverBoxDDP", "RK4"])

@@ -34,15 +34,35 @@ def factory(empc, problem, prm, cls=None):
 def save(name, rep):
     try:
         os.makedirs(OUT, exist_ok=True)
-        with open(os.path.join(OUT, "r03_stepwise_%s.json" % name), "w") as f:
+        with open(os.path.join(OUT, "r04_stepwise_%s.json" % name), "w") as f:
             json.dump(rep, f, indent=1, default=lambda o: o.tolist() if hasattr(o, "tolist") else str(o))
+        print("stepwise %s: waived %.3f (free run %.3f), accepted chaotic trials %d of which prefix-checked %d" % (
+            name, rep.get("waived_fraction", -1), rep["free_run"].get("waived_fraction", -1), rep.get("accepted_trials_chaotic", 0),
+            rep.get("accepted_chaotic_prefix_checked", 0)))
     except OSError:
         pass
 
 
-def check(rep):
+def waived_fraction(rep):
+    """Share of the teacher-forced iterations that carry NO numerical assertion on the step they took: decisions excused as
+    chaotic / tied / direction ties, iterates skipped as exploded, and accepted chaotic trials for which not even a knot prefix
+    could be compared.  An accepted chaotic trial whose candidate was compared knot by knot up to the split of the oracle's own
+    variants (tests/stepwise.py, PREFIX_SPLIT) counts as checked."""
+    waived = (rep.get("decisions_excused_chaotic", 0) + rep.get("decisions_excused_tied", 0) + rep.get("direction_ties_excused", 0) +
+              rep.get("iterates_skipped_exploded", 0) + rep.get("accepted_chaotic_no_prefix", 0) +
+              rep.get("accepted_chaotic_variants_disagree_on_step", 0))
+    return waived / max(rep["decisions_checked"], 1)
+
+
+def check(rep, max_waived=0.10):
+    """every pair went through the comparison, nothing unexplained in the reverse direction, and the waivers stay a bounded
+    minority (a collapse of the harness into 'everything excused' fails here)"""
     assert rep["decisions_checked"] == rep["pairs"] > 0
     assert rep["free_run"]["unexplained"] == 0
+    rep["waived_fraction"] = waived_fraction(rep)
+    fr = rep["free_run"]
+    rep["free_run"]["waived_fraction"] = (fr["excused_chaotic_or_tied"] + fr["skipped_exploded_iterates"]) / max(fr["device_iterations"], 1)
+    assert rep["waived_fraction"] <= max_waived, (rep["waived_fraction"], max_waived)
 
 
 def test_eagle_catch_perturbed_64(empc, problems):
@@ -51,10 +71,10 @@ def test_eagle_catch_perturbed_64(empc, problems):
     d = problem.desc
     prm = ob.default_params()
     x0s = empc.perturbed_x0s(problem.x0, 64, nq=d.model.nq)
-    rep = sw.stepwise_parity(factory(empc, problem, prm), d, prm, x0s, chunk=1024, tape_every=53)
+    rep = sw.stepwise_parity(factory(empc, problem, prm), d, prm, x0s, chunk=1024, tape_every=11)
+    check(rep, max_waived=0.10)
     save("eagle_catch_64", rep)
-    check(rep)
-    assert rep["pairs"] > 2000 and rep["tapes_checked"] > 30
+    assert rep["pairs"] > 2000 and rep["tapes_checked"] > 250
 
 
 def test_select_alone_on_gpu(empc, problems):
@@ -77,8 +97,10 @@ def test_contact_options(empc, tmp_path, contact, gains):
     x0s = empc.perturbed_x0s(problem.x0, 6, nq=d.model.nq, amplitude=0.02)
     x0s[0] = problem.x0
     rep = sw.stepwise_parity(factory(empc, problem, prm), d, prm, x0s, tape_every=41)
-    save("contact_%s_%g" % (contact, gains[0]), rep)
-    check(rep)
+    try:
+        check(rep, max_waived=0.15)
+    finally:
+        save("contact_%s_%g" % (contact, gains[0]), rep)
 
 
 @pytest.mark.parametrize("name,dt,solver_type", [("hover", 40, 1), ("hover", 40, 2), ("eagle_catch", 32, 1), ("eagle_catch", 32, 2), ("displacement", 80, 2)])
@@ -92,8 +114,12 @@ def test_box_solvers(empc, name, dt, solver_type):
     cls = {1: empc.SolverBoxFDDP, 2: empc.SolverBoxDDP}[solver_type]
     x0s = empc.perturbed_x0s(problem.x0, 8, nq=d.model.nq)
     rep = sw.stepwise_parity(factory(empc, problem, prm, cls), d, prm, x0s, maxiter=30, tape_every=29, do_same_minimum=False)
-    save("box_%s_%d" % (name, solver_type), rep)
-    check(rep)
+    try:
+        # (cold starts of the box solvers: a third of the accepted steps are rollouts the oracle's own builds differ on by more
+        #  than 1e-4; their candidates are compared knot by knot up to the split, which turns most of them into checked steps)
+        check(rep, max_waived=0.25)
+    finally:
+        save("box_%s_%d" % (name, solver_type), rep)
 
 
 @pytest.mark.parametrize("name", ["eagle_catch", "displacement"])
@@ -105,8 +131,10 @@ def test_rk4_nodes(empc, problems, name):
     x0s = empc.perturbed_x0s(problem.x0, 4, nq=d.model.nq, amplitude=0.02)
     # (tape at 1e-8: the RK4 node's Lu is a sum of four stage terms on Hessians of 1e9; measured 5e-9)
     rep = sw.stepwise_parity(factory(empc, problem, prm), d, prm, x0s, tape_every=31, tol_tape=1e-8)
-    save("rk4_" + name, rep)
-    check(rep)
+    try:
+        check(rep, max_waived=0.10)
+    finally:
+        save("rk4_" + name, rep)
 
 
 @pytest.mark.parametrize("rel", ["iris/trajectories/loop.yaml", "iris_px4/trajectories/hover.yaml", "hexacopter370/trajectories/hover.yaml"])
@@ -126,5 +154,9 @@ def test_long_running_shipped_files(empc, rel):
     # digit; common restart at 1e-12: iris_px4/hover's valley is flat (cost equal to 1e-9 still leaves xs 4e-4 apart)
     rep = sw.stepwise_parity(factory(empc, problem, prm), d, prm, x0s, tape_every=43, do_same_minimum="hover" in rel,
                              tol_tape=1e-8, tight=1e-12)
-    save(rel.replace("/", "_").replace(".yaml", ""), rep)
-    check(rep)
+    try:
+        # (perturbed hovers: most rollouts explode in their first iteration on both sides -- DESIGN.md, divergence study -- and
+        #  iterate on at costs of 1e13: those iterates are skipped as exploded)
+        check(rep, max_waived=0.70 if "hexacopter370" in rel else 0.15)
+    finally:
+        save(rel.replace("/", "_").replace(".yaml", ""), rep)
