@@ -226,7 +226,7 @@ def test_rk4_integrator_on_gpu(empc, name, dt, B):
             import stepwise as sw
             from test_gpu_teacher_forced import check, factory
             prm = ob.default_params()
-            check(sw.stepwise_parity(factory(empc, problem, prm), d, prm, x0p, tape_every=29, do_same_minimum=False))
+            check(sw.stepwise_parity(factory(empc, problem, prm), d, prm, x0p, tape_every=29, do_same_minimum=False), max_waived=0.3)
         return
     assert np.array_equal(s.iter_batch, r["iter"]) and np.array_equal(s.status_batch, r["status"]), (s.iter_batch, r["iter"])
     # states to the north-star bound.  The controls of the RK4 displacement problem sit on Hessians of 1e9: two free runs end
@@ -354,7 +354,10 @@ def test_shortest_horizons_and_single_iterations(empc, name, dt):
             import stepwise as sw
             from test_gpu_teacher_forced import check, factory
             prm = ob.default_params()
-            check(sw.stepwise_parity(factory(empc, problem, prm), d, prm, np.array([problem.x0]), tape_every=17, do_same_minimum=False))
+            # (knots of 0.64 s: nearly half of this path's iterates have exploded on both sides and are only required to stay
+            #  finite -- the bound on the waived share is loose here on purpose)
+            check(sw.stepwise_parity(factory(empc, problem, prm), d, prm, np.array([problem.x0]), tape_every=17, do_same_minimum=False),
+                  max_waived=0.6)
             continue
         assert s.iter == r["iter"] and s.status_batch[0] == r["status"], (name, maxiter, s.iter, r["iter"])
         if maxiter == 100:
