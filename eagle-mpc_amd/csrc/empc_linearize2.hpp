@@ -50,7 +50,7 @@ struct Lin2Smem {
   // Jc nc x NV | M^-1 Jc^T NV x nc | packed G nc (nc + 1) / 2.  The nc-dependent part comes last, so a unit of the 3D
   // instantiation is no larger than it has to be (units per CU are LDS-bound in the contact problem)
   static constexpr int OFF_LAM = OFF_RED + 16;
-  static_assert(NU + 1 <= 16, "reduction area");
+  static_assert(NU + 1 <= 12, "reduction area: cost sum | control-cost partial sums | [12..14] flags of the unit for the role lanes");
   static constexpr int OFF_FEXT = OFF_LAM + 6;
   static constexpr int OFF_CONE = OFF_FEXT + 6;
   static constexpr int OFF_JC = OFF_CONE + 26;
@@ -428,6 +428,15 @@ EMPC_HD void lin2_frame_jcol(const MT& m, const double* N, int j, int bf, const 
   do {               \
   } while (0)
 #endif
+// scheduling fence: a block of LDS reads stays ahead of the arithmetic that consumes it (without it the compiler pairs every
+// read with its own wait: one exposed LDS round trip per operand)
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+#define LIN_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define LIN_FENCE() \
+  do {              \
+  } while (0)
+#endif
 // FR: this instantiation handles the units whose cost set captures operational frames (frame costs or a contact);
 // FR = false is the lean body for all other units -- the frame Jacobian / velocity-derivative columns (72 registers per
 // lane) do not exist in it.  The kernel is launched once per flavour; a unit returns at once from the wrong one
@@ -550,7 +559,8 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
       for (int i = 0; i < 6; ++i) F[12 + i] = fv[i];
     }
   };
-  auto euler_section = [&](double* Nu, int bu, bool feasu) {
+  // Euler step and its Lie Jacobians (J1, J2), next state
+  auto euler_section = [&](double* Nu) {
     double x[NX], dxe[NDX], xnext[NX], pe[3], J2[36];
 #pragma unroll
     for (int i = 0; i < NX; ++i) x[i] = Nu[SM::OFF_X + i];
@@ -583,11 +593,24 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
     for (int i = 0; i < NDX; ++i) Nu[SM::OFF_DXE + i] = dxe[i];
 #pragma unroll
     for (int i = 0; i < NX; ++i) Nu[SM::OFF_XN + i] = xnext[i];
-    // gaps: fs[t+1] = xnext (-) xs[t+1];  fs[0] = x0 (-) xs[0]
+  };
+  // gaps: fs[t+1] = xnext (-) xs[t+1];  fs[0] = x0 (-) xs[0].  Its own section (its own wavefront in the role phase): it takes
+  // the Euler step again -- the same operations, the same xnext -- instead of waiting for the Jacobian section's
+  auto gap_section = [&](double* Nu, int bu, bool feasu) {
+    double x[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x[i] = Nu[SM::OFF_X + i];
     if (!terminal) {
       double gap[NDX];
       if (!feasu) {
-        double xn[NX];
+        double dxe[NDX], xnext[NX], xn[NX];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          const double ai = Nu[SM::OFF_A + i];
+          dxe[i] = x[NQ + i] * dt + ai * dt * dt;
+          dxe[NV + i] = ai * dt;
+        }
+        state_integrate<DM>(x, dxe, xnext, nullptr);
 #pragma unroll
         for (int i = 0; i < NX; ++i) xn[i] = Nu[SM::OFF_GAP + i];  // staged at S0
         state_diff<DM>(xn, xnext, gap, nullptr);
@@ -621,16 +644,23 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
   auto role_phase = [&]() {
     if constexpr (RW > 0) {
       const int wv = RL->tid / 64, wl = RL->tid % 64;
-      auto traj = [&](int u) { return RL->list ? RL->list[RL->b0 + u] : RL->b0 + u; };
-      auto live = [&](int u) {
-        if (u >= RL->upb || RL->b0 + u >= RL->n) return false;
-        const TrajState& su = D.st[traj(u)];
-        return su.phase != PHASE_DONE && su.need_lin != 0;
-      };
+      // what a role lane needs to know about ITS unit (does it have work, is its trajectory feasible, which trajectory is
+      // it) was left in the unit's LDS block by the unit's own lane 0 before the barrier: no dependent global loads
+      // (list entry -> trajectory state) at the head of the phase
+      auto flagp = [&](int u) { return RL->base + (size_t)u * RL->usz + SM::OFF_RED + 12; };
+      auto traj = [&](int u) { return (int)flagp(u)[2]; };
+      auto live = [&](int u) { return u < RL->upb && flagp(u)[0] != 0.0; };
+      auto feasible = [&](int u) { return flagp(u)[1] != 0.0; };
+      // wavefront 0: chain; 1: Euler step + Lie Jacobians; the last: gaps (with four wavefronts it has nothing else to do;
+      // with fewer it is the Euler wavefront again); RW - 1: state differences
+      constexpr int NWV = (RW >= 3) ? 4 : RW;
       if (wv == 0) {
         if (live(wl)) chain_section(RL->base + (size_t)wl * RL->usz);
       } else if (wv == 1) {
-        if (live(wl)) euler_section(RL->base + (size_t)wl * RL->usz, traj(wl), D.st[traj(wl)].is_feasible != 0 || raw);
+        if (live(wl)) euler_section(RL->base + (size_t)wl * RL->usz);
+      }
+      if (wv == (NWV == 4 ? 3 : 1)) {
+        if (live(wl)) gap_section(RL->base + (size_t)wl * RL->usz, traj(wl), feasible(wl));
       }
       if (wv == RW - 1) {
         const int u = wl / SM::NSLOT, q = wl % SM::NSLOT;
@@ -642,7 +672,17 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
   // must sit in wave-uniform control flow -- a wavefront holds two units, one of which may be idle -- so the idle unit
   // skips the stages, not the barriers.
   bool unit_on = true;
-  if constexpr (RW > 0) unit_on = RL->active;
+  if constexpr (RW > 0) {
+    unit_on = RL->active;
+    // flags for the role lanes (see role_phase): every unit of the block writes them, idle ones too
+    ex.each([&](int lane, int sl) {
+      if (lane == 0) {
+        N[SM::OFF_RED + 12] = unit_on ? 1.0 : 0.0;
+        N[SM::OFF_RED + 13] = (unit_on && feas) ? 1.0 : 0.0;
+        N[SM::OFF_RED + 14] = (double)b;
+      }
+    });
+  }
   // ---- S0: load x, s, a ------------------------------------------------------------------------------------
   if (unit_on) ex.each([&](int lane, int sl) {
     const double* xg = D.xs + ((size_t)b * (T + 1) + t) * NX;
@@ -715,7 +755,8 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
     });
     LIN_STAMP(12);
     ex.each([&](int lane, int sl) {
-      if (lane == 1) euler_section(N, b, feas);
+      if (lane == 1) euler_section(N);
+      if (lane == 2) gap_section(N, b, feas);
     });
     ex.sync();
   }
@@ -832,46 +873,33 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
   });
   ex.sync();
   LIN_STAMP(3);
-  // ---- S4: Cholesky of M (lane 0), in place, reciprocal diagonal --------------------------------------------------
+  // ---- S4: Cholesky of M, in the registers of every lane that solves with it ------------------------------------------------
+  // (Round 3 had lane 0 factor M in place in LDS -- 3.7k cycles with 31 lanes idle -- and every solve of S5 read the factor
+  //  back entry by entry: 90 dependent LDS round trips per lane, ~6k cycles.  Now each solving lane reads the lower triangle
+  //  once, in one block, factors it redundantly in registers (165 multiply-adds) and solves from registers.  Same
+  //  factorisation, same substitutions, same order: chol_packed / chol_solve_packed.)
+  double Lq_l[Exec::SLOTS][DM::NTRI];
   ex.each([&](int lane, int sl) {
-    if (lane != 0) return;
-    double* M = N + SM::OFF_M;
-    for (int j = 0; j < NV; ++j) {
-      double s = M[j * NV + j];
-      for (int k = 0; k < j; ++k) s -= M[j * NV + k] * M[j * NV + k];
-      const double inv = frsqrt(s);
-      M[j * NV + j] = inv;
-      for (int i = j + 1; i < NV; ++i) {
-        double tt = M[i * NV + j];
-        for (int k = 0; k < j; ++k) tt -= M[i * NV + k] * M[j * NV + k];
-        M[i * NV + j] = tt * inv;
-      }
-    }
+    const int k = lane - 2 * NV;
+    if (!(lane < NDX) && !(k >= 0 && k < NU)) return;
+    const double* M = N + SM::OFF_M;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+      for (int j = 0; j <= i; ++j) Lq_l[sl][i * (i + 1) / 2 + j] = M[i * NV + j];
+    LIN_FENCE();
+    chol_packed<NV>(Lq_l[sl]);
   });
-  ex.sync();
   if constexpr (CT) {
     if (use_contact) {
       // M^-1 Jc^T (lanes 0..nc-1), then G = Jc M^-1 Jc^T and its Cholesky factor (lane 0)
       ex.each([&](int lane, int sl) {
         if (lane >= NCR) return;
-        const double* Lm = N + SM::OFF_M;
         double y[NV];
 #pragma unroll
         for (int i = 0; i < NV; ++i) y[i] = N[SM::OFF_JC + lane * NV + i];
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-          double s_ = y[i];
-#pragma unroll
-          for (int kk = 0; kk < i; ++kk) s_ -= Lm[i * NV + kk] * y[kk];
-          y[i] = s_ * Lm[i * NV + i];
-        }
-#pragma unroll
-        for (int i = NV - 1; i >= 0; --i) {
-          double s_ = y[i];
-#pragma unroll
-          for (int kk = i + 1; kk < NV; ++kk) s_ -= Lm[kk * NV + i] * y[kk];
-          y[i] = s_ * Lm[i * NV + i];
-        }
+        LIN_FENCE();
+        chol_solve_packed<NV>(Lq_l[sl], y);
 #pragma unroll
         for (int i = 0; i < NV; ++i) N[OFF_MIJ + i * NCR + lane] = y[i];
       });
@@ -916,21 +944,7 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
         da[i] = Bik * dus;
       }
     }
-    const double* Lm = N + SM::OFF_M;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      double s = da[i];
-#pragma unroll
-      for (int kk = 0; kk < i; ++kk) s -= Lm[i * NV + kk] * da[kk];
-      da[i] = s * Lm[i * NV + i];
-    }
-#pragma unroll
-    for (int i = NV - 1; i >= 0; --i) {
-      double s = da[i];
-#pragma unroll
-      for (int kk = i + 1; kk < NV; ++kk) s -= Lm[kk * NV + i] * da[kk];
-      da[i] = s * Lm[i * NV + i];
-    }
+    chol_solve_packed<NV>(Lq_l[sl], da);
     if constexpr (CT) {
       if (use_contact) {
         // [M Jc^T; Jc 0][da; -dlam] = [rhs; -dcon]:  dlam = -(Jc M^-1 Jc^T)^-1 (Jc M^-1 rhs + dcon), da += M^-1 Jc^T dlam
@@ -982,18 +996,27 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
       G[NV + i] = da[i] * dt;
     }
     double top[6];
+    {
+      // the Lie Jacobian of the Euler step, read as one block (36 broadcast reads in flight, one wait) before the products
+      double J2r[36], J1c[6];
 #pragma unroll
-    for (int r = 0; r < 6; ++r) {
-      double a_ = 0;
+      for (int i = 0; i < 36; ++i) J2r[i] = N[SM::OFF_J2 + i];
 #pragma unroll
-      for (int l = 0; l < 6; ++l) a_ += N[SM::OFF_J2 + r * 6 + l] * G[l];
-      top[r] = a_;
+      for (int r = 0; r < 6; ++r) J1c[r] = N[SM::OFF_J1 + r * 6 + (lane < 6 ? lane : 0)];
+      LIN_FENCE();
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        double a_ = 0;
+#pragma unroll
+        for (int l = 0; l < 6; ++l) a_ += J2r[r * 6 + l] * G[l];
+        top[r] = a_;
+      }
+      if (xlane && lane < 6) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) top[r] += J1c[r];
+      }
     }
     if (xlane) {
-      if (lane < 6) {
-#pragma unroll
-        for (int r = 0; r < 6; ++r) top[r] += N[SM::OFF_J1 + r * 6 + lane];
-      }
 #pragma unroll
       for (int r = 0; r < 6; ++r) out[DM::OFF_FX + r * DM::NM + lane] = top[r];
 #pragma unroll
@@ -1098,23 +1121,38 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
         if (!on[q]) continue;
         const double* S = N + SM::OFF_CST + q * SM::SLOT;
         const double* J6 = N + SM::OFF_CST + own[q] * SM::SLOT + 3 * NDX;
+        // operands first, as one block of LDS reads (the base lanes need the whole log Jacobian and the six leading activation
+        // derivatives: 48 reads in flight instead of 120 read-wait pairs), then the arithmetic in its original order
+        double J6r[36], J6c[6], Ar6[6], Arr6[6];
+        if (lane < 6) {
+#pragma unroll
+          for (int rr = 0; rr < 6; ++rr) J6c[rr] = J6[rr * 6 + lane];  // column `lane` of the log Jacobian
+#pragma unroll
+          for (int i = 0; i < 36; ++i) J6r[i] = J6[i];
+#pragma unroll
+          for (int rr = 0; rr < 6; ++rr) {
+            Ar6[rr] = S[NDX + rr];
+            Arr6[rr] = S[2 * NDX + rr];
+          }
+        }
+        const double ar_own = S[NDX + lane], arr_own = S[2 * NDX + lane];
+        LIN_FENCE();
         if (lane < 6) {
           double g = 0;
 #pragma unroll
-          for (int rr = 0; rr < 6; ++rr) g += J6[rr * 6 + lane] * S[NDX + rr];
+          for (int rr = 0; rr < 6; ++rr) g += J6c[rr] * Ar6[rr];
           lx_l[sl] += g;
 #pragma unroll
           for (int i = 0; i < 6; ++i) {
             double h = 0;
 #pragma unroll
-            for (int rr = 0; rr < 6; ++rr) h += J6[rr * 6 + i] * S[2 * NDX + rr] * J6[rr * 6 + lane];
+            for (int rr = 0; rr < 6; ++rr) h += J6r[rr * 6 + i] * Arr6[rr] * J6c[rr];
             hx_l[sl][i] += h;
           }
         } else {
-          lx_l[sl] += S[NDX + lane];
+          lx_l[sl] += ar_own;
 #pragma unroll
-          for (int i = 6; i < NDX; ++i)
-            if (i == lane) hx_l[sl][i] += S[2 * NDX + lane];
+          for (int i = 6; i < NDX; ++i) hx_l[sl][i] += (i == lane) ? arr_own : 0.0;  // (a select, not a branch per entry)
         }
       }
     });
@@ -1126,16 +1164,38 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
     const int k = lane - 2 * NV;
     if (k < 0 || k >= NU) return;
     double cv = 0;
-    for (int ci = 0; ci < set.ncosts; ++ci) {
-      const EMPC_K EmpcCost& c = set.costs[ci];
-      if (!c.active || c.type != EMPC_COST_CONTROL) continue;
-      double av, Ar, Arr;
-      activation1(c.activation, N[SM::OFF_S + k] - c.ref[k], act_weight(c, k, smooth, platform_of<DM>(P)), c.lb[k], c.ub[k], av, Ar, Arr);
-      cv += c.weight * av;
-      lx_l[sl] += c.weight * Ar;
+    // The set's Control costs from the host-made list (same order as the table scan), in groups of CG: the lane's parameters
+    // of the whole group (reference, weight, bounds of component k: vector loads from the problem image) are requested before
+    // the first activation is evaluated -- one memory round trip per group instead of one per cost.
+    constexpr int CG = 3;
+    const double sk = N[SM::OFF_S + k];
+    const auto PL = platform_of<DM>(P);
+    for (int base = 0; base < si.n_ctrl; base += CG) {
+      double pref[CG], pw[CG], plb[CG], pub[CG], wgt[CG];
+      int act[CG];
+      bool on[CG];
 #pragma unroll
-      for (int i = 0; i < NU; ++i)
-        if (i == k) hx_l[sl][i] += c.weight * Arr;
+      for (int q = 0; q < CG; ++q) {
+        on[q] = base + q < si.n_ctrl;
+        const EMPC_K EmpcCost& c = set.costs[si.ctrl_ci[on[q] ? base + q : base]];
+        pref[q] = c.ref[k];
+        pw[q] = act_weight(c, k, smooth, PL);
+        plb[q] = c.lb[k];
+        pub[q] = c.ub[k];
+        wgt[q] = c.weight;
+        act[q] = c.activation;
+      }
+      LIN_FENCE();
+#pragma unroll
+      for (int q = 0; q < CG; ++q) {
+        if (!on[q]) continue;
+        double av, Ar, Arr;
+        activation1(act[q], sk - pref[q], pw[q], plb[q], pub[q], av, Ar, Arr);
+        cv += wgt[q] * av;
+        lx_l[sl] += wgt[q] * Ar;
+#pragma unroll
+        for (int i = 0; i < NU; ++i) hx_l[sl][i] += (i == k) ? wgt[q] * Arr : 0.0;  // (a select, not a branch per entry)
+      }
     }
     N[SM::OFF_RED + 1 + k] = cv;
   });
