@@ -282,6 +282,8 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
   int okD[Exec::SLOTS];
   double xkC[Exec::SLOTS][RK4 ? NX : 1], ksC[Exec::SLOTS][RK4 ? NDX : 1];  // C, RK4 nodes: state of the knot, sum w_i k_i
   double ellD[Exec::SLOTS];                   // D, RK4 nodes: sum w_i l_i of the knot being finished
+  double xD[Exec::SLOTS][NX], rsD[Exec::SLOTS][NDX];  // D: trial state and last state difference, from phase I to phase II of a knot
+  int rsofD[Exec::SLOTS];                     // D: which reference rsD belongs to
   constexpr int NST = RK4 ? 4 : 1;
 
   // x_try of knot 0 (C): x0, contracted towards the nominal start by the gap when the pass keeps gaps
@@ -618,17 +620,23 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
           for (int i = 0; i < NX; ++i) xs_o[i] = x[i];
         }
         R6_SUB(1);
-        double rstate[NDX];
-        int rstate_of = -1;
-        for (int ks = 0; ks < si.n_state; ++ks) {
+        // State costs: the first half of the set's list here, the rest after the barrier (D's phase I -- 7k cycles per knot with
+        // all of them -- was the longest of the four roles, its phase II the shortest beside C's 5.5k; the state and the last
+        // state difference travel across the barrier in registers, XT itself is overwritten by C in phase II).  Same
+        // operations, same order per cost.
+        rsofD[sl] = -1;
+        const int n_first = (si.n_state + 1) / 2;
+        for (int ks = 0; ks < n_first; ++ks) {
           const int ci = si.state_ci[ks];
           const auto& c = set.costs[ci];
-          if (!(c.ref_share >= 0 && c.ref_share == rstate_of)) {
-            state_diff<DM>(c.ref, x, rstate, nullptr);
-            rstate_of = (c.ref_share >= 0) ? c.ref_share : ci;
+          if (!(c.ref_share >= 0 && c.ref_share == rsofD[sl])) {
+            state_diff<DM>(c.ref, x, rsD[sl], nullptr);
+            rsofD[sl] = (c.ref_share >= 0) ? c.ref_share : ci;
           }
-          VAL[ci * NL + lane] = activation_value<NDX>(c, rstate, NDX);
+          VAL[ci * NL + lane] = activation_value<NDX>(c, rsD[sl], NDX);
         }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xD[sl][i] = x[i];
         R6_SUB(2);
       }
       R6_SCHED_FENCE();
@@ -777,8 +785,19 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
     // ---- D: Control costs of this knot, control of the trial to memory -----------------------------------------------------------
     if constexpr (ROLE == R6_D) ex.each([&](int lane, int sl) {
       const Roll6Lane& L = LL[sl];
-      if (!L.live || st > 0) return;  // (RK4 nodes: the control and its cost values are those of stage 0 for all four stages)
+      if (!L.live) return;
       R6_SUB(6);
+      // the rest of the State costs of this knot / stage (see phase I)
+      for (int ks = (si.n_state + 1) / 2; ks < si.n_state; ++ks) {
+        const int ci = si.state_ci[ks];
+        const auto& c = set.costs[ci];
+        if (!(c.ref_share >= 0 && c.ref_share == rsofD[sl])) {
+          state_diff<DM>(c.ref, xD[sl], rsD[sl], nullptr);
+          rsofD[sl] = (c.ref_share >= 0) ? c.ref_share : ci;
+        }
+        VAL[ci * NL + lane] = activation_value<NDX>(c, rsD[sl], NDX);
+      }
+      if (st > 0) return;  // (RK4 nodes: the control and its cost values are those of stage 0 for all four stages)
       double s[NU];
 #pragma unroll
       for (int i = 0; i < NU; ++i) s[i] = terminal ? 0.0 : UT[i * NL + lane];
