@@ -29,17 +29,6 @@
 #define EMPC_KPTR(T, ptr) (ptr)
 #endif
 
-// Scheduling fence between a block of operand loads (LDS, constant memory) and the arithmetic that consumes them: the loads are
-// issued together and waited for once.  Left alone the compiler sinks each load next to its use (read, wait, use, read, wait ...:
-// one exposed round trip per operand) whenever register pressure is high.  No effect on values.
-#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
-#define EMPC_LOAD_FENCE() __builtin_amdgcn_sched_barrier(0)
-#else
-#define EMPC_LOAD_FENCE() \
-  do {                    \
-  } while (0)
-#endif
-
 namespace empc {
 
 // ---- one-direction dual number -------------------------------------------------------------------

@@ -520,26 +520,18 @@ EMPC_HD double activation_value(const CostT& c, const double* r, int nr) {
     double w[NR];
 #pragma unroll
     for (int i = 0; i < NR; ++i) w[i] = c.act_w[i];
-    EMPC_LOAD_FENCE();
 #pragma unroll
     for (int i = 0; i < NR; ++i)
       if (i < nr) cval += 0.5 * w[i] * r[i] * r[i];
   } else {
     const bool weighted = (c.activation != EMPC_ACT_QUADRATIC_BARRIER);
     double w[NR], lb[NR], ub[NR];
-    if (weighted) {  // (one uniform branch around the block of loads, not a select per element)
-#pragma unroll
-      for (int i = 0; i < NR; ++i) w[i] = c.act_w[i];
-    } else {
-#pragma unroll
-      for (int i = 0; i < NR; ++i) w[i] = 1.0;
-    }
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
+      w[i] = weighted ? c.act_w[i] : 1.0;
       lb[i] = c.lb[i];
       ub[i] = c.ub[i];
     }
-    EMPC_LOAD_FENCE();
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
       if (i < nr) {
@@ -555,14 +547,8 @@ EMPC_HD double activation_value(const CostT& c, const double* r, int nr) {
 template <int NU, class CostT, class PlatT>
 EMPC_HD double control_cost_value(const CostT& c, const double* s, double smooth, const PlatT& P) {
   double r[NU];
-  {
-    double ref[NU];
 #pragma unroll
-    for (int i = 0; i < NU; ++i) ref[i] = c.ref[i];
-    EMPC_LOAD_FENCE();
-#pragma unroll
-    for (int i = 0; i < NU; ++i) r[i] = s[i] - ref[i];
-  }
+  for (int i = 0; i < NU; ++i) r[i] = s[i] - c.ref[i];
   if (!c.is_barrier) return activation_value<NU>(c, r, NU);
   // SolverSbFDDP::barrierUpdate (src/sbfddp.cpp:464-477): weights 1 / (smooth (ub - lb))^2, bounds from the cost
   double cval = 0;
@@ -574,7 +560,6 @@ EMPC_HD double control_cost_value(const CostT& c, const double* s, double smooth
     lb[i] = c.lb[i];
     ub[i] = c.ub[i];
   }
-  EMPC_LOAD_FENCE();
   if (c.activation == EMPC_ACT_QUAD || c.activation == EMPC_ACT_WEIGHTED_QUAD) {
     const bool weighted = (c.activation == EMPC_ACT_WEIGHTED_QUAD);
 #pragma unroll

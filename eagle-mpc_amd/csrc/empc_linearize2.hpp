@@ -908,7 +908,10 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
         if (lane != 0) return;
         constexpr int NG = NCR * (NCR + 1) / 2;
         double G[NG];
+        // (compile-time indices throughout: an array indexed by a run-time loop counter lives in scratch memory)
+#pragma unroll
         for (int r = 0; r < NCR; ++r)
+#pragma unroll
           for (int c = 0; c <= r; ++c) {
             double g = 0;
             for (int i = 0; i < NV; ++i) g += N[SM::OFF_JC + r * NV + i] * N[OFF_MIJ + i * NCR + c];
@@ -1255,7 +1258,9 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
         for (int i = 0; i < 6; ++i) r[i] = F[12 + i] - c.ref[i];
       }
       double cv = 0;
-      for (int i = 0; i < nr; ++i) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {  // (compile-time indices: r stays in registers)
+        if (i >= nr) continue;
         double av, Ar, Arr;
         activation1(c.activation, r[i], c.act_w[i], c.lb[i], c.ub[i], av, Ar, Arr);
         cv += av;
@@ -1303,7 +1308,9 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
         for (int i = 0; i < 6; ++i) col[i] = dvcc[i];
       }
       double g = 0;
-      for (int i = 0; i < nr; ++i) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {  // (compile-time indices: col / wcol stay in registers)
+        if (i >= nr) continue;
         g += col[i] * S[NDX + i];
         wcol_l[sl][i] = S[2 * NDX + i] * col[i];
         N[SM::OFF_RSH + i * NDX + lane] = col[i];
@@ -1318,7 +1325,9 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
       for (int i = 0; i < NDX; ++i) {
         if (i >= ni) continue;
         double h = 0;
-        for (int rr = 0; rr < nr; ++rr) h += N[SM::OFF_RSH + rr * NDX + i] * wcol_l[sl][rr];
+#pragma unroll
+        for (int rr = 0; rr < 6; ++rr)
+          if (rr < nr) h += N[SM::OFF_RSH + rr * NDX + i] * wcol_l[sl][rr];
         hx_l[sl][i] += h;
       }
     });
@@ -1332,9 +1341,12 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
       ex.each([&](int lane, int sl) {
         if (lane != 0) return;
         double AR[5][3];  // A R_n^T, precomputed by prepare_problem in ref[4..18]
+#pragma unroll
         for (int i = 0; i < 5; ++i)
+#pragma unroll
           for (int j = 0; j < 3; ++j) AR[i][j] = c.ref[4 + 3 * i + j];
         double cv = 0;
+#pragma unroll
         for (int i = 0; i < 5; ++i) {
           const double r = AR[i][0] * N[SM::OFF_LAM] + AR[i][1] * N[SM::OFF_LAM + 1] + AR[i][2] * N[SM::OFF_LAM + 2];
           double av, Ar, Arr;
@@ -1355,6 +1367,7 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
         if (!xlane && !ulane) return;
         const int colidx = xlane ? lane : NDX + k;
         double g = 0;
+#pragma unroll
         for (int i = 0; i < 5; ++i) {
           const double col = N[SM::OFF_CONE + i * 3] * dlam_l[sl][0] + N[SM::OFF_CONE + i * 3 + 1] * dlam_l[sl][1] +
                              N[SM::OFF_CONE + i * 3 + 2] * dlam_l[sl][2];
@@ -1374,6 +1387,7 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
 #pragma unroll
           for (int i = 0; i < NDX; ++i) {
             double h = 0;
+#pragma unroll
             for (int rr = 0; rr < 5; ++rr) h += N[SM::OFF_RSH + rr * (NDX + NU) + i] * wc_l[sl][rr];
             hx_l[sl][i] += h;
           }
@@ -1381,12 +1395,14 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
 #pragma unroll
           for (int i = 0; i < NDX; ++i) {
             double h = 0;
+#pragma unroll
             for (int rr = 0; rr < 5; ++rr) h += N[SM::OFF_RSH + rr * (NDX + NU) + i] * wc_l[sl][rr];
             hxu_l[sl][i] += h;
           }
 #pragma unroll
           for (int l = 0; l < NU; ++l) {
             double h = 0;
+#pragma unroll
             for (int rr = 0; rr < 5; ++rr) h += N[SM::OFF_RSH + rr * (NDX + NU) + NDX + l] * wc_l[sl][rr];
             hx_l[sl][l] += h;
           }

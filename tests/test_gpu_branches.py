@@ -363,8 +363,14 @@ def test_shortest_horizons_and_single_iterations(empc, name, dt):
         if maxiter == 100:
             continue
         for key, mine in (("xs", np.array(s.xs)), ("us_squash", np.array(s.us_squash))):
-            noise = np.abs(rf[key] - r[key]).max()
-            assert np.abs(mine - r[key]).max() <= max(1e-6, 10.0 * noise), (name, maxiter, key, noise)
+            # knot by knot: a knot on which the oracle's own two builds differ by more than 1e-3 holds the squashed image of a
+            # control from a trial that was blowing up (sigma of 1e22: both square roots cancel, what is left is rounding noise
+            # of any magnitude, DESIGN.md deviations) -- such knots carry no bound; the others are held to 10 x the builds' distance
+            noise_k = np.abs(rf[key] - r[key]).reshape(len(r[key]), -1).max(axis=1)
+            err_k = np.abs(mine - r[key]).reshape(len(r[key]), -1).max(axis=1)
+            sane = noise_k <= 1e-3
+            assert sane.sum() >= 1, (name, maxiter, key, noise_k)  # (knots of 0.6 ... 1 s: often only the first few are comparable)
+            assert (err_k[sane] <= np.maximum(1e-6, 10.0 * noise_k[sane].max())).all(), (name, maxiter, key, err_k, noise_k)
     row = s.solve_stream(np.array([problem.x0]), 100)
     assert row["iter"][0] == s.iter and np.array_equal(row["xs"][0], np.array(s.xs), equal_nan=True)
 
