@@ -144,6 +144,36 @@ def secondary_displacement(empc, B, maxiter, device):
                              "sweeps_per_solve": agg["sweeps"] / steps}}
 
 
+def slots_sweep(empc, problem, d, args, device, B0, value0):
+    """The occupancy view: the same stream with 2 x and 4 x the slots in flight on the one GPU, the same
+    number of steps each (queue = steps x slots), throughput normalised to 1024 slots.  The headline stays at B0 slots; this
+    says what the chain kernels leave on the table there: at 1024 slots the rollout occupies 171 of the 256 CUs and every chain
+    kernel runs one wavefront per SIMD (profiles/r04_slots_sweep.md)."""
+    import torch
+    rows = [{"slots": B0, "value_per_%d_slots" % B0: value0, "relative": 1.0}]
+    for mult in (2, 4):
+        Bn = B0 * mult
+        try:
+            x0n = empc.perturbed_x0s(problem.x0, Bn * args.steps, nq=d.model.nq)
+            sn = empc.SolverSbFDDP(problem, batch=Bn, device=device)
+            sn.stream_begin(np.ascontiguousarray(x0n[:Bn]))
+            sn.stream_run(args.maxiter)  # warm-up
+            sn.stream_begin(x0n)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            sn.stream_run(args.maxiter)
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            st = sn.stats()
+            v = st["total_iters"] / B0 / el
+            rows.append({"slots": Bn, "value_per_%d_slots" % B0: v, "relative": v / value0, "ms_per_sweep": el * 1e3 / max(st["sweeps"], 1),
+                         "solves": Bn * args.steps})
+            del sn
+        except Exception as e:  # e.g. out of memory on a smaller part: the sweep is a side view, never the headline
+            rows.append({"slots": Bn, "error": str(e)[:200]})
+    return rows
+
+
 def cpu_baseline_and_parity(empc, solver, problem, d, x0s, B, maxiter, unit):
     """Rank 0, N = 1, after the timed region: the oracle (CPU restatement, `kind: port`) on the host cores of this box as
     the reported CPU baseline, and -- on the same oracle results -- the parity block of the north star.  The oracle is the
@@ -280,6 +310,7 @@ def main():
                     help="stream: the steps x batch initial states go through the batch slots as one queue; batch: one plain solve per step")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short displacement run appended at N = 1")
     ap.add_argument("--no-single-batch", action="store_true", help="skip the plain batched solves appended to a stream run at N = 1")
+    ap.add_argument("--no-slots-sweep", action="store_true", help="skip the 2048- and 4096-slot stream runs appended at N = 1")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-launched workers (0 = pick a free one)")
     ap.add_argument("--maxiter", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -616,6 +647,8 @@ def main():
                                    "sweeps_per_solve": aggb["sweeps"] / nb,
                                    "note": "plain empc_solver_solve of one batch at a time: ~3/4 of its sweeps run on the few "
                                            "rollouts that need many iterations"}
+        if stream and world == 1 and not args.no_slots_sweep:
+            out["slots_sweep"] = slots_sweep(empc, problem, d, args, local_dev, B, iters_total / B / elapsed)
         if world == 1 and not is_mpc and not args.no_secondary and args.config != "displacement":
             out["secondary"] = secondary_displacement(empc, B, args.maxiter, local_dev)
         if not args.no_cpu_baseline and not is_mpc and world == 1:  # rank 0 at N = 1 only

@@ -97,8 +97,17 @@ struct RoleExec {
   // drain them (vmcnt(0)) twice per knot.
   __device__ __forceinline__ void sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 };
+// EMPC_ROLL_WAVES / EMPC_BWD_WAVES (build-time, default 1): resident wavefronts per SIMD the chain kernels are compiled for.
+// 2 caps their register budget at 256 (they take 280-400 at the compiler's choice): the occupancy experiment of
+// profiles/r04_slots_sweep.md -- measured slower at 1024 slots and no better per 1024 at 2048 / 4096, so 1 is shipped.
+#ifndef EMPC_ROLL_WAVES
+#define EMPC_ROLL_WAVES 1
+#endif
+#ifndef EMPC_BWD_WAVES
+#define EMPC_BWD_WAVES 1
+#endif
 template <class DM, int CT, bool RK4>
-__global__ void __launch_bounds__(64 * R6_WAVES) k_rollout6(DevBuffers D) {
+__global__ void __launch_bounds__(64 * R6_WAVES) __attribute__((amdgpu_waves_per_eu(EMPC_ROLL_WAVES, EMPC_ROLL_WAVES))) k_rollout6(DevBuffers D) {
   extern __shared__ double smem_roll6[];
   RoleExec ex{(int)(threadIdx.x & 63)};
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: the role switch is a scalar branch
@@ -225,7 +234,7 @@ struct BlockExec {
 
 // the shipped backward pass: matrix cores, zero-padded LDS tiles (empc_backward4.hpp)
 template <class DM, bool BOX>
-__global__ void __launch_bounds__(64) k_backward4(DevBuffers D) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EMPC_BWD_WAVES, EMPC_BWD_WAVES))) k_backward4(DevBuffers D) {
   extern __shared__ double smem_bwd4[];
   BlockExec ex{(int)threadIdx.x};
   backward_traj4<DM, BOX>(ex, D, blockIdx.x, smem_bwd4);

@@ -43,8 +43,8 @@ case "$MODE" in
     ;;
   ab)
     for cfg in eagle_catch displacement push_slide; do
-      bench_line "${cfg}_baked" "EMPC_BAKED=1" --config $cfg --no-cpu-baseline --no-secondary --steps 10
-      bench_line "${cfg}_generic" "EMPC_BAKED=0" --config $cfg --no-cpu-baseline --no-secondary --steps 10
+      bench_line "${cfg}_baked" "EMPC_BAKED=1" --config $cfg --no-cpu-baseline --no-secondary --no-slots-sweep --steps 10
+      bench_line "${cfg}_generic" "EMPC_BAKED=0" --config $cfg --no-cpu-baseline --no-secondary --no-slots-sweep --steps 10
     done
     ;;
   profiles)
@@ -57,10 +57,10 @@ case "$MODE" in
       STEPS=20; [ "$CFG" = push_slide ] && STEPS=5
       timeout 900 python3 bench.py --config $CFG --steps $STEPS --warmup 1 --no-secondary > $O/bench_$CFG.json 2> $O/bench_$CFG.err; echo "bench $CFG rc $?"
       tail -c 400 $O/bench_$CFG.json; echo
-      ARGS="--config $CFG --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-single-batch"
+      ARGS="--config $CFG --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-single-batch --no-slots-sweep"
       rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$CFG -- python3 bench.py $ARGS > $O/bench_under_rocprof_$CFG.json 2> $O/stats_$CFG.err
       python3 tools/profile_summarize.py stats $O/stats_$CFG $O/kernel_stats_$CFG.csv | head -12
-      PARGS="--config $CFG --steps 2 --warmup 0 --no-cpu-baseline --no-secondary --no-single-batch"
+      PARGS="--config $CFG --steps 2 --warmup 0 --no-cpu-baseline --no-secondary --no-single-batch --no-slots-sweep"
       rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/p_fetch_$CFG -- python3 bench.py $PARGS > /dev/null 2> $O/p_fetch_$CFG.err
       rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/p_write_$CFG -- python3 bench.py $PARGS > /dev/null 2> $O/p_write_$CFG.err
       rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES --output-format csv -d $O/p_fp64_$CFG -- python3 bench.py $PARGS > /dev/null 2> $O/p_fp64_$CFG.err
@@ -68,6 +68,29 @@ case "$MODE" in
       python3 tools/profile_summarize.py pmc $CFG $O/pmc_$CFG.json 1024 $T 10 $O/p_fetch_$CFG $O/p_write_$CFG $O/p_fp64_$CFG $O/p_act_$CFG | cut -c1-1500
     done
     find $O -name "*.csv" -size +1M -delete; find $O -name "*.db" -delete; du -sh $O
+    ;;
+  slots)
+    # occupancy experiment: slots in flight per GPU x {shipped kernels (one wavefront per SIMD for the chain
+    # kernels), libempc_w2.so = backward and rollout compiled for two (256 registers, spills)}; trajectory-iterations/s / 1024
+    for LIBV in ${SLOT_LIBS:-default "$ROOT/eagle-mpc_amd/libempc_w2.so"}; do
+      [ "$LIBV" = default ] && LIBV=""
+      for CFG in ${CONFIGS:-eagle_catch displacement}; do
+        for B in 1024 2048 4096; do
+          ST=${SLOT_STEPS:-20}  # the same number of steps (queue = steps x slots) for every size: equal share of drain sweeps
+          EMPC_LIB_PATH="$LIBV" timeout 900 python3 bench.py --config $CFG --batch $B --steps $ST --warmup 1 --no-cpu-baseline --no-secondary --no-single-batch --no-slots-sweep > gpurun_out/${TAG}_slots.json 2> gpurun_out/${TAG}_slots.err
+          python3 - "gpurun_out/${TAG}_slots.json" "$CFG" "$B" "${LIBV:-shipped}" <<'PY' | tee -a "gpurun_out/${TAG}_slots_sweep.jsonl"
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    k = d["kernels"]
+    print(json.dumps({"config": sys.argv[2], "slots": int(sys.argv[3]), "library": sys.argv[4].split("/")[-1], "iters_per_s_per_1024": d["trajectory_iters_per_s"] / 1024.0,
+                      "ms_per_sweep": d["ms_per_sweep"], "ms": {n: k[n]["avg_ms"] for n in k}}))
+except Exception as e:
+    print(json.dumps({"config": sys.argv[2], "slots": int(sys.argv[3]), "library": sys.argv[4].split("/")[-1], "error": str(e)}))
+PY
+        done
+      done
+    done
     ;;
   stamps)
     # phase-level launches: product library first (ms per launch), then the diagnostic build with in-kernel cycle stamps
