@@ -374,7 +374,7 @@ static void launch_calc(DevBuffers D, hipStream_t s) {
 }
 template <class DM, int CT, int BLK>
 static void launch_linearize_blk(DevBuffers D, hipStream_t s) {
-  constexpr int LPU = (3 * DM::NV <= 32) ? 32 : 64;
+  constexpr int LPU = lin_lanes_per_unit<DM, CT>();  // 32; 64 for the 11-dof class with contact dynamics
   constexpr int UPB = BLK / LPU;
   constexpr int USZ = Lin2Smem<DM>::size_for(CT);
   const int n = D.B * (D.T + 1);

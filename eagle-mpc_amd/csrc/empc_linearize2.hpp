@@ -61,6 +61,24 @@ struct Lin2Smem {
   static constexpr int SIZE_NC = (OFF_LAM + 1) / 2 * 2;  // problems without contacts never touch the contact block
 };
 
+// Lanes per (trajectory, node) unit.  3 NV tangent directions (dq | dv | da) and NDX + NU output columns: 27 / 27 for the 9-dof
+// arm -> 32 lanes, two units per wavefront.  The 11-dof arm needs 33 / 33: one lane over a half wavefront -- a whole
+// wavefront per unit with 31 idle lanes and half the units in flight.  FOLDED layout (free dynamics only): 32 lanes, the 33rd
+// direction and column folded away --
+//   * direction da of the LAST joint only supplies the last diagonal entry of the joint-space inertia (the rest of its column is
+//     the upper triangle, which the Cholesky factorisation never reads): S^T I S of the last body, evaluated directly (lane 0);
+//   * the control column of the last joint (k = NU - 1) is a second pass of lane 2 NV - 1 (the last dv lane) through the solve,
+//     the Control-cost and the store stages, with its own three accumulators (the Control costs only touch the diagonal of Luu).
+// Same operations per quantity as the 64-lane layout.
+template <class DM, int CT>
+constexpr bool lin_folded() {
+  return CT == 0 && 3 * DM::NV == 33 && DM::NDX + DM::NU == 33;
+}
+template <class DM, int CT>
+constexpr int lin_lanes_per_unit() {
+  return (3 * DM::NV <= 32 || lin_folded<DM, CT>()) ? 32 : 64;
+}
+
 // forward kinematics + nominal Newton-Euler quantities of one unit, executed by ONE lane
 template <class DM, class MT>
 EMPC_HD void lin2_nominal_chain(const MT& m, double* N, int cbody = -1) {
@@ -462,6 +480,9 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
   constexpr int NB = DM::NB, NV = DM::NV, NQ = DM::NQ, NX = DM::NX, NDX = DM::NDX, NU = DM::NU, NROT = DM::NROT;
   constexpr int REC = DM::REC;
   static_assert(NU <= NV, "control columns reuse the NV inertia-column lanes");
+  constexpr bool FOLD = lin_folded<DM, CT>();  // 32-lane layout of the 11-dof class (see lin_folded)
+  constexpr int LXL = 2 * NV - 1;              // FOLD: the lane that also carries control column KX
+  constexpr int KX = NU - 1;
   const EMPC_K DevProblem& P = EMPC_KREF(DevProblem, D.P);
   const auto& m = model_of<DM>(P);
   const TrajState& st = D.st[b];
@@ -776,6 +797,17 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
 #pragma unroll
       for (int i = 0; i < NV; ++i) N[SM::OFF_M + i * NV + (lane - 2 * NV)] = dtau_l[sl][i];
     }
+    if constexpr (FOLD) {
+      // direction da of the last joint: da = S = [0; axis] on the last body, nothing on the others, no velocity terms --
+      // dtau[NV - 1] = axis . (I S).angular, the operations lin2_tangent / lin2_dforce perform for that direction
+      if (lane == 0) {
+        const double Sl[6] = {0.0, 0.0, 0.0, m.axis[NB - 1][0], m.axis[NB - 1][1], m.axis[NB - 1][2]};
+        double IS[6];
+        inertia_apply<double>(m, NB - 1, Sl, IS);
+        const double ax[3] = {m.axis[NB - 1][0], m.axis[NB - 1][1], m.axis[NB - 1][2]};
+        N[SM::OFF_M + (NV - 1) * NV + (NV - 1)] = dot3<double>(ax, IS + 3);
+      }
+    }
 #pragma unroll
     for (int c = 0; c < NCAP; ++c) {
       if (c >= ncap) continue;
@@ -881,7 +913,7 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
   double Lq_l[Exec::SLOTS][DM::NTRI];
   ex.each([&](int lane, int sl) {
     const int k = lane - 2 * NV;
-    if (!(lane < NDX) && !(k >= 0 && k < NU)) return;
+    if (!(lane < NDX) && !(k >= 0 && k < NU)) return;  // (FOLD: all 32 lanes)
     const double* M = N + SM::OFF_M;
 #pragma unroll
     for (int i = 0; i < NV; ++i)
@@ -926,11 +958,7 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
   }
   LIN_STAMP(4);
   // ---- S5: M^-1 solves, Euler Jacobian columns -> tape ------------------------------------------------------------
-  ex.each([&](int lane, int sl) {
-    const bool xlane = lane < NDX;
-    const int k = lane - 2 * NV;
-    const bool ulane = k >= 0 && k < NU;
-    if (!xlane && !ulane) return;
+  auto s5_column = [&](int lane, int sl, const bool xlane, const int k) {
     double da[NV];
     if (xlane) {
 #pragma unroll
@@ -1034,6 +1062,15 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
     if (xlane) {
       if (!terminal) D.tape[((size_t)b * (T + 1) + t + 1) * REC + DM::OFF_GAP + lane] = N[SM::OFF_GAP + lane];
       if (t == 0) D.tape[((size_t)b * (T + 1)) * REC + DM::OFF_GAP + lane] = N[SM::OFF_GAP + NDX + lane];
+    }
+  };
+  ex.each([&](int lane, int sl) {
+    const bool xlane = lane < NDX;
+    const int k = lane - 2 * NV;
+    const bool ulane = k >= 0 && k < NU && lane < lpu;
+    if (xlane || ulane) s5_column(lane, sl, xlane, k);
+    if constexpr (FOLD) {
+      if (lane == LXL) s5_column(lane, sl, false, KX);  // the folded control column: a second pass of this lane
     }
   });
 
@@ -1163,9 +1200,9 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
   }
   LIN_STAMP(6);
   // round 2: Control costs (including the barrier): component k on u lane k
-  ex.each([&](int lane, int sl) {
-    const int k = lane - 2 * NV;
-    if (k < 0 || k >= NU) return;
+  // (component k of every Control cost of the set: value sum returned, gradient entry added to `lxa`, Hessian diagonal entry
+  //  to `diag` -- a Control cost is separable, it only touches the diagonal of Luu)
+  auto ctrl_component = [&](const int k, double& lxa, double& diag) {
     double cv = 0;
     // The set's Control costs from the host-made list (same order as the table scan), in groups of CG: the lane's parameters
     // of the whole group (reference, weight, bounds of component k: vector loads from the problem image) are requested before
@@ -1195,12 +1232,29 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
         double av, Ar, Arr;
         activation1(act[q], sk - pref[q], pw[q], plb[q], pub[q], av, Ar, Arr);
         cv += wgt[q] * av;
-        lx_l[sl] += wgt[q] * Ar;
-#pragma unroll
-        for (int i = 0; i < NU; ++i) hx_l[sl][i] += (i == k) ? wgt[q] * Arr : 0.0;  // (a select, not a branch per entry)
+        lxa += wgt[q] * Ar;
+        diag += wgt[q] * Arr;
       }
     }
-    N[SM::OFF_RED + 1 + k] = cv;
+    return cv;
+  };
+  double lux_l[Exec::SLOTS], luux_l[Exec::SLOTS];  // FOLD: gradient / Hessian-diagonal entry of the folded control column
+  ex.each([&](int lane, int sl) {
+    const int k = lane - 2 * NV;
+    if (k >= 0 && k < NU && lane < lpu) {
+      double diag = 0.0;
+      const double cv = ctrl_component(k, lx_l[sl], diag);
+#pragma unroll
+      for (int i = 0; i < NU; ++i) hx_l[sl][i] += (i == k) ? diag : 0.0;  // (a select, not a branch per entry)
+      N[SM::OFF_RED + 1 + k] = cv;
+    }
+    if constexpr (FOLD) {
+      if (lane == LXL) {
+        lux_l[sl] = 0.0;
+        luux_l[sl] = 0.0;
+        N[SM::OFF_RED + 1 + KX] = ctrl_component(KX, lux_l[sl], luux_l[sl]);
+      }
+    }
   });
   ex.sync();
   ex.each([&](int lane, int sl) {
@@ -1421,7 +1475,7 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
       for (int i = 0; i < NDX; ++i) out[DM::OFF_LXX + i * DM::NM + lane] = hx_l[sl][i] * cscale;
     }
     const int k = lane - 2 * NV;
-    if (k >= 0 && k < NU) {
+    if (k >= 0 && k < NU && lane < lpu) {
       out[DM::OFF_LU + k] = lx_l[sl] * cscale;
 #pragma unroll
       for (int i = 0; i < NU; ++i) out[DM::OFF_LUU + i * NU + k] = hx_l[sl][i] * cscale;
@@ -1430,6 +1484,15 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
         double v_ = 0.0;
         if constexpr (CT) v_ = hxu_l[sl][i] * cscale;
         out[DM::OFF_LXU + i * DM::NM + k] = v_;
+      }
+    }
+    if constexpr (FOLD) {
+      if (lane == LXL) {  // the folded control column: Lu entry, column of Luu (diagonal entry only), column of Lxu (zeros)
+        out[DM::OFF_LU + KX] = lux_l[sl] * cscale;
+#pragma unroll
+        for (int i = 0; i < NU; ++i) out[DM::OFF_LUU + i * NU + KX] = ((i == KX) ? luux_l[sl] : 0.0) * cscale;
+#pragma unroll
+        for (int i = 0; i < NDX; ++i) out[DM::OFF_LXU + i * DM::NM + KX] = 0.0;
       }
     }
     if (lane == 0) out[DM::OFF_COST] = N[SM::OFF_RED] * cscale;

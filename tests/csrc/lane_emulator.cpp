@@ -235,7 +235,7 @@ static void emu_linearize(Emu& e) {
 }
 template <class DM>
 static void emu_linearize_view(Emu& e, const DevBuffers& Dl) {
-  constexpr int LPU = (3 * DM::NV <= 32) ? 32 : 64;
+  constexpr int LPU = lin_lanes_per_unit<DM, 0>();  // (the contact bodies emulated here are the 9-dof arm's: 32 lanes either way)
   std::vector<double> smem(Lin2Smem<DM>::SIZE);
   for (int t = 0; t <= e.T; ++t)
     for (int b = 0; b < Dl.B; ++b) {
