@@ -285,18 +285,28 @@ def golden_rank_check(empc, device, maxiter):
                 np.abs(s.us_batch[0] - g["us"][0]).max() < 1e-4)
 
 
-# what bounds each hot kernel (SQ counters of these kernels: profiles/r03_pmc_sq_*.csv)
+# what bounds each hot kernel; the measured shares (vector unit active, waiting) are appended from this round's PMC summary
+# (profiles/r04_pmc_<config>.json: SQ_ACTIVE_INST_VALU, SQ_WAIT_ANY over SQ_WAVE_CYCLES) when it exists for the workload
 LIMITERS = {
-    "linearize": "not HBM: two register-bound wavefronts per SIMD (256 VGPRs each; a third one spills: measured 1.8x slower); "
-                 "VALU active 23 % of a wavefront's cycles = ~47 % of a SIMD's issue slots, a wavefront waits 48 % of its life at "
-                 "stage barriers, single-lane sections (nominal chain, Cholesky) and LDS round trips",
+    "linearize": "not HBM: register-bound wavefronts (two per SIMD at 256 VGPRs for the 9-dof arm, one at ~500 for the 11-dof arm; a "
+                 "third / second one spills) walking ~10 LDS-synchronised stages per unit, of which the role phase (nominal chain, "
+                 "Euler step, state differences: one lane per unit) is the longest",
     "backward": "not HBM: one wavefront per trajectory and SIMD walking the knots backwards (dependent chain); per knot 52 FP64 "
-                "MFMAs keep the matrix pipe busy 36 % of the time (the gfx950 FP64 MFMA rate equals the vector rate), the rest is "
-                "the LLT + triangular solves, the symmetrisation and the gap terms on the vector unit",
+                "MFMAs (the gfx950 FP64 MFMA rate equals the vector rate), the redundant per-lane LLT + triangular solves, the "
+                "symmetrisation and the gap terms, ~12 LDS hand-overs",
     "rollout": "not HBM: FP64 instruction issue of one wavefront per SIMD along the knot chain (a wave64 FP64 instruction "
                "occupies its SIMD for 4 cycles whatever the number of useful lanes); four role wavefronts per 6 trajectories, "
-               "two LDS barriers per knot, 60 of 64 lanes busy",
+               "two LDS barriers per knot, 60 of 64 lanes busy, 171 of 256 CUs at 1024 slots",
 }
+
+
+def limiter_text(kernel, pmc):
+    c = (pmc or {}).get(kernel) or {}
+    txt = LIMITERS[kernel]
+    if c.get("valu_active_frac") is not None:
+        txt += "; measured on full-batch launches: vector unit active %.0f %% of a wavefront's cycles, waiting %.0f %%, issue stalls %.0f %%" % (
+            100 * c["valu_active_frac"], 100 * c.get("wait_frac", 0.0), 100 * c.get("issue_stall_frac", 0.0))
+    return txt
 
 
 def main():
@@ -593,12 +603,20 @@ def main():
                          "unit_definition": "(trajectory, step length, knot): one launch rolls out all %d step lengths of "
                                             "the line search" % solver.stats_na() if dom == "rollout" else "(trajectory, knot)",
                          "avg_launch_ms": avg_ms,
-                         "limiter": LIMITERS[dom]},
+                         "limiter": limiter_text(dom, pmc)},
             "kernels": per_launch,
             "iteration_roofline": {"algorithmic_bytes_per_traj_knot_iter": words["iteration"] * 8,
                                    "achieved_GBs": iters_total * d.T * words["iteration"] * 8 / elapsed / 1e9 / world,
                                    "frac_of_8TBs": iters_total * d.T * words["iteration"] * 8 / elapsed / 1e9 / world / HBM_PEAK_GBS},
         }
+        if per_launch[dom].get("fp64_TFLOPs") is not None:
+            # compute side of the dominant kernel: FP64 flop issued per launch (SQ instruction counters of the committed PMC
+            # pass, scaled to this run's units per launch) over this run's launch time, against the FP64 vector peak
+            out["roofline"]["compute"] = {"bound": "fp64-valu", "achieved": per_launch[dom]["fp64_TFLOPs"], "peak": FP64_PEAK_TFLOPS,
+                                          "unit": "TFLOP/s", "frac": per_launch[dom]["fp64_frac_of_78.6TF"],
+                                          "flop_per_unit": per_launch[dom]["fp64_flop_per_unit"],
+                                          "valu_active_frac_of_wave_cycles": per_launch[dom]["valu_active_frac_of_wave_cycles"],
+                                          "source": "profiles/r04_pmc_%s.json" % args.config}
         if dist is not None:
             out["ranks_seen"] = ranks_seen
             out["ranks_matching_golden_vector"] = ranks_golden_ok
