@@ -67,7 +67,7 @@ case "$MODE" in
       rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_ANY --output-format csv -d $O/p_act_$CFG -- python3 bench.py $PARGS > /dev/null 2> $O/p_act_$CFG.err
       python3 tools/profile_summarize.py pmc $CFG $O/pmc_$CFG.json 1024 $T 10 $O/p_fetch_$CFG $O/p_write_$CFG $O/p_fp64_$CFG $O/p_act_$CFG | cut -c1-1500
     done
-    find $O -name "*.csv" -size +1M -delete; find $O -name "*.db" -delete; du -sh $O
+    find $O -name "*kernel_trace.csv" -size +1M -delete; find $O -name "*.csv" -size +6M -delete; find $O -name "*.db" -delete; du -sh $O
     ;;
   slots)
     # occupancy experiment: slots in flight per GPU x {shipped kernels (one wavefront per SIMD for the chain

@@ -125,24 +125,31 @@ def pmc(config, out, B, T, NA, dirs):
       valu_active_frac       SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES (both in quad-cycles): share of a wavefront's life with a
                              vector instruction in execution; wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES
     linearize = lean launch + full-body launch of one sweep (whichever exist)."""
-    rows = collections.defaultdict(lambda: collections.defaultdict(list))  # kernel -> counter -> values of full-grid launches
+    rows = collections.defaultdict(lambda: collections.defaultdict(list))  # kernel -> counter -> values of full-batch launches
     grids = collections.defaultdict(int)
-    recs = []
     for d in dirs:
         files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
         if not files:
             print("no counter_collection.csv under", d)
             continue
+        recs = []
         for r in csv.DictReader(open(max(files, key=os.path.getmtime))):
             k = short(r["Kernel_Name"])
-            if k not in ("k_linearize", "k_linearize_full", "k_backward", "k_rollout"):
-                continue
-            g = int(r["Grid_Size"])
-            grids[k] = max(grids[k], g)
-            recs.append((k, g, r["Counter_Name"], float(r["Counter_Value"])))
-    for k, g, c, v in recs:
-        if g == grids[k]:
-            rows[k][c].append(v)
+            if k in ("k_linearize", "k_linearize_full", "k_linearize_all", "k_backward", "k_rollout"):
+                recs.append((int(r["Dispatch_Id"]), k, int(r["Grid_Size"]), r["Counter_Name"], float(r["Counter_Value"])))
+                if k != "k_linearize_all":
+                    grids[k] = max(grids[k], int(r["Grid_Size"]))
+        # A sweep is linearize (one or two launches) -> backward -> rollout, in dispatch order.  The linearize grid follows the
+        # number of live slots (the backward / rollout grids do not: their surplus workgroups return at once), so a sweep counts
+        # as FULL when its linearize launch(es) have the largest grid seen; backward and rollout inherit the flag of the
+        # linearize launch that precedes them.
+        recs.sort()
+        full = False
+        for disp, k, g, c, v in recs:
+            if k.startswith("k_linearize"):
+                full = (k != "k_linearize_all") and g == grids[k]
+            if full and k != "k_linearize_all":
+                rows[k][c].append(v)
     mean = lambda k, c: (sum(rows[k][c]) / len(rows[k][c])) if rows[k].get(c) else None
     units = {"linearize": B * (T + 1), "backward": B * T, "rollout": B * NA * (T + 1)}
     res = {"config": config, "B": B, "T": T, "NA": NA, "kernels": {},
