@@ -4,6 +4,8 @@
 #                                displacement + push_slide, no CPU baseline (kernel comparison only)
 #   tools/gpu_r4.sh tests        GPU suite only
 #   tools/gpu_r4.sh profiles     rocprofv3 kernel stats + PMC passes behind profiles/r04_*
+#   tools/gpu_r4.sh lines        bench lines of hover and the three closed-loop MPC configurations
+#   tools/gpu_r4.sh slots        occupancy experiment (slots in flight x build variants)
 #   tools/gpu_r4.sh stamps       in-kernel cycle stamps (libempc_stamps.so)
 set -uo pipefail
 ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)}"
@@ -90,6 +92,12 @@ except Exception as e:
 PY
         done
       done
+    done
+    ;;
+  lines)
+    # the bench lines of the other configurations (profiles/r04_bench_<config>.json)
+    for cfg in ${CONFIGS:-hover carrot_mpc rail_mpc weighted_mpc}; do
+      bench_line "$cfg" "EMPC_X=0" --config $cfg --no-cpu-baseline --no-secondary --no-slots-sweep
     done
     ;;
   stamps)
