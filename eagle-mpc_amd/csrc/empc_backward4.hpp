@@ -53,19 +53,30 @@ struct Bwd4Smem {
   static constexpr int QS = 16 * NTQ + 1;       // row stride of Q
   static constexpr int WS = 16 * MTN + 1;       // row stride of the unsymmetrised Vxx
   static constexpr int KS = 16 * MTN + 1;       // row stride of -K
-  static constexpr int OFF_REC = 0;                                   // the record, flat, in whole 64-double rows (+ one row of slack)
-  static constexpr int OFF_V = (DM::REC + 63) / 64 * 64 + 64;         // [16 MTN][VS], zero outside n x n
+  // Q rows: the A-operand fetch of the Vxx stage touches 16 MTN rows, the accumulator store rows < nm rounded up to 4
+  static constexpr int QROWS = (16 * MTN > (nm + 3) / 4 * 4) ? 16 * MTN : (nm + 3) / 4 * 4;
+  static constexpr int OFF_REC = 0;                                   // the record, flat, in whole 64-double rows
+  // Aliases inside the record area (LDS per wavefront decides how many trajectories a CU holds: 4 only below 40 KB, and the
+  // 11-dof class was at 53 KB = 3 per CU = two rounds of workgroups for 1024 trajectories):
+  //  * W, the unsymmetrised Vxx, lives from the end of the Vxx stage to the symmetrise stage; [Fx Fu] and H (the record
+  //    in front of Lx / Lu / gap) are dead after the Q stage and the next record arrives after the symmetrise stage;
+  //  * the inverse of the free block of Quu (box solvers) sits behind W, also in front of OFF_LX;
+  //  * the prologue's partial sums are used before the first record is written.
+  static constexpr int WROWS = (n + 3) / 4 * 4;                       // accumulator rows of the Vxx tiles that are stored
+  static constexpr int OFF_W = OFF_REC;                               // [WROWS][WS]
+  static constexpr int OFF_HINV = OFF_W + WROWS * WS;                 // m x m
+  static constexpr int OFF_PRO = OFF_REC;                             // prologue reductions: 3 x 64
+  static_assert(OFF_HINV + m * m <= DM::OFF_LX, "W and Hinv must fit in front of the part of the record that stays live");
+  static constexpr int OFF_V = (DM::REC + 63) / 64 * 64;              // [16 MTN][VS], zero outside n x n
+  static_assert(3 * 64 <= OFF_V, "prologue sums inside the record area");
   static constexpr int OFF_VX = OFF_V + 16 * MTN * VS;                // [4 KSN], zero beyond n
-  static constexpr int OFF_Q = OFF_VX + 4 * KSN;                      // [16 MTQ][QS]
-  static constexpr int OFF_W = OFF_Q + 16 * MTQ * QS;                 // [16 MTN][WS]
-  static constexpr int OFF_KN = OFF_W + 16 * MTN * WS;                // [4 KSM][KS], zero outside m x n
+  static constexpr int OFF_Q = OFF_VX + 4 * KSN;                      // [QROWS][QS]
+  static constexpr int OFF_KN = OFF_Q + QROWS * QS;                   // [4 KSM][KS], zero outside m x n
   static constexpr int OFF_KF = OFF_KN + 4 * KSM * KS;                // k (m), Quuk (m)
   static constexpr int OFF_RED = OFF_KF + 2 * m;                      // 3 x 32 partial sums
   static constexpr int OFF_FLAG = OFF_RED + 96;
   static constexpr int OFF_ZERO = OFF_FLAG + 2;                       // a word that holds 0.0 (H entries outside the matrix)
-  static constexpr int OFF_HINV = OFF_ZERO + 2;                       // m x m: inverse of the free block of Quu (box solvers)
-  static constexpr int OFF_PRO = OFF_HINV + m * m;                    // prologue reductions: 3 x 64
-  static constexpr int SIZE = (OFF_PRO + 3 * 64 + 1) / 2 * 2;
+  static constexpr int SIZE = (OFF_ZERO + 2 + 1) / 2 * 2;
 };
 
 // BOX: the instantiation for crocoddyl's SolverBoxFDDP / SolverBoxDDP (box-QP gains); the squash-box solver's instantiation

@@ -153,9 +153,16 @@ __device__ __forceinline__ void lin_block(const DevBuffers& D, const int block, 
   const int i0 = (block % bpk) * UPB;  // position in the list of trajectories that linearize in this sweep
   const int nlist = D.lin_list ? *D.lin_count : D.B;
   if (i0 >= nlist) return;
-  const int u = threadIdx.x / LPU, lane = threadIdx.x % LPU;
+  int u = threadIdx.x / LPU;
+  const int lane = threadIdx.x % LPU;
+  // A unit that fills its wavefront (LPU = 64: the 11-dof class with contact dynamics) has a wave-uniform unit index: say so,
+  // and the trajectory index, the record pointer and the unit's LDS block live in scalar registers.  (Besides the registers
+  // it saves, this keeps those long-lived values out of the vector-register live-range splitting that, under the pressure
+  // of these instantiations, left the record pointer defined in lane 0 only -- DESIGN.md, round 4, "GPU memory fault".)
+  if constexpr (LPU == 64) u = __builtin_amdgcn_readfirstlane(u);
   bool active = i0 + u < nlist;
-  const int b = active ? (D.lin_list ? D.lin_list[i0 + u] : i0 + u) : (D.lin_list ? D.lin_list[i0] : i0);
+  int b = active ? (D.lin_list ? D.lin_list[i0 + u] : i0 + u) : (D.lin_list ? D.lin_list[i0] : i0);
+  if constexpr (LPU == 64) b = __builtin_amdgcn_readfirstlane(b);
   if (active) {
     const TrajState& st = D.st[b];
     active = !(st.phase == PHASE_DONE || !st.need_lin);
@@ -238,6 +245,48 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EMPC_BW
   extern __shared__ double smem_bwd4[];
   BlockExec ex{(int)threadIdx.x};
   backward_traj4<DM, BOX>(ex, D, blockIdx.x, smem_bwd4);
+}
+
+// The same pass with WPB trajectories per workgroup, one per wavefront and SIMD (EMPC_BWD_WPB=4): the wavefronts share
+// nothing (own LDS slice, wavefront-level ordering instead of workgroup barriers), but the workgroup takes a whole CU, so a
+// half batch occupies half of the CUs completely instead of half of every CU's SIMDs -- which leaves whole CUs to the
+// rollout workgroups (four role wavefronts, one per SIMD) of ANOTHER chunk of the batch running on its own stream.
+struct WaveExec {
+  int lane;
+  static constexpr int SLOTS = 1;
+  template <class F>
+  __device__ __forceinline__ void each(F&& f) {
+    __builtin_amdgcn_sched_barrier(0);
+    f(lane, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __device__ __forceinline__ void sync() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    wave_sync();  // LDS operations of one wavefront complete in order: only the compiler has to keep them in order
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  template <class F>
+  __device__ __forceinline__ bool any(F&& f) {
+    return __builtin_amdgcn_ballot_w64(f(lane, 0)) != 0;
+  }
+  template <class A, class B, class C>
+  __device__ __forceinline__ void mfma(A& a, int ia, B& b, int ib, C& c, int im, int in) {
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    d4 v = {c[0][im][in][0], c[0][im][in][1], c[0][im][in][2], c[0][im][in][3]};
+    v = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][ia], b[0][ib], v, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c[0][im][in][r] = v[r];
+  }
+};
+template <class DM, bool BOX, int WPB>
+__global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(1, 1))) k_backward4w(DevBuffers D) {
+  extern __shared__ double smem_bwd4w[];
+  const int w = (int)threadIdx.x / 64;
+  const int b = (int)blockIdx.x * WPB + w;
+  if (b >= D.B) return;
+  WaveExec ex{(int)threadIdx.x % 64};
+  backward_traj4<DM, BOX>(ex, D, b, smem_bwd4w + (size_t)w * Bwd4Smem<DM>::SIZE);
 }
 
 template <class DM>
@@ -463,6 +512,18 @@ static void launch_rk4_linearize(DevBuffers D, Rk4Buffers R, hipStream_t s) {
 
 template <class DM>
 static void launch_backward(DevBuffers D, hipStream_t s) {
+  constexpr int WPB = 4;
+  constexpr size_t smem4 = sizeof(double) * Bwd4Smem<DM>::SIZE * WPB;
+  static const bool cu_exclusive = [] {
+    const char* e = getenv("EMPC_BWD_WPB");  // 4 = one workgroup per CU (four trajectories), 1 = one wavefront per workgroup
+    const bool on = e && atoi(e) == WPB && smem4 <= 160 * 1024;
+    if (on) (void)hipFuncSetAttribute((const void*)k_backward4w<DM, false, WPB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem4);
+    return on;
+  }();
+  if (cu_exclusive && D.solver_type == EMPC_SOLVER_SBFDDP) {
+    hipLaunchKernelGGL((k_backward4w<DM, false, WPB>), dim3((D.B + WPB - 1) / WPB), dim3(64 * WPB), smem4, s, D);
+    return;
+  }
   if (D.solver_type != EMPC_SOLVER_SBFDDP)  // the BoxQP gains: their own instantiation
     hipLaunchKernelGGL((k_backward4<DM, true>), dim3(D.B), dim3(64), sizeof(double) * Bwd4Smem<DM>::SIZE, s, D);
   else

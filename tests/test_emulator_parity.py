@@ -76,6 +76,15 @@ def test_contact_options_kernel_bodies_vs_oracle(empc, emu, tmp_path, contact, g
     kernel_bodies(emu, problem, "eagle_catch", 2, 4, 6)
 
 
+@pytest.mark.parametrize("contact,gains", [("ContactModel3D", (7.0, 3.0)), ("ContactModel6D", (0.0, 0.0))])
+def test_arm5_contact_kernel_bodies_vs_oracle(empc, emu, tmp_path, contact, gains):
+    """Contact dynamics on the 11-dof arm class (64 lanes per linearize unit; empc_inst_6_6_contact*.hip) through the kernel
+    bodies: tape / gains / rollouts against the oracle.  The GPU-only fault of round 4 lived in code only this class runs."""
+    from conftest import arm5_contact_variant
+    _, problem = arm5_contact_variant(empc, tmp_path, contact, gains)
+    kernel_bodies(emu, problem, "eagle_catch", 2, 4, 6)  # ("eagle_catch": phases only, no emulated solve)
+
+
 def test_unweighted_quadratic_barrier_kernel_bodies(empc, emu, tmp_path):
     """ActivationModelQuadraticBarrier (bounds, no weights; src/factory/activation.cpp:53-68) through the kernel bodies"""
     from conftest import unweighted_barrier_variant

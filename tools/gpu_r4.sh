@@ -100,6 +100,16 @@ PY
       bench_line "$cfg" "EMPC_X=0" --config $cfg --no-cpu-baseline --no-secondary --no-slots-sweep
     done
     ;;
+  overlap)
+    # chunks of the batch on their own streams x the CU-exclusive backward launch (four trajectories per workgroup): does the
+    # rollout of one chunk (171 of 256 CUs at a full batch) run beside the backward pass of another?
+    for CFG in ${CONFIGS:-eagle_catch displacement}; do
+      for V in ${VARIANTS:-1:1 4:1 1:2 4:2 4:3 4:4}; do
+        W=${V%%:*}; NS=${V##*:}
+        bench_line "${CFG}_wpb${W}_streams${NS}" "EMPC_BWD_WPB=$W EMPC_STREAMS=$NS" --config $CFG --no-cpu-baseline --no-secondary --no-slots-sweep --no-single-batch --steps ${OV_STEPS:-10}
+      done
+    done
+    ;;
   stamps)
     # phase-level launches: product library first (ms per launch), then the diagnostic build with in-kernel cycle stamps
     for c in displacement eagle_catch; do
