@@ -68,7 +68,7 @@ struct Bwd4Smem {
   static constexpr int OFF_PRO = OFF_REC;                             // prologue reductions: 3 x 64
   static_assert(OFF_HINV + m * m <= DM::OFF_LX, "W and Hinv must fit in front of the part of the record that stays live");
   static constexpr int OFF_V = (DM::REC + 63) / 64 * 64;              // [16 MTN][VS], zero outside n x n
-  static_assert(3 * 64 <= OFF_V, "prologue sums inside the record area");
+  static_assert(5 * 64 <= OFF_V, "prologue sums / end-of-pass sums inside the record area");
   static constexpr int OFF_VX = OFF_V + 16 * MTN * VS;                // [4 KSN], zero beyond n
   static constexpr int OFF_Q = OFF_VX + 4 * KSN;                      // [QROWS][QS]
   static constexpr int OFF_KN = OFF_Q + QROWS * QS;                   // [4 KSM][KS], zero outside m x n
@@ -171,10 +171,15 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
 
   double xreg = st.xreg, ureg = st.ureg;
   double dg_u = 0, dq_u = 0, dg_f = 0, dq_f = 0, qu2 = 0;
+  // The sums of the expected improvement and of the stopping criterion (sum_t Qu.k, k.Quu k, Qu.Qu, Vx.f, f.Vxx f) are kept
+  // per lane -- lane i adds ITS term of every knot -- and the lanes' totals are added once, after the last knot.  (Rounds 2-3:
+  // every lane read all 2 x (m + n) terms of a knot back from LDS and added them, 1.2k of a knot's 13.5k cycles.)
+  double dgu_l[Exec::SLOTS], dqu_l[Exec::SLOTS], qu2_l[Exec::SLOTS], dgf_l[Exec::SLOTS], dqf_l[Exec::SLOTS];
   bool failed_final = false;
   while (true) {
     bool fail = false;
     dg_u = dq_u = dg_f = dq_f = qu2 = 0;
+    ex.each([&](int lane, int sl) { dgu_l[sl] = dqu_l[sl] = qu2_l[sl] = dgf_l[sl] = dqf_l[sl] = 0.0; });
     // ---- terminal node ---------------------------------------------------------------------------------------
     {
       const double* r = tape + (size_t)T * REC;
@@ -195,18 +200,16 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
         const double nv = vx[lane] + (infeas ? a_ : 0.0);
         D.Vf[((size_t)b * (T + 1) + T) * n + lane] = a_;
         D.Vx[((size_t)b * (T + 1) + T) * n + lane] = nv;
-        red[lane] = infeas ? nv * red[64 + lane] : 0.0;
-        red[32 + lane] = infeas ? red[64 + lane] * a_ : 0.0;
+        if (infeas) {
+          dgf_l[sl] -= nv * red[64 + lane];
+          dqf_l[sl] += red[64 + lane] * a_;
+        }
         Q[lane] = nv;              // staged: vx is still being read by the other lanes
       });
       ex.sync();
       ex.each([&](int lane, int sl) {
         if (lane < n) vx[lane] = Q[lane];
       });
-      for (int i = 0; i < n; ++i) {
-        dg_f -= red[i];
-        dq_f += red[32 + i];
-      }
       ex.sync();
     }
     // first record of the sweep
@@ -427,11 +430,17 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
             kv[j] = kf[j];
           }
           const double kl = kf[lane];
+          const double ql = Q[(n + lane) * QS + nm];  // Qu of this control (zeroed on a clamped one by the box path)
           BWD_FENCE();
           double a_ = 0;
 #pragma unroll
           for (int j = 0; j < m; ++j) a_ += qrow[j] * kv[j];
-          kf[m + lane] = a_ + ureg * kl;
+          const double qk = a_ + ureg * kl;
+          kf[m + lane] = qk;
+          // this control's terms of the sums (a pass that fails at this knot starts over with the sums at zero)
+          dgu_l[sl] += ql * kl;
+          dqu_l[sl] -= kl * qk;
+          qu2_l[sl] += ql * ql;
         }
       });
       ex.sync();
@@ -439,22 +448,6 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
       if (flag[0] != 0.0) {
         fail = true;
         break;
-      }
-      {
-        double quv[m], kv[m], qkv[m];
-#pragma unroll
-        for (int i = 0; i < m; ++i) {
-          quv[i] = Q[(n + i) * QS + nm];
-          kv[i] = kf[i];
-          qkv[i] = kf[m + i];
-        }
-        BWD_FENCE();
-#pragma unroll
-        for (int i = 0; i < m; ++i) {
-          dg_u += quv[i] * kv[i];
-          dq_u -= kv[i] * qkv[i];
-          qu2 += quv[i] * quv[i];
-        }
       }
       BWD_STAMP(3);
       // Vx = Qx + K^T Quuk - 2 K^T Qu from the lane's own column; Vxx = Qxx + (Qxu)(-K) on the matrix cores: the Qxx tiles
@@ -567,34 +560,16 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
         vx[lane] = nv;
         vfo[sl] = a_;
         vxo[sl] = nv;
-        red[lane] = infeas ? nv * rec[DM::OFF_GAP + lane] : 0.0;
-        red[32 + lane] = infeas ? rec[DM::OFF_GAP + lane] * a_ : 0.0;
+        if (infeas) {  // (with closed gaps every term would be an exact zero)
+          const double g = rec[DM::OFF_GAP + lane];
+          dgf_l[sl] -= nv * g;
+          dqf_l[sl] += g * a_;
+        }
         badl[sl] = badl[sl] || bad_number(nv);  // NaN, inf or >= 1e30 in Vx (crocoddyl's raiseIfNaN on max |Vx|)
       });
       BWD_STAMP(13);
       const bool badAny = ex.any([&](int lane, int sl) { return badl[sl]; });
       BWD_STAMP(14);
-      if (infeas) {  // same order of summation as backward3; with closed gaps every term would be an exact zero
-        constexpr int CH = 6;
-#pragma unroll
-        for (int i0 = 0; i0 < n; i0 += CH) {
-          double ra[CH], rb[CH];
-#pragma unroll
-          for (int i = 0; i < CH; ++i)
-            if (i0 + i < n) {
-              ra[i] = red[i0 + i];
-              rb[i] = red[32 + i0 + i];
-            }
-          BWD_FENCE();
-#pragma unroll
-          for (int i = 0; i < CH; ++i)
-            if (i0 + i < n) {
-              dg_f -= ra[i];
-              dq_f += rb[i];
-            }
-          BWD_FENCE();
-        }
-      }
       if (badAny) {
         fail = true;
         break;
@@ -610,7 +585,28 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
       });
 #endif
     ex.sync();
-    if (!fail) break;
+    if (!fail) {
+      // lanes' totals -> the five sums, added in lane order (the record area is dead after the last knot)
+      ex.each([&](int lane, int sl) {
+        rec[lane] = dgu_l[sl];
+        rec[64 + lane] = dqu_l[sl];
+        rec[128 + lane] = qu2_l[sl];
+        rec[192 + lane] = dgf_l[sl];
+        rec[256 + lane] = dqf_l[sl];
+      });
+      ex.sync();
+      for (int i = 0; i < m; ++i) {
+        dg_u += rec[i];
+        dq_u += rec[64 + i];
+        qu2 += rec[128 + i];
+      }
+      for (int i = 0; i < n; ++i) {
+        dg_f += rec[192 + i];
+        dq_f += rec[256 + i];
+      }
+      ex.sync();
+      break;
+    }
     xreg *= P.prm.reg_incfactor;
     if (xreg > P.prm.reg_max) xreg = P.prm.reg_max;
     ureg = xreg;
