@@ -44,6 +44,16 @@ namespace empc {
   } while (0)
 #endif
 
+// two doubles that travel together (one 16-byte global load, one 16-byte LDS write): records are 128-byte aligned
+// (a native vector type on the device: an array of 16-byte structs indexed by an unrolled loop stays in scratch memory)
+#if defined(__HIPCC__)
+typedef double Bwd4Pair __attribute__((ext_vector_type(2)));
+#else
+struct alignas(16) Bwd4Pair {
+  double a, b;
+};
+#endif
+
 template <class DM>
 struct Bwd4Smem {
   static constexpr int n = DM::NDX, m = DM::NU, nm = n + m;
@@ -67,7 +77,7 @@ struct Bwd4Smem {
   static constexpr int OFF_HINV = OFF_W + WROWS * WS;                 // m x m
   static constexpr int OFF_PRO = OFF_REC;                             // prologue reductions: 3 x 64
   static_assert(OFF_HINV + m * m <= DM::OFF_LX, "W and Hinv must fit in front of the part of the record that stays live");
-  static constexpr int OFF_V = (DM::REC + 63) / 64 * 64;              // [16 MTN][VS], zero outside n x n
+  static constexpr int OFF_V = (DM::REC + 127) / 128 * 128;           // [16 MTN][VS], zero outside n x n
   static_assert(5 * 64 <= OFF_V, "prologue sums / end-of-pass sums inside the record area");
   static constexpr int OFF_VX = OFF_V + 16 * MTN * VS;                // [4 KSN], zero beyond n
   static constexpr int OFF_Q = OFF_VX + 4 * KSN;                      // [QROWS][QS]
@@ -87,7 +97,7 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
   constexpr int NL = 64;
   constexpr int n = DM::NDX, m = DM::NU, nm = n + m, REC = DM::REC;
   static_assert(nm <= 47 && n <= 32, "tile counts of the matrix-core backward pass");
-  constexpr int PRE = (REC + NL - 1) / NL;  // prefetch registers per lane
+  constexpr int PRE = (REC + 2 * NL - 1) / (2 * NL);  // prefetch register PAIRS per lane: the record moves in 16-byte pieces
   constexpr int MTN = SM::MTN, MTQ = SM::MTQ, NTQ = SM::NTQ, KSN = SM::KSN, KSM = SM::KSM;
   constexpr int VS = SM::VS, QS = SM::QS, WS = SM::WS, KS = SM::KS;
   TrajState& st = D.st[b];
@@ -168,6 +178,27 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
     for (int i = lane; i < SM::SIZE - SM::OFF_V; i += NL) smem[SM::OFF_V + i] = 0.0;
   });
   ex.sync();
+  // symmetrise stage: entry (i, j), i <= j, of the upper triangle per lane and round; offsets of W[i][j], W[j][i], V[i][j], V[j][i]
+  // (-1: no entry).  One read pair and one average serve both halves (a + b == b + a bit for bit).
+  constexpr int NTRI = n * (n + 1) / 2, NSY = (NTRI + NL - 1) / NL;
+  int sy_w[Exec::SLOTS][NSY][2], sy_v[Exec::SLOTS][NSY][2];
+  ex.each([&](int lane, int sl) {
+#pragma unroll
+    for (int q = 0; q < NSY; ++q) {
+      int idx = lane + q * NL, i = 0;
+      const bool on = idx < NTRI;
+      if (!on) idx = 0;
+      while (idx >= n - i) {
+        idx -= n - i;
+        ++i;
+      }
+      const int j = i + idx;
+      sy_w[sl][q][0] = on ? i * WS + j : -1;
+      sy_w[sl][q][1] = j * WS + i;
+      sy_v[sl][q][0] = i * VS + j;
+      sy_v[sl][q][1] = (i == j) ? -1 : j * VS + i;  // -1 marks a diagonal entry: regularised, written once
+    }
+  });
 
   double xreg = st.xreg, ureg = st.ureg;
   double dg_u = 0, dq_u = 0, dg_f = 0, dq_f = 0, qu2 = 0;
@@ -213,11 +244,11 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
       ex.sync();
     }
     // first record of the sweep
-    double pre[Exec::SLOTS][PRE];
+    Bwd4Pair pre[Exec::SLOTS][PRE];
     ex.each([&](int lane, int sl) {
-      const double* r = tape + (size_t)(T - 1) * REC;
+      const Bwd4Pair* r = reinterpret_cast<const Bwd4Pair*>(tape + (size_t)(T - 1) * REC);
 #pragma unroll
-      for (int q = 0; q < PRE; ++q) pre[sl][q] = r[lane + q * NL];  // whole rows: the tape has one row of slack
+      for (int q = 0; q < PRE; ++q) pre[sl][q] = r[lane + q * NL];  // whole 128-double rows: they end inside the next record
     });
 #if defined(EMPC_STAMPS) && defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
     unsigned long long bst[16];
@@ -244,10 +275,10 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
       BWD_STAMP(7);
       ex.each([&](int lane, int sl) {
 #pragma unroll
-        for (int q = 0; q < PRE; ++q) rec[lane + q * NL] = pre[sl][q];
+        for (int q = 0; q < PRE; ++q) reinterpret_cast<Bwd4Pair*>(rec)[lane + q * NL] = pre[sl][q];
         if (t < T - 1) flush_outputs(t + 1, lane, sl);
         if (t > 0) {
-          const double* r = tape + (size_t)(t - 1) * REC;
+          const Bwd4Pair* r = reinterpret_cast<const Bwd4Pair*>(tape + (size_t)(t - 1) * REC);
 #pragma unroll
           for (int q = 0; q < PRE; ++q) pre[sl][q] = r[lane + q * NL];
         }
@@ -509,23 +540,22 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
       bool badl[Exec::SLOTS];
       ex.each([&](int lane, int sl) {
         bool bad = false;
-        constexpr int NS = (n * n + NL - 1) / NL;
-        double wa[NS], wb[NS];
+        double wa[NSY], wb[NSY];
 #pragma unroll
-        for (int q = 0; q < NS; ++q) {
-          const int i = lane + q * NL, ic = i < n * n ? i : 0;
-          const int rr = ic / n, cc = ic % n;
-          wa[q] = W[rr * WS + cc];
-          wb[q] = W[cc * WS + rr];
+        for (int q = 0; q < NSY; ++q) {
+          const int oa = sy_w[sl][q][0];
+          wa[q] = W[oa < 0 ? 0 : oa];
+          wb[q] = W[sy_w[sl][q][1]];
         }
         BWD_FENCE();
 #pragma unroll
-        for (int q = 0; q < NS; ++q) {
-          const int i = lane + q * NL;
-          if (i < n * n) {
-            const int rr = i / n, cc = i % n;
-            const double v_ = 0.5 * (wa[q] + wb[q]) + ((rr == cc) ? xreg : 0.0);
-            V[rr * VS + cc] = v_;
+        for (int q = 0; q < NSY; ++q) {
+          if (sy_w[sl][q][0] >= 0) {
+            const bool diag = sy_v[sl][q][1] < 0;
+            const double h = 0.5 * (wa[q] + wb[q]);
+            const double v_ = diag ? h + xreg : h;
+            V[sy_v[sl][q][0]] = v_;
+            if (!diag) V[sy_v[sl][q][1]] = v_;
             bad = bad || bad_number(v_);
           }
         }
@@ -538,8 +568,7 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
         if (lane >= n) return;
         double a_ = 0;
         if (infeas) {
-          constexpr int CH = 6;
-          static_assert(n % CH == 0 || true, "");
+          constexpr int CH = (n + 1) / 2;  // two blocks of reads (round 3: three)
 #pragma unroll
           for (int j0 = 0; j0 < n; j0 += CH) {
             double vv[CH], gg[CH];

@@ -224,9 +224,11 @@ struct BlockExec {
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
   }
+  // (the workgroups of this executor are ONE wavefront: a ballot answers "any lane?" without the LDS reduction and the
+  //  barrier __syncthreads_or compiles to -- 300 cycles per knot of the backward pass)
   template <class F>
   __device__ __forceinline__ bool any(F&& f) {
-    return __syncthreads_or(f(lane, 0) ? 1 : 0) != 0;
+    return __builtin_amdgcn_ballot_w64(f(lane, 0)) != 0;
   }
   // one v_mfma_f64_16x16x4_f64 of the wavefront: acc[im][in] += A-operand a[ia] x B-operand b[ib] (per-lane values)
   template <class A, class B, class C>

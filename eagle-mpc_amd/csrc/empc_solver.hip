@@ -342,7 +342,7 @@ EmpcSolver* empc_solver_create(const EmpcProblemDesc* problem, const EmpcSolverP
   D.xs = s->dalloc<double>(B * (T + 1) * k.nx);
   D.us = s->dalloc<double>(B * T * k.nu);
   D.acc = s->dalloc<double>(B * (T + 1) * k.nacc);
-  D.tape = s->dalloc<double>(B * (T + 1) * k.rec + 64);  // + one wavefront of slack: the backward pass prefetches whole 64-double rows
+  D.tape = s->dalloc<double>(B * (T + 1) * k.rec + 128);  // + slack: the backward pass prefetches whole 128-double rows
   D.K = s->dalloc<double>(B * T * k.nu * k.ndx);
   D.kff = s->dalloc<double>(B * T * k.nu);
   D.Vx = s->dalloc<double>(B * (T + 1) * k.ndx);
@@ -376,7 +376,7 @@ EmpcSolver* empc_solver_create(const EmpcProblemDesc* problem, const EmpcSolverP
     s->R4.ys = s->dalloc<double>(4 * B * (T + 1) * k.nx);
     s->R4.accs = s->dalloc<double>(4 * B * (T + 1) * k.nacc);
     s->R4.us4 = s->dalloc<double>(4 * B * T * k.nu);
-    s->R4.tape4 = s->dalloc<double>(4 * B * (T + 1) * k.rec + 64);
+    s->R4.tape4 = s->dalloc<double>(4 * B * (T + 1) * k.rec + 128);
     s->R4.st4 = s->dalloc<TrajState>(4 * B);
     HIP_CHECK(hipMemsetAsync(s->R4.tape4, 0, sizeof(double) * 4 * B * (T + 1) * k.rec, s->stream));
     HIP_CHECK(hipMemsetAsync(s->R4.accs, 0, sizeof(double) * 4 * B * (T + 1) * k.nacc, s->stream));

@@ -105,7 +105,7 @@ static void emu_alloc(Emu& e) {
   e.xs.assign((size_t)B * (T + 1) * DM::NX, 0);
   e.us.assign((size_t)B * T * DM::NU, 0);
   e.acc.assign((size_t)B * (T + 1) * DM::NACC, 0);
-  e.tape.assign((size_t)B * (T + 1) * DM::REC + 64, 0);  // slack for the backward pass's whole-row prefetch
+  e.tape.assign((size_t)B * (T + 1) * DM::REC + 128, 0);  // slack for the backward pass's whole-row prefetch
   e.K.assign((size_t)B * T * DM::NU * DM::NDX, 0);
   e.kff.assign((size_t)B * T * DM::NU, 0);
   e.Vx.assign((size_t)B * (T + 1) * DM::NDX, 0);
@@ -188,7 +188,7 @@ template <class DM>
 static void emu_linearize_rk4(Emu& e) {
   const size_t B = e.B, T = e.T;
   std::vector<double> ys(4 * B * (T + 1) * DM::NX, 0.0), accs(4 * B * (T + 1) * DM::NACC, 0.0), us4(4 * B * T * DM::NU, 0.0),
-      tape4(4 * B * (T + 1) * DM::REC + 64, 0.0);
+      tape4(4 * B * (T + 1) * DM::REC + 128, 0.0);
   std::vector<TrajState> st4(4 * B);
   Rk4Buffers R{ys.data(), accs.data(), us4.data(), tape4.data(), st4.data()};
   const bool ct = e.H.P.has_contact != 0;
@@ -557,7 +557,7 @@ void emu_phase_linearize(void* h, double* tape, double* acc) {
   Emu* e = static_cast<Emu*>(h);
   DISPATCH(e, emu_calc, *e);
   DISPATCH(e, emu_linearize, *e);
-  if (tape) std::memcpy(tape, e->tape.data(), sizeof(double) * (e->tape.size() - 64));
+  if (tape) std::memcpy(tape, e->tape.data(), sizeof(double) * (e->tape.size() - 128));
   if (acc) {
     const int nacc = e->nv + 6;
     for (size_t u = 0; u < (size_t)e->B * (e->T + 1); ++u) std::memcpy(acc + u * e->nv, &e->acc[u * nacc], sizeof(double) * e->nv);
@@ -624,7 +624,7 @@ void emu_get_trials(void* h, double* cost, double* dv, int* ok) {
 }
 void emu_get_tape(void* h, double* tape) {
   Emu* e = static_cast<Emu*>(h);
-  std::memcpy(tape, e->tape.data(), sizeof(double) * (e->tape.size() - 64));
+  std::memcpy(tape, e->tape.data(), sizeof(double) * (e->tape.size() - 128));
 }
 void emu_get_gains(void* h, double* K, double* k, double* Vx) {
   Emu* e = static_cast<Emu*>(h);
