@@ -87,6 +87,7 @@ struct Bwd4Smem {
   static constexpr int OFF_FLAG = OFF_RED + 96;
   static constexpr int OFF_ZERO = OFF_FLAG + 2;                       // a word that holds 0.0 (H entries outside the matrix)
   static constexpr int SIZE = (OFF_ZERO + 2 + 1) / 2 * 2;
+  static_assert(4 * sizeof(double) * SIZE <= 160 * 1024, "four trajectories (one per SIMD) must fit the LDS of a CU: a class beyond that runs in two rounds");
 };
 
 // BOX: the instantiation for crocoddyl's SolverBoxFDDP / SolverBoxDDP (box-QP gains); the squash-box solver's instantiation

@@ -675,20 +675,17 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
       // wavefront 0: chain; 1: Euler step + Lie Jacobians; the last: gaps (with four wavefronts it has nothing else to do;
       // with fewer it is the Euler wavefront again); RW - 1: state differences
       constexpr int NWV = (RW >= 3) ? 4 : RW;
-#ifndef EMPC_DBG_SKIP
-#define EMPC_DBG_SKIP 0
-#endif
       if (wv == 0) {
-        if (!(EMPC_DBG_SKIP & 1) && live(wl)) chain_section(RL->base + (size_t)wl * RL->usz);
+        if (live(wl)) chain_section(RL->base + (size_t)wl * RL->usz);
       } else if (wv == 1) {
-        if (!(EMPC_DBG_SKIP & 2) && live(wl)) euler_section(RL->base + (size_t)wl * RL->usz);
+        if (live(wl)) euler_section(RL->base + (size_t)wl * RL->usz);
       }
       if (wv == (NWV == 4 ? 3 : 1)) {
-        if (!(EMPC_DBG_SKIP & 4) && live(wl)) gap_section(RL->base + (size_t)wl * RL->usz, traj(wl), feasible(wl));
+        if (live(wl)) gap_section(RL->base + (size_t)wl * RL->usz, traj(wl), feasible(wl));
       }
       if (wv == RW - 1) {
         const int u = wl / SM::NSLOT, q = wl % SM::NSLOT;
-        if (!(EMPC_DBG_SKIP & 8) && live(u)) owner_section(RL->base + (size_t)u * RL->usz, 0, q);
+        if (live(u)) owner_section(RL->base + (size_t)u * RL->usz, 0, q);
       }
     }
   };
