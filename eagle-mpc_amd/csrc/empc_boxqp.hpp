@@ -42,6 +42,7 @@ EMPC_HD bool box_qp_lane(const double* H, const double* q, const double* lb, con
     return true;
   };
   auto invert_free = [&]() {
+#pragma unroll
     for (int c = 0; c < M; ++c) {
       double col[M];
 #pragma unroll
@@ -53,6 +54,7 @@ EMPC_HD bool box_qp_lane(const double* H, const double* q, const double* lb, con
   };
   auto fval = [&](const double* z) {
     double f = 0;
+#pragma unroll
     for (int i = 0; i < M; ++i) {
       double a = 0;
 #pragma unroll
@@ -61,9 +63,13 @@ EMPC_HD bool box_qp_lane(const double* H, const double* q, const double* lb, con
     }
     return f;
   };
+  // One exit: every way out of the iteration ends in the same `invert_free` (one copy of its code; with the loops above
+  // unrolled every array is indexed by compile-time constants and lives in registers -- rounds 2-3 kept them in scratch memory)
+  bool want_inv = false;
   for (int k = 0; k < maxiter; ++k) {
     double gmax = 0;
     int nf = 0;
+#pragma unroll
     for (int i = 0; i < M; ++i) {
       double a = q[i];
 #pragma unroll
@@ -77,21 +83,16 @@ EMPC_HD bool box_qp_lane(const double* H, const double* q, const double* lb, con
       free_mask[j] = clamped ? 0 : 1;
       nf += free_mask[j];
     }
+    // the factorisation of an unchanged free set is the one already held
+    bool same = have_inv;
+#pragma unroll
+    for (int i = 0; i < M; ++i) same = same && prev_mask[i] == free_mask[i];
+    if (!same) ok = factor_free(free_mask);
     if (gmax <= th_grad || nf == 0) {
-      bool same = have_inv;
-#pragma unroll
-      for (int i = 0; i < M; ++i) same = same && prev_mask[i] == free_mask[i];
-      if (!same) ok = factor_free(free_mask);
-      if (ok) invert_free();
-      return ok;
+      want_inv = ok;
+      break;
     }
-    {
-      // the factorisation of an unchanged free set is the one already held
-      bool same = have_inv;
-#pragma unroll
-      for (int i = 0; i < M; ++i) same = same && prev_mask[i] == free_mask[i];
-      if (!same && !factor_free(free_mask)) return false;
-    }
+    if (!ok) return false;
     // Newton step on the free space: dxf = -Hff^-1 (qf + Hfc xc) - xf (the clamped rows of the factor are unit pivots)
     {
       double r[M];
@@ -128,12 +129,11 @@ EMPC_HD bool box_qp_lane(const double* H, const double* q, const double* lb, con
     }
     // an iteration that left x where it was repeats itself (same gradient, same free set, same step) until maxiter: the
     // result is the one at hand (a control clamped with a non-zero multiplier keeps the gradient norm above th_grad for ever)
-    if (!moved) {
-      invert_free();
-      return true;
-    }
+    want_inv = have_inv;  // (the exit by maxiter: whatever factor is held)
+    if (!moved) break;
   }
-  if (have_inv) invert_free();
+  if (!ok) return false;
+  if (want_inv) invert_free();
   return true;
 }
 
