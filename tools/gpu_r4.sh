@@ -4,6 +4,7 @@
 #                                displacement + push_slide, no CPU baseline (kernel comparison only)
 #   tools/gpu_r4.sh tests        GPU suite only
 #   tools/gpu_r4.sh profiles     rocprofv3 kernel stats + PMC passes behind profiles/r04_*
+#   tools/gpu_r4.sh final        check + profiles + lines (then: bash tools/keep_r04.sh <tag> copies the summaries to profiles/)
 #   tools/gpu_r4.sh lines        bench lines of hover and the three closed-loop MPC configurations
 #   tools/gpu_r4.sh slots        occupancy experiment (slots in flight x build variants)
 #   tools/gpu_r4.sh stamps       in-kernel cycle stamps (libempc_stamps.so)
@@ -109,6 +110,12 @@ PY
         bench_line "${CFG}_wpb${W}_streams${NS}" "EMPC_BWD_WPB=$W EMPC_STREAMS=$NS" --config $CFG --no-cpu-baseline --no-secondary --no-slots-sweep --no-single-batch --steps ${OV_STEPS:-10}
       done
     done
+    ;;
+  final)
+    # everything the committed round-4 artefacts come from, in one call: GPU suite, default bench line, profiles, other lines
+    bash "$0" check "$TAG"
+    bash "$0" profiles "$TAG"
+    bash "$0" lines "$TAG"
     ;;
   stamps)
     # phase-level launches: product library first (ms per launch), then the diagnostic build with in-kernel cycle stamps
