@@ -75,7 +75,9 @@ case "$MODE" in
   slots)
     # occupancy experiment: slots in flight per GPU x {shipped kernels (one wavefront per SIMD for the chain
     # kernels), libempc_w2.so = backward and rollout compiled for two (256 registers, spills)}; trajectory-iterations/s / 1024
-    for LIBV in ${SLOT_LIBS:-default "$ROOT/eagle-mpc_amd/libempc_w2.so"}; do
+    # (the two-wavefront variant is not kept built: make -C eagle-mpc_amd BUILD=build_w2 LIB=libempc_w2.so EXTRA="-DEMPC_ROLL_WAVES=2 -DEMPC_BWD_WAVES=2",
+    #  then SLOT_LIBS="default $PWD/eagle-mpc_amd/libempc_w2.so")
+    for LIBV in ${SLOT_LIBS:-default}; do
       [ "$LIBV" = default ] && LIBV=""
       for CFG in ${CONFIGS:-eagle_catch displacement}; do
         for B in 1024 2048 4096; do
