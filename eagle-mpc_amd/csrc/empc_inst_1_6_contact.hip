@@ -1,0 +1,5 @@
+// Kernel instantiation for (bodies, rotors, contact dynamics) = Dims<1, 6>: ContactModel3D and ContactModel6D stages behind the branch on the node's
+// contact type (CT_MIXED).  No shipped file puts a contact on this robot class; the factory accepts one (src/factory/contacts.cpp:26-79).
+#define EMPC_INSTANTIATE
+#include "empc_launch.hpp"
+KernelTable empc_table_1_6_contact() { return make_table<Dims<1, 6>, CT_MIXED>(); }

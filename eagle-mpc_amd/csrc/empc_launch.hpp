@@ -43,6 +43,9 @@ struct KernelTable {
 KernelTable empc_table_1_4();
 KernelTable empc_table_1_6();
 KernelTable empc_table_3_6();
+KernelTable empc_table_1_4_contact();  // (both contact types behind a branch: CT_MIXED)
+KernelTable empc_table_1_6_contact();
+KernelTable empc_table_3_6_contact();
 KernelTable empc_table_4_6();
 KernelTable empc_table_4_6_contact();
 KernelTable empc_table_4_6_contact6();

@@ -94,6 +94,11 @@ static bool find_table(const DevProblem& P, int nb, int nrot, bool contact, int 
   if (nb == 1 && nrot == 4 && !contact) k = empc_table_1_4();
   else if (nb == 1 && nrot == 6 && !contact) k = empc_table_1_6();
   else if (nb == 3 && nrot == 6 && !contact) k = empc_table_3_6();
+  // contact dynamics on the single-body and two-joint classes: one instantiation per class serves ContactModel3D, ContactModel6D
+  // and problems mixing them (the branch on the node's contact type costs nothing next to the dynamics; no shipped file is here)
+  else if (nb == 1 && nrot == 4 && contact) k = empc_table_1_4_contact();
+  else if (nb == 1 && nrot == 6 && contact) k = empc_table_1_6_contact();
+  else if (nb == 3 && nrot == 6 && contact) k = empc_table_3_6_contact();
   else if (nb == 4 && nrot == 6 && !contact) k = empc_table_4_6();
   else if (nb == 4 && nrot == 6 && contact && contact_rows == empc::CT_MIXED) k = empc_table_4_6_contact_mixed();
   else if (nb == 4 && nrot == 6 && contact && contact_rows != 6) k = empc_table_4_6_contact();

@@ -140,6 +140,65 @@ def arm5_contact_variant(empc, tmp_path, contact="ContactModel3D", gains=(0.0, 0
     return tr, tr.createProblem(dt, True, "IntegratedActionModelEuler")
 
 
+SMALL_CLASS_CONTACT_STAGE = '''
+    - name: "touch"
+      duration: 400 #ms
+      transition: false
+      costs:
+        - name: "reg_state"
+          type: "CostModelState"
+          weight: 1e-2
+          reference: %(xref)s
+          activation: "ActivationModelWeightedQuad"
+          weights: %(w)s
+
+        - name: "reg_control"
+          type: "CostModelControl"
+          weight: 1e-2
+          reference: %(uref)s
+          activation: "ActivationModelWeightedQuad"
+          weights: %(uw)s
+
+        - name: "friction_cone"
+          type: "CostModelContactFrictionCone"
+          weight: 10
+          n_surf: [0, 0, 1]
+          mu: 0.7
+          link_name: "%(link)s"
+
+      contacts:
+        - name: "touch"
+          type: "%(contact)s"
+          link_name: "%(link)s"
+          position: [0.1, 0.0, 2.4]
+%(orientation)s          gains: [%(g0)r, %(g1)r]
+'''
+
+# robot classes without an arm chain long enough for the shipped contact files: (bodies, rotors) = (1, 6), (1, 4), (3, 6)
+SMALL_CLASSES = {"hexacopter370": ("hexacopter370/trajectories/hover.yaml", "hexacopter370__base_link"),
+                 "iris": ("iris/trajectories/hover.yaml", "iris__base_link"),
+                 "hexacopter680_flying_arm_2": ("hexacopter680_flying_arm_2/trajectories/hover.yaml", "hexacopter680__base_link")}
+
+
+def small_class_contact_variant(empc, tmp_path, robot, contact="ContactModel3D", gains=(0.0, 0.0), dt=40):
+    """A hover file of one of the smaller robot classes with a contact stage appended (contact at the base link, friction
+    cone cost): src/factory/contacts.cpp:26-79 builds a contact for any robot, no shipped YAML has one on these.  Returns
+    (trajectory, problem)."""
+    rel, link = SMALL_CLASSES[robot]
+    t0 = empc.Trajectory()
+    t0.autoSetup(empc.yaml_path(rel))
+    xref = [0.0] * t0.nx
+    xref[6] = 1.0
+    src = open(empc.yaml_path(rel)).read().rstrip("\n") + "\n" + SMALL_CLASS_CONTACT_STAGE % dict(
+        xref=xref, w=[1] * t0.ndx, uref=[0] * t0.nu, uw=[1] * t0.nu, link=link, contact=contact,
+        orientation='          orientation: [0, 0, 0, 1]\n' if contact == "ContactModel6D" else "", g0=float(gains[0]), g1=float(gains[1]))
+    f = tmp_path / ("%s_%s_%g_%g.yaml" % (robot, contact, gains[0], gains[1]))
+    f.write_text(src)
+    tr = empc.Trajectory()
+    tr.autoSetup(str(f))
+    return tr, tr.createProblem(dt, True, "IntegratedActionModelEuler")
+
+
 def mixed_contact_variant(empc, tmp_path, gains6=(0.0, 0.0), dt=32):
     """eagle_catch with its grasp stage followed by a copy of it ("hold") whose contact is a ContactModel6D: a problem with
     stages of BOTH contact types (src/factory/contacts.cpp:26-79 builds either per stage; no shipped YAML mixes them).

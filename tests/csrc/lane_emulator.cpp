@@ -165,7 +165,7 @@ static void emu_calc(Emu& e) {
   const bool ct = e.H.P.has_contact != 0;
   for (int b = 0; b < e.B; ++b)
     for (int t = 0; t <= e.T; ++t) {
-      if constexpr (DM::NB == 4 || DM::NB == 6) {  // the robot classes with contact instantiations
+      if constexpr (true) {  // (every robot class has contact instantiations since round 4)
         if (ct) {
           if (e.H.contact_rows == CT_MIXED) {
             calc_thread<DM, CT_MIXED>(e.D, b, t);
@@ -194,7 +194,7 @@ static void emu_linearize_rk4(Emu& e) {
   const bool ct = e.H.P.has_contact != 0;
   for (int t = 0; t <= e.T; ++t)
     for (int b = 0; b < e.B; ++b) {
-      if constexpr (DM::NB == 4 || DM::NB == 6) {  // the robot classes with contact instantiations
+      if constexpr (true) {  // (every robot class has contact instantiations since round 4)
         if (ct) {
           if (e.H.contact_rows == CT_MIXED) {
             rk4_stage_thread<DM, CT_MIXED>(e.D, R, b, t);
@@ -245,7 +245,7 @@ static void emu_linearize_view(Emu& e, const DevBuffers& Dl) {
       const TrajState& st = Dl.st[b];
       if (st.phase == PHASE_DONE || !st.need_lin) continue;
       if (poison) std::memset(smem.data(), 0xFF, smem.size() * sizeof(double));
-      if constexpr (DM::NB == 4 || DM::NB == 6) {  // the robot classes with contact instantiations
+      if constexpr (true) {  // (every robot class has contact instantiations since round 4)
         if (e.H.P.has_contact) {
           CpuExec<64> ex{LPUC};
           constexpr int LPU = LPUC;
@@ -306,7 +306,7 @@ static void emu_rollout(Emu& e) {
     const int G = roll6_group_size(e.NA);
     std::vector<double> smem6(Roll6Smem<DM>::SIZE);
     for (int grp = 0; grp * G < e.B; ++grp) {
-      if constexpr (DM::NB == 4 || DM::NB == 6) {  // the robot classes with contact instantiations
+      if constexpr (true) {  // (every robot class has contact instantiations since round 4)
         if (ct) {
           if (e.H.contact_rows == CT_MIXED) {
             emu_rollout_group6<DM, CT_MIXED>(e.D, grp, smem6.data());
@@ -328,7 +328,7 @@ static void emu_rollout(Emu& e) {
         if (ai > 0) continue;  // one call per trajectory: the 64 lanes cover every step length
         std::vector<double> smem5(Roll5Smem<DM>::SIZE);
         CpuExec<64> ex{64};
-        if constexpr (DM::NB == 4 || DM::NB == 6) {  // the robot classes with contact instantiations
+        if constexpr (true) {  // (every robot class has contact instantiations since round 4)
           if (ct) {
             if (e.H.contact_rows == CT_MIXED) {
               rollout_wave5<DM, CT_MIXED>(ex, e.D, b, 64, smem5.data());
@@ -343,7 +343,7 @@ static void emu_rollout(Emu& e) {
         rollout_wave5<DM, 0>(ex, e.D, b, 64, smem5.data());
         continue;
       }
-      if constexpr (DM::NB == 4 || DM::NB == 6) {  // the robot classes with contact instantiations
+      if constexpr (true) {  // (every robot class has contact instantiations since round 4)
         if (ct) {
           if (e.H.contact_rows == CT_MIXED) {
             rollout_thread<DM, CT_MIXED>(e.D, b, ai);
@@ -460,7 +460,7 @@ static void emu_node(Emu& e, int t, const double* x, const double* u, double smo
                      double* usq, double* lam) {
   const EmpcCostSet& set = e.H.sets[e.H.knot_set[t]];
   double c = 0;
-  if constexpr (DM::NB == 4 || DM::NB == 6) {  // the robot classes with contact instantiations
+  if constexpr (true) {  // (every robot class has contact instantiations since round 4)
     if (e.H.P.has_contact) {
       if (e.H.contact_rows == CT_MIXED) {
         node_nominal<DM, CT_MIXED>(e.H.P, set, smooth, x, u, u == nullptr, xnext, acc, c, usq, lam);

@@ -1,0 +1,54 @@
+"""Contact dynamics on the robot classes the shipped contact files do not use -- (bodies, rotors) = (1, 6) hexacopter370,
+(1, 4) iris, (3, 6) hexacopter680_flying_arm_2 -- with ContactModel3D and ContactModel6D (src/factory/contacts.cpp:26-79 builds
+a contact for any robot).  The problems are hover files with a contact stage at the base link
+appended (conftest.small_class_contact_variant).  Kernel instantiations: empc_inst_{1_6,1_4,3_6}_contact.hip."""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import stepwise as sw
+from conftest import SMALL_CLASSES, small_class_contact_variant
+from test_gpu_parity import phase_parity
+from test_gpu_teacher_forced import check, factory
+
+pytestmark = pytest.mark.gpu
+
+VARIANTS = [("ContactModel3D", (0.0, 0.0)), ("ContactModel6D", (5.0, 2.0))]
+
+
+@pytest.mark.parametrize("contact,gains", VARIANTS)
+@pytest.mark.parametrize("robot", sorted(SMALL_CLASSES))
+def test_small_class_contact_phase_parity(empc, tmp_path, robot, contact, gains):
+    """linearize / backward / rollout kernels against the oracle's calcDiff / backwardPass / forwardPass"""
+    _, problem = small_class_contact_variant(empc, tmp_path, robot, contact, gains)
+    assert empc.solver_supported(problem), empc.last_error()
+    assert problem.desc.has_contact
+    phase_parity(empc, problem, robot + "/" + contact)
+
+
+@pytest.mark.parametrize("robot,contact,gains", [("hexacopter370", "ContactModel3D", (0.0, 0.0)), ("hexacopter680_flying_arm_2", "ContactModel6D", (5.0, 2.0))])
+def test_small_class_contact_stepwise(empc, tmp_path, robot, contact, gains):
+    """Every iteration of the oracle's paths reproduced by the device and the other way round (tests/stepwise.py); the cold
+    starts of the hover files explode on both sides (divergence study): the bound on the waived share is the
+    perturbed hover's"""
+    _, problem = small_class_contact_variant(empc, tmp_path, robot, contact, gains)
+    d = problem.desc
+    prm = ob.default_params()
+    x0s = empc.perturbed_x0s(problem.x0, 3, nq=d.model.nq, amplitude=0.02)
+    x0s[0] = problem.x0
+    rep = sw.stepwise_parity(factory(empc, problem, prm), d, prm, x0s, maxiter=40, tape_every=13, do_same_minimum=False)
+    check(rep, max_waived=0.7)
+
+
+def test_small_class_contact_solves_are_finite_and_batch_independent(empc, tmp_path):
+    """a batch of four equals four batches of one, bit for bit (the kernels of this class follow the same rules)"""
+    _, problem = small_class_contact_variant(empc, tmp_path, "iris", "ContactModel3D", (0.0, 0.0))
+    d = problem.desc
+    x0s = empc.perturbed_x0s(problem.x0, 4, nq=d.model.nq, amplitude=0.02)
+    s = empc.SolverSbFDDP(problem, batch=4)
+    s.solve([], [], 30, x0s=x0s)
+    assert np.isfinite(s.xs_batch).all() and s.kernel_family == "runtime model"
+    one = empc.SolverSbFDDP(problem, batch=1)
+    for b in range(4):
+        one.solve([], [], 30, x0s=x0s[b:b + 1])
+        assert np.array_equal(one.xs_batch[0], s.xs_batch[b]) and one.iter_batch[0] == s.iter_batch[b]
