@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""CPU only: the step-wise parity driver (tests/stepwise.py) on the lane emulator of the CURRENT kernel bodies, on initial
+states the test-suite does not use.  Written for the end of round 4, when the GPU pool was closed to this repository: it is
+the evidence that the last changes of the backward pass (per-lane sums, triangle symmetrisation, 16-byte record moves) keep
+every decision of the solver -- the GPU edition of the same driver is tools/gpu_stepwise_soak.py.
+
+    python3 tools/emulator_stepwise_soak.py <rollouts per workload> <seed> [out.jsonl]"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+
+import empc_loader
+
+empc = empc_loader.load()
+import oracle_binding as ob
+import stepwise as sw
+from conftest import CONFIGS
+
+
+def main():
+    n, seed = int(sys.argv[1]), int(sys.argv[2])
+    out = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles", "r04_stepwise_emulator_soak.jsonl")
+    emu = sw.load_emulator()
+    for name in ("displacement", "eagle_catch", "push_slide", "hover"):
+        rel, dt = CONFIGS[name]
+        tr = empc.Trajectory()
+        tr.autoSetup(empc.yaml_path(rel))
+        problem = tr.createProblem(dt, True, "IntegratedActionModelEuler")
+        d = problem.desc
+        prm = ob.default_params()
+        x0s = empc.perturbed_x0s(problem.x0, n, nq=d.model.nq, seed=seed)
+        rep = sw.stepwise_parity(lambda k, p2: sw.EmuBackend(emu, d, p2 if p2 is not None else prm, k), d, prm, x0s, chunk=64,
+                                 tape_every=7, tight_maxiter=200, do_same_minimum=(name != "hover"))
+        row = {"workload": name, "seed": seed, "rollouts": n, "backend": "CPU lane emulator of the kernel bodies (tests/csrc/lane_emulator.cpp)"}
+        row.update({k: v for k, v in rep.items() if k != "free_run"})
+        row["free_run"] = {k: v for k, v in rep["free_run"].items() if k != "first_divergences"}
+        ok = rep["decisions_checked"] == rep["pairs"] and rep["free_run"]["unexplained"] == 0
+        row["all_claims_hold"] = bool(ok)
+        with open(out, "a") as f:
+            f.write(json.dumps(row, default=float) + "\n")
+        print(name, "pairs", rep["pairs"], "decisions", rep["decisions_checked"], "unexplained", rep["free_run"]["unexplained"],
+              "same_minimum", (rep.get("same_minimum") or {}).get("xs_err_max"), "OK" if ok else "FAILED", flush=True)
+
+
+if __name__ == "__main__":
+    main()
