@@ -47,5 +47,46 @@ def main():
               "same_minimum", (rep.get("same_minimum") or {}).get("xs_err_max"), "OK" if ok else "FAILED", flush=True)
 
 
+
+
+def variants():
+    """python3 tools/emulator_stepwise_soak.py variants <rollouts> <seed>: the option variants (contact types, contact on the
+    other robot classes, RK4 nodes, the box solvers) on a few rollouts each"""
+    import pathlib
+    import tempfile
+    from conftest import arm5_contact_variant, contact_variant, mixed_contact_variant, small_class_contact_variant
+    n, seed = int(sys.argv[2]), int(sys.argv[3])
+    out = os.path.join(ROOT, "profiles", "r04_stepwise_emulator_soak.jsonl")
+    emu = sw.load_emulator()
+    tmp = pathlib.Path(tempfile.mkdtemp())
+    tr = empc.Trajectory()
+    tr.autoSetup(empc.yaml_path(CONFIGS["displacement"][0]))
+    cases = [("eagle_catch/ContactModel6D", contact_variant(empc, tmp, "ContactModel6D", (7.0, 2.0))[1], 0, {}),
+             ("eagle_catch/mixed 3D+6D", mixed_contact_variant(empc, tmp, (5.0, 1.0))[1], 0, {}),
+             ("arm5/ContactModel3D", arm5_contact_variant(empc, tmp, "ContactModel3D", (4.0, 2.0))[1], 0, {"maxiter": 40}),
+             ("hexacopter370/ContactModel3D", small_class_contact_variant(empc, tmp, "hexacopter370", "ContactModel3D", (0.0, 0.0))[1], 0,
+              {"maxiter": 40, "do_same_minimum": False}),
+             ("iris/ContactModel6D", small_class_contact_variant(empc, tmp, "iris", "ContactModel6D", (5.0, 2.0))[1], 0,
+              {"maxiter": 40, "do_same_minimum": False}),
+             ("displacement/RK4", tr.createProblem(80, True, "IntegratedActionModelRK4"), 0, {"tol_tape": 1e-8}),
+             ("displacement/SolverBoxFDDP", tr.createProblem(80, False, "IntegratedActionModelEuler"), 1, {"maxiter": 30, "do_same_minimum": False}),
+             ("displacement/SolverBoxDDP", tr.createProblem(80, False, "IntegratedActionModelEuler"), 2, {"maxiter": 30, "do_same_minimum": False})]
+    for tag, problem, st, kw in cases:
+        d = problem.desc
+        prm = ob.default_params()
+        prm.solver_type = st
+        x0s = empc.perturbed_x0s(problem.x0, n, nq=d.model.nq, amplitude=0.02, seed=seed)
+        rep = sw.stepwise_parity(lambda k, p2: sw.EmuBackend(emu, d, p2 if p2 is not None else prm, k), d, prm, x0s, chunk=64, tape_every=13, **kw)
+        row = {"workload": tag, "seed": seed, "rollouts": n, "backend": "CPU lane emulator of the kernel bodies (tests/csrc/lane_emulator.cpp)"}
+        row.update({k: v for k, v in rep.items() if k != "free_run"})
+        row["free_run"] = {k: v for k, v in rep["free_run"].items() if k != "first_divergences"}
+        ok = rep["decisions_checked"] == rep["pairs"] and rep["free_run"]["unexplained"] == 0
+        row["all_claims_hold"] = bool(ok)
+        with open(out, "a") as f:
+            f.write(json.dumps(row, default=float) + "\n")
+        print(tag, "pairs", rep["pairs"], "decisions", rep["decisions_checked"], "unexplained", rep["free_run"]["unexplained"],
+              "same_minimum", (rep.get("same_minimum") or {}).get("xs_err_max"), "OK" if ok else "FAILED", flush=True)
+
+
 if __name__ == "__main__":
-    main()
+    variants() if sys.argv[1] == "variants" else main()
