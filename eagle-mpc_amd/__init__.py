@@ -65,6 +65,10 @@ def lib():
     L.empc_trajectory_get_param.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int]
     L.empc_trajectory_remove_stage.argtypes = [C.c_void_p, C.c_int]
     L.empc_trajectory_robot_model_path.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    L.empc_trajectory_stage_cost_type.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.c_int]
+    L.empc_trajectory_stage_contact.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_int]
+    L.empc_trajectory_get_platform_params.argtypes = [C.c_void_p, _dp, C.c_char_p, C.c_int]
+    L.empc_trajectory_get_rotor_pose.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _ip]
     L.empc_problem_destroy.argtypes = [C.c_void_p]
     L.empc_problem_desc.restype = C.POINTER(T.ProblemDesc)
     L.empc_problem_desc.argtypes = [C.c_void_p]
@@ -211,14 +215,29 @@ class SquashingModelSmoothSat:
         self.smooth = 0.1
 
 
-class PlatformParams:
-    """MultiCopterBaseParams as far as the hot path reads it: tau_f (6 x n_rotors), control limits (rotor thrusts, then arm
-    joint torques), n_rotors."""
+class RotorPose:
+    """One entry of MultiCopterBaseParams.rotors_pose (a pinocchio::SE3 in the reference): rotation (3 x 3), translation (3)
+    of the rotor frame in the base link, and the rotor's spin direction (the platform file's `spin_direction`)."""
 
-    def __init__(self, tau_f, u_lb, u_ub):
+    def __init__(self, rotation, translation, spin_direction):
+        self.rotation, self.translation, self.spin_direction = rotation, translation, spin_direction
+
+
+class PlatformParams:
+    """MultiCopterBaseParams (bindings/python/eagle_mpc/multicopter-base-params.hpp:47-88): cf, cm, n_rotors, tau_f (6 x
+    n_rotors), max_thrust / min_thrust, base_link_name, the control limits u_lb / u_ub (rotor thrusts, then arm joint torques:
+    setControlLimits, src/multicopter-base-params.cpp:89-101), rotors_pose.  `max_torque` / `min_torque` are declared by the
+    reference and never filled (include/eagle_mpc/multicopter-base-params.hpp:55-56); here they hold the arm part of the limits."""
+
+    def __init__(self, tau_f, u_lb, u_ub, scalars=None, base_link_name="", rotors_pose=()):
         self.tau_f, self.u_lb, self.u_ub = tau_f, u_lb, u_ub
         self.n_rotors = tau_f.shape[1]
-        self.max_thrust, self.min_thrust = float(u_ub[0]), float(u_lb[0])
+        if scalars is None:
+            scalars = (0.0, 0.0, float(u_ub[0]), float(u_lb[0]), 0.0, 0.0)
+        self.cf, self.cm, self.max_thrust, self.min_thrust, self.max_prop_speed, self.min_prop_speed = [float(v) for v in scalars]
+        self.base_link_name = base_link_name
+        self.rotors_pose = list(rotors_pose)
+        self.max_torque, self.min_torque = u_ub[self.n_rotors:].copy(), u_lb[self.n_rotors:].copy()
 
 
 class RobotModel:
@@ -231,12 +250,18 @@ class RobotModel:
 
 
 class StageInfo:
-    """One entry of Trajectory.stages: the read-only view of a Stage (bindings/python/eagle_mpc/stage.hpp: name, duration,
-    is_transition, t_ini, costs, contacts)."""
+    """One entry of Trajectory.stages: the read-only view of a Stage (bindings/python/eagle_mpc/stage.hpp:47-73: name, duration,
+    t_ini, is_transition, is_terminal, costs, cost_types, contacts, contact_types).  `costs` is a list of {name, weight,
+    active, type}; `cost_types` / `contact_types` map names to the factory's type names; `is_terminal` is false for every stage,
+    as in the reference (src/stage.cpp:15 sets it once and nothing changes it)."""
 
-    def __init__(self, name, duration, is_transition, n_costs, n_contacts, t_ini, costs):
+    def __init__(self, name, duration, is_transition, n_costs, n_contacts, t_ini, costs, contacts=()):
         self.name, self.duration, self.is_transition, self.t_ini = name, duration, is_transition, t_ini
         self.n_costs, self.n_contacts, self.costs = n_costs, n_contacts, costs
+        self.contacts = list(contacts)
+        self.cost_types = {c["name"]: c.get("type") for c in costs}
+        self.contact_types = {c["name"]: c["type"] for c in self.contacts}
+        self.is_terminal = False
 
     def __repr__(self):
         return "StageInfo(%r, duration=%d ms, t_ini=%d ms, costs=%d, contacts=%d%s)" % (
@@ -327,7 +352,15 @@ class Trajectory:
         """get_platform_params(): the fields of MultiCopterBaseParams the hot path uses (tau_f, u_lb, u_ub, n_rotors;
         bindings/python/eagle_mpc/multicopter-base-params.hpp)"""
         tau_f, lb, ub = self.platform()
-        return PlatformParams(tau_f, lb, ub)
+        sc = np.zeros(6)
+        name = C.create_string_buffer(128)
+        _check(lib().empc_trajectory_get_platform_params(self._h, _ptr(sc), name, 128))
+        poses = []
+        for i in range(tau_f.shape[1]):
+            R, p, spin = np.zeros((3, 3)), np.zeros(3), C.c_int()
+            _check(lib().empc_trajectory_get_rotor_pose(self._h, i, _ptr(R), _ptr(p), C.byref(spin)))
+            poses.append(RotorPose(R, p, spin.value))
+        return PlatformParams(tau_f, lb, ub, sc, name.value.decode(), poses)
 
     @property
     def robot_model(self):
@@ -348,9 +381,16 @@ class Trajectory:
         for k in range(v[2].value):
             cname, w, a = C.create_string_buffer(64), C.c_double(), C.c_int()
             _check(lib().empc_trajectory_stage_cost(self._h, i, k, cname, 64, C.byref(w), C.byref(a)))
-            costs.append(dict(name=cname.value.decode(), weight=w.value, active=bool(a.value)))
+            ctype = C.create_string_buffer(64)
+            _check(lib().empc_trajectory_stage_cost_type(self._h, i, cname.value, ctype, 64))
+            costs.append(dict(name=cname.value.decode(), weight=w.value, active=bool(a.value), type=ctype.value.decode()))
+        contacts = []
+        for k in range(v[3].value):
+            cname, ctype = C.create_string_buffer(64), C.create_string_buffer(64)
+            _check(lib().empc_trajectory_stage_contact(self._h, i, k, cname, 64, ctype, 64))
+            contacts.append(dict(name=cname.value.decode(), type=ctype.value.decode()))
         return dict(name=name.value.decode(), duration=v[0].value, is_transition=bool(v[1].value), n_costs=v[2].value,
-                    n_contacts=v[3].value, t_ini=int(lib().empc_trajectory_stage_t_ini(self._h, i)), costs=costs)
+                    n_contacts=v[3].value, t_ini=int(lib().empc_trajectory_stage_t_ini(self._h, i)), costs=costs, contacts=contacts)
 
     def get_param(self, key):
         buf = C.create_string_buffer(4096)

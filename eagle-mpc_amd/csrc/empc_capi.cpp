@@ -134,6 +134,62 @@ int empc_trajectory_stage_cost(const EmpcTrajectory* t, int stage, int cost, cha
   EMPC_CATCH(EMPC_ERR_INVALID)
 }
 
+static void copy_out(const std::string& v, char* dst, int len) {
+  if (dst && len > 0) {
+    std::strncpy(dst, v.c_str(), (size_t)len - 1);
+    dst[len - 1] = 0;
+  }
+}
+int empc_trajectory_stage_cost_type(const EmpcTrajectory* t, int stage, const char* cost_name, char* type, int type_len) {
+  EMPC_TRY
+  if (!t || !cost_name) throw std::invalid_argument("NULL argument");
+  static const char* names[] = {"CostModelState", "CostModelControl", "CostModelFramePlacement", "CostModelFrameRotation",
+                                "CostModelFrameVelocity", "CostModelFrameTranslation", "CostModelContactFrictionCone"};
+  const auto& types = t->t->get_stages().at((size_t)stage)->get_cost_types();
+  const auto it = types.find(cost_name);
+  if (it == types.end()) throw std::out_of_range(std::string("no cost named '") + cost_name + "' in this stage");
+  copy_out(names[(int)it->second], type, type_len);
+  return EMPC_OK;
+  EMPC_CATCH(EMPC_ERR_INVALID)
+}
+int empc_trajectory_stage_contact(const EmpcTrajectory* t, int stage, int contact, char* name, int name_len, char* type, int type_len) {
+  EMPC_TRY
+  if (!t) throw std::invalid_argument("trajectory is NULL");
+  static const char* names[] = {"ContactModel2D", "ContactModel3D", "ContactModel6D"};
+  const auto& st = t->t->get_stages().at((size_t)stage);
+  const auto& contacts = st->get_contacts()->get_contacts();
+  if (contact < 0 || (size_t)contact >= contacts.size()) throw std::out_of_range("contact index out of range");
+  auto it = contacts.begin();
+  std::advance(it, contact);
+  copy_out(it->first, name, name_len);
+  copy_out(names[(int)st->get_contact_types().at(it->first)], type, type_len);
+  return EMPC_OK;
+  EMPC_CATCH(EMPC_ERR_INVALID)
+}
+int empc_trajectory_get_platform_params(const EmpcTrajectory* t, double* scalars, char* base_link_name, int name_len) {
+  EMPC_TRY
+  if (!t) throw std::invalid_argument("trajectory is NULL");
+  const auto& pp = t->t->get_platform_params();
+  if (scalars) {
+    const double v[6] = {pp->cf_, pp->cm_, pp->max_thrust_, pp->min_thrust_, pp->max_prop_speed_, pp->min_prop_speed_};
+    std::memcpy(scalars, v, sizeof(v));
+  }
+  copy_out(pp->base_link_name_, base_link_name, name_len);
+  return EMPC_OK;
+  EMPC_CATCH(EMPC_ERR_INVALID)
+}
+int empc_trajectory_get_rotor_pose(const EmpcTrajectory* t, int rotor, double* R, double* p, int* spin_direction) {
+  EMPC_TRY
+  if (!t) throw std::invalid_argument("trajectory is NULL");
+  const auto& pp = t->t->get_platform_params();
+  if (rotor < 0 || (size_t)rotor >= pp->rotors_pose_.size()) throw std::out_of_range("rotor index out of range");
+  if (R) std::memcpy(R, pp->rotors_pose_[(size_t)rotor].R, sizeof(double) * 9);
+  if (p) std::memcpy(p, pp->rotors_pose_[(size_t)rotor].p, sizeof(double) * 3);
+  if (spin_direction) *spin_direction = pp->rotors_spin_dir_[(size_t)rotor];
+  return EMPC_OK;
+  EMPC_CATCH(EMPC_ERR_INVALID)
+}
+
 int empc_trajectory_get_initial_state(const EmpcTrajectory* t, double* x0) {
   EMPC_TRY
   if (!t || !x0) throw std::invalid_argument("NULL argument");

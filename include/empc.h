@@ -73,6 +73,15 @@ int empc_trajectory_stage_cost(const EmpcTrajectory* t, int stage, int cost, cha
 int empc_trajectory_remove_stage(EmpcTrajectory* t, int stage);
 /* Trajectory::get_robot_model_path() (src/trajectory.cpp:160; bindings .../trajectory.hpp:42-43); returns the length */
 int empc_trajectory_robot_model_path(const EmpcTrajectory* t, char* path, int path_len);
+/* Stage::get_cost_types() / get_contacts() / get_contact_types() (include/eagle_mpc/stage.hpp; bindings/python/eagle_mpc/stage.hpp:50-73):
+   the factory type name of a cost ("CostModelState", ...), name and type ("ContactModel3D" | "ContactModel6D") of contact k */
+int empc_trajectory_stage_cost_type(const EmpcTrajectory* t, int stage, const char* cost_name, char* type, int type_len);
+int empc_trajectory_stage_contact(const EmpcTrajectory* t, int stage, int contact, char* name, int name_len, char* type, int type_len);
+/* MultiCopterBaseParams (include/eagle_mpc/multicopter-base-params.hpp:40-60; bindings .../multicopter-base-params.hpp:47-88):
+   scalars = { cf, cm, max_thrust, min_thrust, max_prop_speed, min_prop_speed }, base_link_name; pose of rotor i (R row-major
+   3 x 3, p) and its spin direction */
+int empc_trajectory_get_platform_params(const EmpcTrajectory* t, double* scalars /* 6 */, char* base_link_name, int name_len);
+int empc_trajectory_get_rotor_pose(const EmpcTrajectory* t, int rotor, double* R /* 9 */, double* p /* 3 */, int* spin_direction);
 int empc_trajectory_get_initial_state(const EmpcTrajectory* t, double* x0 /* nx */);
 int empc_trajectory_set_initial_state(EmpcTrajectory* t, const double* x0 /* nx */);
 int empc_trajectory_get_platform(const EmpcTrajectory* t, double* tau_f /* 6 x n_rotors */, double* u_lb, double* u_ub,

@@ -16,6 +16,8 @@ ARM3 = "hexacopter370_flying_arm_3"
 SURFACE = {
     "Trajectory": ["autoSetup", "createProblem", "removeStage", "stages", "robot_model", "robot_model_path", "platform_params",
                    "squash", "initial_state", "duration"],
+    "PlatformParams": [],  # instance attributes: cf, cm, n_rotors, tau_f, max_thrust, min_thrust, base_link_name, max_torque,
+                           # min_torque, u_lb, u_ub, rotors_pose (test_platform_params_and_stage_views)
     "SolverSbFDDP": ["solve", "setCallbacks", "getCallbacks", "xs", "us", "us_squash", "iter", "cost", "stop", "problem",
                      "convergence_init"],
     "CarrotMpc": ["updateProblem", "solver", "problem", "robot_model", "platform_params", "iters"],
@@ -70,6 +72,34 @@ def test_trajectory_members(empc):
     pp, rm = t.platform_params, t.robot_model
     assert pp.n_rotors == 6 and pp.tau_f.shape == (6, 6) and pp.u_lb.shape == (9,) and pp.max_thrust == pp.u_ub[0]
     assert (rm.nq, rm.nv) == (10, 9) and isinstance(rm.name, str) and rm.name
+
+
+def test_platform_params_and_stage_views(empc):
+    """CPU: MultiCopterBaseParams as the reference's bindings expose it (cf, cm, thrust limits, base link, rotor poses whose
+    thrust axes and arms rebuild tau_f: src/multicopter-base-params.cpp:67-78) and the Stage views (cost_types, contacts,
+    contact_types, is_terminal)"""
+    t = arm3_trajectory(empc, "eagle_catch")
+    pp = t.platform_params
+    assert pp.cf == pytest.approx(4.138394792004922e-06) and pp.cm == pytest.approx(6.991478005829954e-08)
+    assert pp.max_thrust == 20.6991 and pp.min_thrust == 0.0 and pp.base_link_name == "hexacopter370__base_link"
+    assert pp.max_prop_speed == pytest.approx(np.sqrt(pp.max_thrust / pp.cf)) and pp.min_prop_speed == 0.0
+    assert len(pp.rotors_pose) == pp.n_rotors == 6
+    assert np.array_equal(pp.max_torque, pp.u_ub[6:]) and np.array_equal(pp.min_torque, pp.u_lb[6:]) and pp.max_torque.shape == (3,)
+    for i, rp in enumerate(pp.rotors_pose):
+        assert abs(np.linalg.det(rp.rotation) - 1.0) < 1e-12 and rp.spin_direction in (-1, 1)
+        axis = rp.rotation[:, 2]  # thrust along the rotor frame's z axis
+        assert np.allclose(pp.tau_f[:3, i], axis, atol=1e-12)
+        assert np.allclose(pp.tau_f[3:, i], np.cross(rp.translation, axis) + rp.spin_direction * pp.cm / pp.cf * axis, atol=1e-12)
+    stages = t.stages
+    grasp = [s for s in stages if s.n_contacts][0]
+    assert grasp.contacts == [{"name": grasp.contacts[0]["name"], "type": "ContactModel3D"}]
+    assert grasp.contact_types == {grasp.contacts[0]["name"]: "ContactModel3D"}
+    assert all(s.is_terminal is False for s in stages)
+    known = {"CostModelState", "CostModelControl", "CostModelFramePlacement", "CostModelFrameRotation", "CostModelFrameVelocity",
+             "CostModelFrameTranslation", "CostModelContactFrictionCone"}
+    for s in stages:
+        assert set(s.cost_types) == {c["name"] for c in s.costs} and set(s.cost_types.values()) <= known
+    assert "CostModelContactFrictionCone" in grasp.cost_types.values()
 
 
 def test_remove_stage(empc):
