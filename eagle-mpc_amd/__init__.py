@@ -881,6 +881,26 @@ class MpcProblem:
         _check(self._set_x0_fn(self._mpc._h, _ptr(v)))
 
 
+def _mpc_squash(self):
+    """get_squash() of MpcAbstract (bindings/python/eagle_mpc/mpc-base.hpp:53): SquashingModelSmoothSat over the platform's limits"""
+    pp = self.platform_params
+    return SquashingModelSmoothSat(pp.u_lb, pp.u_ub, len(pp.u_lb))
+
+
+def _mpc_robot_model_path(self):
+    """get_robot_model_path() of MpcAbstract (bindings .../mpc-base.hpp:43): the URDF of the trajectory the controller was built
+    from (RailMpc, which takes no trajectory, reads the robot from its own YAML: not recorded here -> None)"""
+    tr = getattr(self, "trajectory", None)
+    return tr.robot_model_path if tr is not None else None
+
+
+def _mpc_create_problem(self):
+    """MpcAbstract::createProblem() (bindings .../mpc-base.hpp:39): the controllers of this mirror build their problem in the
+    constructor, as the reference's constructors do (src/mpc-controllers/carrot-mpc.cpp:48); returns it"""
+    return self.problem
+
+
+
 class CarrotMpc:
     """Mirror of eagle_mpc.CarrotMpc(trajectory, state_ref, dt_ref, yaml_path)
     (bindings/python/eagle_mpc/mpc-controllers/carrot-mpc.hpp, src/mpc-controllers/carrot-mpc.cpp).
@@ -1028,3 +1048,9 @@ def perturbed_x0s(x0, batch, nq, seed=0, amplitude=0.05, joint_lb=None, joint_ub
         out[b] += amplitude * rng.uniform(-1, 1, size=x0.shape)
         out[b, 3:7] /= np.linalg.norm(out[b, 3:7])
     return out
+
+
+for _cls in (CarrotMpc, _Mpc):
+    _cls.squash = property(_mpc_squash)
+    _cls.robot_model_path = property(_mpc_robot_model_path)
+    _cls.createProblem = _mpc_create_problem

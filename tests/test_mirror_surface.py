@@ -20,9 +20,9 @@ SURFACE = {
                            # min_torque, u_lb, u_ub, rotors_pose (test_platform_params_and_stage_views)
     "SolverSbFDDP": ["solve", "setCallbacks", "getCallbacks", "xs", "us", "us_squash", "iter", "cost", "stop", "problem",
                      "convergence_init"],
-    "CarrotMpc": ["updateProblem", "solver", "problem", "robot_model", "platform_params", "iters"],
-    "RailMpc": ["updateProblem", "solver", "problem", "robot_model", "platform_params", "iters"],
-    "WeightedMpc": ["updateProblem", "solver", "problem", "robot_model", "platform_params", "iters"],
+    "CarrotMpc": ["updateProblem", "createProblem", "solver", "problem", "robot_model", "robot_model_path", "platform_params", "squash", "iters"],
+    "RailMpc": ["updateProblem", "createProblem", "solver", "problem", "robot_model", "robot_model_path", "platform_params", "squash", "iters"],
+    "WeightedMpc": ["updateProblem", "createProblem", "solver", "problem", "robot_model", "robot_model_path", "platform_params", "squash", "iters"],
 }
 
 
@@ -100,6 +100,21 @@ def test_platform_params_and_stage_views(empc):
     for s in stages:
         assert set(s.cost_types) == {c["name"] for c in s.costs} and set(s.cost_types.values()) <= known
     assert "CostModelContactFrictionCone" in grasp.cost_types.values()
+
+
+def test_controller_members_without_a_gpu(empc):
+    """CPU: what MpcAbstract's bindings expose besides the solver (bindings/python/eagle_mpc/mpc-base.hpp:39-72): knots, dt, iters,
+    squash, robot_model_path, createProblem -- no GPU needed until `.solver` is touched"""
+    t = arm3_trajectory(empc)
+    yaml = empc.YAML_DIR + "/" + ARM3 + "/mpc/mpc.yaml"
+    ref = np.tile(t.initial_state, (40, 1))
+    for mpc in (empc.CarrotMpc(t, ref, 20, yaml), empc.WeightedMpc(arm3_trajectory(empc), 20, yaml), empc.RailMpc(ref, 20, yaml)):
+        assert mpc.knots == mpc.problem.T + 1 and mpc.dt > 0 and mpc.iters >= 1
+        sq = mpc.squash
+        assert isinstance(sq, empc.SquashingModelSmoothSat) and sq.ns == mpc.nu and np.array_equal(sq.u_ub, mpc.platform_params.u_ub)
+        assert mpc.createProblem() is mpc.problem
+        path = mpc.robot_model_path
+        assert path is None if isinstance(mpc, empc.RailMpc) else path.endswith(".urdf")
 
 
 def test_remove_stage(empc):
