@@ -627,6 +627,26 @@ EMPC_HD void state_integrate(const X0* x, const double* dx, double* xout, double
   }
 }
 
+// state_integrate with exp6 of the step's first six entries already taken (qe, pe = exp6_quat(dx)): the same operations in the same
+// order, minus that call -- for a step that is known before the state is (the gap correction of a rollout, empc_rollout6.hpp)
+template <class DM, class X0>
+EMPC_HD void state_integrate_pre(const X0* x, const double* dx, const double* qe, const double* pe, double* xout) {
+  double R0[9], Rp[3], qn[4];
+  double q0[4] = {x[3], x[4], x[5], x[6]};
+  quat_to_R(q0, R0);
+  matvec3<double>(R0, pe, Rp);
+  quat_mul(q0, qe, qn);
+  quat_normalize(qn);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) xout[i] = x[i] + Rp[i];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) xout[3 + i] = qn[i];
+#pragma unroll
+  for (int i = 7; i < DM::NQ; ++i) xout[i] = x[i] + dx[i - 1];
+#pragma unroll
+  for (int i = 0; i < DM::NV; ++i) xout[DM::NQ + i] = x[DM::NQ + i] + dx[DM::NV + i];
+}
+
 // Friction-cone matrix rows (FrictionCone(n, mu, 4, false)): row i of A R_n^T
 EMPC_HD void cone_rows(const double* nsurf, double mu, double AR[5][3]) {
   const double A[5][3] = {{1, 0, -mu}, {0, 1, -mu}, {-1, 0, -mu}, {0, -1, -mu}, {0, 0, 1}};

@@ -276,6 +276,12 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
   // ---- per-role state that lives across the knots -----------------------------------------------------------------------
   double dvA[Exec::SLOTS];                    // A: -f^T Vxx (xs (-) xs_try) summed over the knots
   double Lc[Exec::SLOTS][DM::NTRI];           // C: Cholesky factor of M, from phase I to phase II of a knot
+#ifdef EMPC_ROLL_GAP_EARLY
+  // C: the gap correction of the NEXT trial state, (alpha - 1) fs[t+1], and exp6 of its first six entries -- known before the
+  // knot's dynamics are, so taken in phase I (where C waits for A and D) instead of at the end of phase II (the knot's critical
+  // path).  Build-time experiment, off by default: prepared while the GPU pool was closed, bit-identical on the lane emulator.
+  double stepC[Exec::SLOTS][NDX], qeC[Exec::SLOTS][4], peC[Exec::SLOTS][3];
+#endif
   int okC[Exec::SLOTS];                       // C: trial state stayed finite
   int ncC[Exec::SLOTS], ncD[Exec::SLOTS];     // C / D: running nodes reached before the first failure (T: none)
   double costD[Exec::SLOTS];                  // D: cost of the trial
@@ -600,6 +606,14 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
       for (int b = 1; b < NB; ++b) fsincos(XT[(7 + b - 1) * NL + lane], &sn[b - 1], &cs[b - 1]);
       crba_chain<NB>(m, cs, sn, Lc[sl]);
       chol_packed<NV>(Lc[sl]);
+#ifdef EMPC_ROLL_GAP_EARLY
+      if (!terminal && last_stage && !L.plain) {
+        const double* gp = D.tape + ((size_t)L.b * (T + 1) + (size_t)(t + 1)) * REC + DM::OFF_GAP;  // fs[t+1] of this lane's trajectory
+#pragma unroll
+        for (int i = 0; i < NDX; ++i) stepC[sl][i] = gp[i] * (L.alpha - 1.0);
+        exp6_quat(stepC[sl], qeC[sl], peC[sl]);
+      }
+#endif
       R6_SUB(5);
     });
     // ---- D: cost of the previous knot, State costs of this one, stores, staging of the next knot's nominal data ----------------
@@ -755,11 +769,15 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
 #pragma unroll
           for (int i = 0; i < NX; ++i) xt[i] = xn[i];
         } else {
+#ifdef EMPC_ROLL_GAP_EARLY
+          state_integrate_pre<DM>(xn, stepC[sl], qeC[sl], peC[sl], xt);
+#else
           const double* gapn = NOM + (size_t)((t + 1) & 1) * SM::NOMSZ + SM::NOM_GAP + L.g * SM::GS;
           double step[NDX];
 #pragma unroll
           for (int i = 0; i < NDX; ++i) step[i] = gapn[i] * (L.alpha - 1.0);
           state_integrate<DM>(xn, step, xt, nullptr);
+#endif
         }
 #pragma unroll
         for (int i = 0; i < NX; ++i) XT[i * NL + lane] = xt[i];
