@@ -118,6 +118,16 @@ PY
     bash "$0" check "$TAG"
     bash "$0" profiles "$TAG"
     bash "$0" lines "$TAG"
+    bash "$0" abgap "$TAG"
+    ;;
+  abgap)
+    # the prepared rollout experiment: shipped library against libempc_gap.so (-DEMPC_ROLL_GAP_EARLY)
+    if [ -f "$ROOT/eagle-mpc_amd/libempc_gap.so" ]; then
+      for cfg in eagle_catch displacement push_slide; do
+        bench_line "${cfg}_shipped" "EMPC_X=0" --config $cfg --no-cpu-baseline --no-secondary --no-slots-sweep --steps 10
+        bench_line "${cfg}_gap_early" "EMPC_LIB_PATH=$ROOT/eagle-mpc_amd/libempc_gap.so" --config $cfg --no-cpu-baseline --no-secondary --no-slots-sweep --steps 10
+      done
+    fi
     ;;
   stamps)
     # phase-level launches: product library first (ms per launch), then the diagnostic build with in-kernel cycle stamps
