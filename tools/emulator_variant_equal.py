@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""CPU only: is a build-time variant of the kernel bodies (a -D macro) bit-identical to the default on the lane emulator?
+Builds tests/csrc/lane_emulator.cpp twice (with and without the macro), runs linearize -> backward -> four step lengths of the
+rollout from a seeded random candidate with open gaps on the four BASELINE workloads (Euler nodes; RK4 nodes on the arm-3 files)
+and compares every trial state, control, cost and expected-improvement term bit for bit.
+
+    python3 tools/emulator_variant_equal.py EMPC_ROLL_GAP_EARLY"""
+import os
+import subprocess
+import sys, ctypes as C, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import empc_loader; empc = empc_loader.load()
+import oracle_binding as ob
+import test_emulator_parity as tep
+from conftest import CONFIGS
+_ip = C.POINTER(C.c_int)
+def load(path):
+    tep.EMU = path
+    return tep.emu.__wrapped__(empc)
+def run(emu, problem, name):
+    d = problem.desc; prm = ob.default_params()
+    emu.emu_set_linearize_version(2); emu.emu_set_backward_version(4); emu.emu_set_rollout_version(6)
+    e = C.c_void_p(emu.emu_create(C.byref(d), C.byref(prm), 1))
+    T, nx, nu, nv = d.T, d.nx, d.nu, d.model.nv
+    xs, us = tep.candidate(d, 3)
+    emu.emu_set_warmstart(e, ob.P(xs), ob.P(us)); emu.emu_phase_setup(e, 0.1, 0, 1e-9, 0)
+    tape = np.zeros((T+1, emu.emu_rec(e))); acc = np.zeros((T+1, nv))
+    emu.emu_phase_linearize(e, ob.P(tape), ob.P(acc))
+    K=np.zeros((T,nu,d.ndx)); k=np.zeros((T,nu)); Vx=np.zeros((T+1,d.ndx)); dg=np.zeros(2); ok=np.zeros(1,dtype=np.int32); fe=np.zeros(1,dtype=np.int32); ce=np.zeros(1)
+    emu.emu_phase_backward(e, ob.P(K), ob.P(k), ob.P(Vx), ob.P(dg), ok.ctypes.data_as(_ip), fe.ctypes.data_as(_ip), ob.P(ce))
+    outs=[]
+    for ai in (1,2,4,6):
+        xt=np.zeros((T+1,nx)); ut=np.zeros((T,nu)); ct=np.zeros(1); dv=np.zeros(1); okr=np.zeros(1,dtype=np.int32)
+        emu.emu_phase_rollout(e, ai, ob.P(xt), ob.P(ut), ob.P(ct), ob.P(dv), okr.ctypes.data_as(_ip))
+        outs.append((xt.copy(), ut.copy(), ct.copy(), dv.copy(), okr.copy()))
+    emu.emu_destroy(e)
+    return outs
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+macro = sys.argv[1]
+for out, flags in (("/tmp/emu_variant_base.so", []), ("/tmp/emu_variant_%s.so" % macro, ["-D" + macro])):
+    subprocess.check_call(["g++", "-O2", "-std=c++20", "-pthread", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include")] + flags +
+                          [os.path.join(ROOT, "tests", "csrc", "lane_emulator.cpp"), "-o", out])
+a = load("/tmp/emu_variant_base.so"); b = load("/tmp/emu_variant_%s.so" % macro)
+all_same = True
+for name in ("displacement","eagle_catch","push_slide","hover"):
+    tr = empc.Trajectory(); tr.autoSetup(empc.yaml_path(CONFIGS[name][0]))
+    for integ in ("IntegratedActionModelEuler","IntegratedActionModelRK4"):
+        if integ.endswith("RK4") and name in ("push_slide","hover"): continue
+        problem = tr.createProblem(CONFIGS[name][1], True, integ)
+        ra, rb = run(a, problem, name), run(b, problem, name)
+        same = all(all(np.array_equal(x, y, equal_nan=True) for x, y in zip(p, q)) for p, q in zip(ra, rb))
+        moved = max(np.abs(p[0][-1]).max() for p in ra)
+        all_same = all_same and same
+        print(name, integ, "bitwise equal:", same, "| finite:", all(np.isfinite(p[2]).all() for p in ra))
+
+sys.exit(0 if all_same else 1)
