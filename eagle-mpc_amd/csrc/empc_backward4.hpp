@@ -77,7 +77,11 @@ struct Bwd4Smem {
   static constexpr int OFF_HINV = OFF_W + WROWS * WS;                 // m x m
   static constexpr int OFF_PRO = OFF_REC;                             // prologue reductions: 3 x 64
   static_assert(OFF_HINV + m * m <= DM::OFF_LX, "W and Hinv must fit in front of the part of the record that stays live");
+#if EMPC_BWD_R4B
   static constexpr int OFF_V = (DM::REC + 127) / 128 * 128;           // [16 MTN][VS], zero outside n x n
+#else
+  static constexpr int OFF_V = (DM::REC + 63) / 64 * 64;              // [16 MTN][VS], zero outside n x n
+#endif
   static_assert(5 * 64 <= OFF_V, "prologue sums / end-of-pass sums inside the record area");
   static constexpr int OFF_VX = OFF_V + 16 * MTN * VS;                // [4 KSN], zero beyond n
   static constexpr int OFF_Q = OFF_VX + 4 * KSN;                      // [QROWS][QS]
@@ -98,7 +102,11 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
   constexpr int NL = 64;
   constexpr int n = DM::NDX, m = DM::NU, nm = n + m, REC = DM::REC;
   static_assert(nm <= 47 && n <= 32, "tile counts of the matrix-core backward pass");
+#if EMPC_BWD_R4B
   constexpr int PRE = (REC + 2 * NL - 1) / (2 * NL);  // prefetch register PAIRS per lane: the record moves in 16-byte pieces
+#else
+  constexpr int PRE = (REC + NL - 1) / NL;  // prefetch registers per lane
+#endif
   constexpr int MTN = SM::MTN, MTQ = SM::MTQ, NTQ = SM::NTQ, KSN = SM::KSN, KSM = SM::KSM;
   constexpr int VS = SM::VS, QS = SM::QS, WS = SM::WS, KS = SM::KS;
   TrajState& st = D.st[b];
@@ -179,6 +187,7 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
     for (int i = lane; i < SM::SIZE - SM::OFF_V; i += NL) smem[SM::OFF_V + i] = 0.0;
   });
   ex.sync();
+#if EMPC_BWD_R4B
   // symmetrise stage: entry (i, j), i <= j, of the upper triangle per lane and round; offsets of W[i][j], W[j][i], V[i][j], V[j][i]
   // (-1: no entry).  One read pair and one average serve both halves (a + b == b + a bit for bit).
   constexpr int NTRI = n * (n + 1) / 2, NSY = (NTRI + NL - 1) / NL;
@@ -200,6 +209,7 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
       sy_v[sl][q][1] = (i == j) ? -1 : j * VS + i;  // -1 marks a diagonal entry: regularised, written once
     }
   });
+#endif
 
   double xreg = st.xreg, ureg = st.ureg;
   double dg_u = 0, dq_u = 0, dg_f = 0, dq_f = 0, qu2 = 0;
@@ -245,12 +255,21 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
       ex.sync();
     }
     // first record of the sweep
+#if EMPC_BWD_R4B
     Bwd4Pair pre[Exec::SLOTS][PRE];
     ex.each([&](int lane, int sl) {
       const Bwd4Pair* r = reinterpret_cast<const Bwd4Pair*>(tape + (size_t)(T - 1) * REC);
 #pragma unroll
       for (int q = 0; q < PRE; ++q) pre[sl][q] = r[lane + q * NL];  // whole 128-double rows: they end inside the next record
     });
+#else
+    double pre[Exec::SLOTS][PRE];
+    ex.each([&](int lane, int sl) {
+      const double* r = tape + (size_t)(T - 1) * REC;
+#pragma unroll
+      for (int q = 0; q < PRE; ++q) pre[sl][q] = r[lane + q * NL];  // whole rows: the tape has one row of slack
+    });
+#endif
 #if defined(EMPC_STAMPS) && defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
     unsigned long long bst[16];
     for (int i = 0; i < 16; ++i) bst[i] = 0;
@@ -275,6 +294,7 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
     for (int t = T - 1; t >= 0; --t) {
       BWD_STAMP(7);
       ex.each([&](int lane, int sl) {
+#if EMPC_BWD_R4B
 #pragma unroll
         for (int q = 0; q < PRE; ++q) reinterpret_cast<Bwd4Pair*>(rec)[lane + q * NL] = pre[sl][q];
         if (t < T - 1) flush_outputs(t + 1, lane, sl);
@@ -283,6 +303,16 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
 #pragma unroll
           for (int q = 0; q < PRE; ++q) pre[sl][q] = r[lane + q * NL];
         }
+#else
+#pragma unroll
+        for (int q = 0; q < PRE; ++q) rec[lane + q * NL] = pre[sl][q];
+        if (t < T - 1) flush_outputs(t + 1, lane, sl);
+        if (t > 0) {
+          const double* r = tape + (size_t)(t - 1) * REC;
+#pragma unroll
+          for (int q = 0; q < PRE; ++q) pre[sl][q] = r[lane + q * NL];
+        }
+#endif
       });
       ex.sync();
       BWD_STAMP(0);
@@ -541,6 +571,7 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
       bool badl[Exec::SLOTS];
       ex.each([&](int lane, int sl) {
         bool bad = false;
+#if EMPC_BWD_R4B
         double wa[NSY], wb[NSY];
 #pragma unroll
         for (int q = 0; q < NSY; ++q) {
@@ -560,6 +591,28 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
             bad = bad || bad_number(v_);
           }
         }
+#else
+        constexpr int NS = (n * n + NL - 1) / NL;
+        double wa[NS], wb[NS];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+          const int i = lane + q * NL, ic = i < n * n ? i : 0;
+          const int rr = ic / n, cc = ic % n;
+          wa[q] = W[rr * WS + cc];
+          wb[q] = W[cc * WS + rr];
+        }
+        BWD_FENCE();
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+          const int i = lane + q * NL;
+          if (i < n * n) {
+            const int rr = i / n, cc = i % n;
+            const double v_ = 0.5 * (wa[q] + wb[q]) + ((rr == cc) ? xreg : 0.0);
+            V[rr * VS + cc] = v_;
+            bad = bad || bad_number(v_);
+          }
+        }
+#endif
         badl[sl] = bad;
       });
       ex.sync();
@@ -569,7 +622,12 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
         if (lane >= n) return;
         double a_ = 0;
         if (infeas) {
+#if EMPC_BWD_R4B
           constexpr int CH = (n + 1) / 2;  // two blocks of reads (round 3: three)
+#else
+          constexpr int CH = 6;
+          static_assert(n % CH == 0 || true, "");
+#endif
 #pragma unroll
           for (int j0 = 0; j0 < n; j0 += CH) {
             double vv[CH], gg[CH];

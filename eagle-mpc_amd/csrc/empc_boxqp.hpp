@@ -13,6 +13,8 @@ namespace empc {
 // H: full M x M (row-major), symmetric positive definite on the free block.  x: in = warm start, out = solution.
 // free_mask[i] = 1 for free components; Hinv: inverse of the free block, zero rows / columns for clamped components.
 // Returns false when a factorisation fails (crocoddyl throws "backward_error").
+#if EMPC_BOXQP_ONE_EXIT
+// (commit b94f9cd: one exit, unrolled loops -- fewer spilled registers in the box backward pass; never run on hardware)
 template <int M>
 EMPC_HD bool box_qp_lane(const double* H, const double* q, const double* lb, const double* ub, double* x, int* free_mask, double* Hinv,
                          int maxiter, double th_acceptstep, double th_grad, double reg) {
@@ -136,5 +138,132 @@ EMPC_HD bool box_qp_lane(const double* H, const double* q, const double* lb, con
   if (want_inv) invert_free();
   return true;
 }
+
+#else
+template <int M>
+EMPC_HD bool box_qp_lane(const double* H, const double* q, const double* lb, const double* ub, double* x, int* free_mask, double* Hinv,
+                         int maxiter, double th_acceptstep, double th_grad, double reg) {
+  // crocoddyl::BoxQP builds its own ten step lengths 2^-n whatever the outer solver's line search uses
+  constexpr int n_alphas = 10;
+  double g[M], xnew[M], dx[M];
+  int prev_mask[M];
+  bool have_inv = false, ok = true;
+#pragma unroll
+  for (int i = 0; i < M; ++i) {
+    x[i] = fmax(fmin(x[i], ub[i]), lb[i]);
+    prev_mask[i] = -1;
+  }
+  // LLT of the free block (kept: the Newton step is one pair of triangular solves, crocoddyl's Hff_inv_llt_.solveInPlace);
+  // the inverse itself (solution_.Hff_inv, which SolverBox*::computeGains multiplies with Qux) is formed at the exits only
+  double L[M * (M + 1) / 2];
+  auto factor_free = [&](const int* mask) {
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+      for (int j = 0; j <= i; ++j)
+        L[i * (i + 1) / 2 + j] = (mask[i] && mask[j]) ? H[i * M + j] + ((i == j) ? reg : 0.0) : ((i == j) ? 1.0 : 0.0);
+    if (!chol_packed<M>(L)) return false;
+#pragma unroll
+    for (int i = 0; i < M; ++i) prev_mask[i] = mask[i];
+    have_inv = true;
+    return true;
+  };
+  auto invert_free = [&]() {
+    for (int c = 0; c < M; ++c) {
+      double col[M];
+#pragma unroll
+      for (int i = 0; i < M; ++i) col[i] = (i == c) ? 1.0 : 0.0;
+      chol_solve_packed<M>(L, col);
+#pragma unroll
+      for (int i = 0; i < M; ++i) Hinv[i * M + c] = (prev_mask[i] && prev_mask[c]) ? col[i] : 0.0;
+    }
+  };
+  auto fval = [&](const double* z) {
+    double f = 0;
+    for (int i = 0; i < M; ++i) {
+      double a = 0;
+#pragma unroll
+      for (int j = 0; j < M; ++j) a += H[i * M + j] * z[j];
+      f += 0.5 * z[i] * a + q[i] * z[i];
+    }
+    return f;
+  };
+  for (int k = 0; k < maxiter; ++k) {
+    double gmax = 0;
+    int nf = 0;
+    for (int i = 0; i < M; ++i) {
+      double a = q[i];
+#pragma unroll
+      for (int j = 0; j < M; ++j) a += H[i * M + j] * x[j];
+      g[i] = a;
+      gmax = fmax(gmax, fabs(a));
+    }
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+      const bool clamped = (x[j] == lb[j] && g[j] > 0.0) || (x[j] == ub[j] && g[j] < 0.0);
+      free_mask[j] = clamped ? 0 : 1;
+      nf += free_mask[j];
+    }
+    if (gmax <= th_grad || nf == 0) {
+      bool same = have_inv;
+#pragma unroll
+      for (int i = 0; i < M; ++i) same = same && prev_mask[i] == free_mask[i];
+      if (!same) ok = factor_free(free_mask);
+      if (ok) invert_free();
+      return ok;
+    }
+    {
+      // the factorisation of an unchanged free set is the one already held
+      bool same = have_inv;
+#pragma unroll
+      for (int i = 0; i < M; ++i) same = same && prev_mask[i] == free_mask[i];
+      if (!same && !factor_free(free_mask)) return false;
+    }
+    // Newton step on the free space: dxf = -Hff^-1 (qf + Hfc xc) - xf (the clamped rows of the factor are unit pivots)
+    {
+      double r[M];
+#pragma unroll
+      for (int j = 0; j < M; ++j) {
+        double a = -q[j];
+#pragma unroll
+        for (int c = 0; c < M; ++c)
+          if (!free_mask[c]) a -= H[j * M + c] * x[c];
+        r[j] = free_mask[j] ? a : 0.0;
+      }
+      chol_solve_packed<M>(L, r);
+#pragma unroll
+      for (int i = 0; i < M; ++i) dx[i] = free_mask[i] ? r[i] - x[i] : 0.0;
+    }
+    const double fold = fval(x);
+    bool moved = false;
+    for (int ia = 0; ia < n_alphas; ++ia) {
+      const double alpha = ldexp(1.0, -ia);
+#pragma unroll
+      for (int i = 0; i < M; ++i) xnew[i] = fmax(fmin(x[i] + alpha * dx[i], ub[i]), lb[i]);
+      const double fnew = fval(xnew);
+      double gd = 0;
+#pragma unroll
+      for (int i = 0; i < M; ++i) gd += g[i] * (x[i] - xnew[i]);
+      if (fold - fnew > th_acceptstep * gd) {
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+          moved = moved || x[i] != xnew[i];
+          x[i] = xnew[i];
+        }
+        break;
+      }
+    }
+    // an iteration that left x where it was repeats itself (same gradient, same free set, same step) until maxiter: the
+    // result is the one at hand (a control clamped with a non-zero multiplier keeps the gradient norm above th_grad for ever)
+    if (!moved) {
+      invert_free();
+      return true;
+    }
+  }
+  if (have_inv) invert_free();
+  return true;
+}
+
+#endif
 
 }  // namespace empc

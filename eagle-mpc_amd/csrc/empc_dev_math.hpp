@@ -8,6 +8,7 @@
 // spatial vectors [linear; angular], quaternion xyzw, right-perturbation Jacobians.
 #pragma once
 #include <math.h>
+#include "empc_variants.hpp"
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>

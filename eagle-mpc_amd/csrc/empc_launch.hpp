@@ -227,11 +227,20 @@ struct BlockExec {
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
   }
-  // (the workgroups of this executor are ONE wavefront: a ballot answers "any lane?" without the LDS reduction and the
-  //  barrier __syncthreads_or compiles to -- 300 cycles per knot of the backward pass)
+  // EMPC_ANY_BALLOT (off: not yet run on hardware): the workgroups of this executor are ONE wavefront, so a ballot answers
+  // "any lane?" without the LDS reduction and the barrier __syncthreads_or compiles to (300 cycles per knot of the backward
+  // pass).  __syncthreads_or also kept the compiler from moving LDS traffic across it; the ballot form states that itself.
   template <class F>
   __device__ __forceinline__ bool any(F&& f) {
-    return __builtin_amdgcn_ballot_w64(f(lane, 0)) != 0;
+#if EMPC_ANY_BALLOT
+    __builtin_amdgcn_sched_barrier(0);
+    const bool r = __builtin_amdgcn_ballot_w64(f(lane, 0)) != 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_sched_barrier(0);
+    return r;
+#else
+    return __syncthreads_or(f(lane, 0) ? 1 : 0) != 0;
+#endif
   }
   // one v_mfma_f64_16x16x4_f64 of the wavefront: acc[im][in] += A-operand a[ia] x B-operand b[ib] (per-lane values)
   template <class A, class B, class C>

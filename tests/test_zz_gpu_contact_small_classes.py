@@ -13,6 +13,12 @@ from test_gpu_teacher_forced import check, factory
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def _opt_in(monkeypatch):
+    """these instantiations are opt-in until this file has passed on hardware (empc_solver.hip find_table)"""
+    monkeypatch.setenv("EMPC_EXPERIMENTAL_CONTACT", "1")
+
 VARIANTS = [("ContactModel3D", (0.0, 0.0)), ("ContactModel6D", (5.0, 2.0))]
 
 

@@ -4,7 +4,10 @@ Builds tests/csrc/lane_emulator.cpp twice (with and without the macro), runs lin
 rollout from a seeded random candidate with open gaps on the four BASELINE workloads (Euler nodes; RK4 nodes on the arm-3 files)
 and compares every trial state, control, cost and expected-improvement term bit for bit.
 
-    python3 tools/emulator_variant_equal.py EMPC_ROLL_GAP_EARLY"""
+    python3 tools/emulator_variant_equal.py EMPC_ROLL_GAP_EARLY [MORE_MACROS ...]      (a macro may carry a value: EMPC_BWD_R4B=1)
+The tape, the gains, Vx, the expected-improvement sums and the status of the backward pass are compared as well.
+Then whole emulated solves with the box solvers (SolverBoxFDDP / SolverBoxDDP: the box-QP gains of the backward pass) on hover and
+displacement, cold and warm: iterations, status, states, controls, cost bit for bit."""
 import os
 import subprocess
 import sys, ctypes as C, numpy as np
@@ -28,7 +31,7 @@ def run(emu, problem, name):
     emu.emu_phase_linearize(e, ob.P(tape), ob.P(acc))
     K=np.zeros((T,nu,d.ndx)); k=np.zeros((T,nu)); Vx=np.zeros((T+1,d.ndx)); dg=np.zeros(2); ok=np.zeros(1,dtype=np.int32); fe=np.zeros(1,dtype=np.int32); ce=np.zeros(1)
     emu.emu_phase_backward(e, ob.P(K), ob.P(k), ob.P(Vx), ob.P(dg), ok.ctypes.data_as(_ip), fe.ctypes.data_as(_ip), ob.P(ce))
-    outs=[]
+    outs=[(tape.copy(), acc.copy(), K.copy(), k.copy(), Vx.copy(), dg.copy(), ok.copy(), fe.copy(), ce.copy())]
     for ai in (1,2,4,6):
         xt=np.zeros((T+1,nx)); ut=np.zeros((T,nu)); ct=np.zeros(1); dv=np.zeros(1); okr=np.zeros(1,dtype=np.int32)
         emu.emu_phase_rollout(e, ai, ob.P(xt), ob.P(ut), ob.P(ct), ob.P(dv), okr.ctypes.data_as(_ip))
@@ -36,8 +39,9 @@ def run(emu, problem, name):
     emu.emu_destroy(e)
     return outs
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-macro = sys.argv[1]
-for out, flags in (("/tmp/emu_variant_base.so", []), ("/tmp/emu_variant_%s.so" % macro, ["-D" + macro])):
+macros = sys.argv[1:]
+macro = "_".join(m.replace("=", "") for m in macros)
+for out, flags in (("/tmp/emu_variant_base.so", []), ("/tmp/emu_variant_%s.so" % macro, ["-D" + m for m in macros])):
     subprocess.check_call(["g++", "-O2", "-std=c++20", "-pthread", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include")] + flags +
                           [os.path.join(ROOT, "tests", "csrc", "lane_emulator.cpp"), "-o", out])
 a = load("/tmp/emu_variant_base.so"); b = load("/tmp/emu_variant_%s.so" % macro)
@@ -49,8 +53,34 @@ for name in ("displacement","eagle_catch","push_slide","hover"):
         problem = tr.createProblem(CONFIGS[name][1], True, integ)
         ra, rb = run(a, problem, name), run(b, problem, name)
         same = all(all(np.array_equal(x, y, equal_nan=True) for x, y in zip(p, q)) for p, q in zip(ra, rb))
-        moved = max(np.abs(p[0][-1]).max() for p in ra)
+        moved = max(np.abs(p[0][-1]).max() for p in ra[1:])
         all_same = all_same and same
-        print(name, integ, "bitwise equal:", same, "| finite:", all(np.isfinite(p[2]).all() for p in ra))
+        print(name, integ, "bitwise equal:", same, "| finite:", all(np.isfinite(p[2]).all() for p in ra[1:]))
+
+def box_solve(emu, tr, dt, warm, solver_type, maxiter=30):
+    problem = tr.createProblem(dt, False, "IntegratedActionModelEuler")
+    d = problem.desc; prm = ob.default_params(); prm.solver_type = solver_type
+    xs0 = us0 = None
+    if warm:
+        sq = tr.createProblem(dt, True, "IntegratedActionModelEuler")
+        o0 = ob.OracleSolver(sq.desc); o0.solve(None, None, 100); r0 = o0.result()
+        xs0, us0 = r0["xs"], np.ascontiguousarray(r0["us_squash"])
+    emu.emu_set_linearize_version(2); emu.emu_set_backward_version(4); emu.emu_set_rollout_version(6)
+    e = C.c_void_p(emu.emu_create(C.byref(d), C.byref(prm), 1))
+    emu.emu_set_warmstart(e, None if xs0 is None else ob.P(xs0), None if us0 is None else ob.P(us0))
+    emu.emu_solve_c(e, maxiter, 1 if warm else 0)
+    T, nx, nu = d.T, d.nx, d.nu
+    xs_e, us_e, ul, ce = np.zeros((T + 1, nx)), np.zeros((T, nu)), np.zeros((T, nu)), np.zeros(1)
+    it, st = np.zeros(1, dtype=np.int32), np.zeros(1, dtype=np.int32)
+    emu.emu_get(e, ob.P(xs_e), ob.P(us_e), ob.P(ul), ob.P(ce), it.ctypes.data_as(_ip), st.ctypes.data_as(_ip))
+    emu.emu_destroy(e)
+    return xs_e, us_e, ce, it, st
+for name, dt, warm in (("hover", 40, False), ("displacement", 80, False), ("displacement", 80, True)):
+    tr = empc.Trajectory(); tr.autoSetup(empc.yaml_path(CONFIGS[name][0]))
+    for solver_type in (1, 2):
+        ra, rb = box_solve(a, tr, dt, warm, solver_type), box_solve(b, tr, dt, warm, solver_type)
+        same = all(np.array_equal(x, y, equal_nan=True) for x, y in zip(ra, rb))
+        all_same = all_same and same
+        print("box solve", name, "warm" if warm else "cold", "solver_type", solver_type, "bitwise equal:", same, "| iterations", int(ra[3][0]), "status", int(ra[4][0]))
 
 sys.exit(0 if all_same else 1)
