@@ -32,11 +32,13 @@ import json
 import os
 import sys
 import time
+import zlib
 
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 CONFIGS = {
     "hover": ("hexacopter370/trajectories/hover.yaml", 40),
@@ -301,6 +303,26 @@ LIMITERS = {
 }
 
 
+def committed_counters(config, B, is_mpc, code_id):
+    """The committed PMC summary of this workload (profiles/r*_pmc_<config>.json, newest round first) -- used only when it was
+    taken on the device code that is running now (`device_code_id` inside the file == the id of the loaded library).
+    -> (kernels dict, file name or None, note)"""
+    import glob
+    if B != 1024 or is_mpc:
+        return {}, None, "no committed counter pass for this workload / batch"
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_%s.json" % config)), reverse=True)
+    seen = []
+    for f in files:
+        try:
+            js = json.load(open(f))
+        except Exception:
+            continue
+        if code_id is not None and js.get("device_code_id") == code_id:
+            return js.get("kernels", {}), os.path.relpath(f, ROOT), "counters taken on this device code (id %s, commit %s)" % (code_id, js.get("commit"))
+        seen.append("%s: %s" % (os.path.basename(f), js.get("device_code_id") or "no id (taken before round 5)"))
+    return {}, None, "no committed counter pass matches the running device code (id %s); seen %s" % (code_id, seen or "none")
+
+
 def limiter_text(kernel, pmc):
     c = (pmc or {}).get(kernel) or {}
     txt = LIMITERS[kernel]
@@ -333,7 +355,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
+    if args.gpus != world and (world > 1 or "WORLD_SIZE" in os.environ):
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # Self-launch: N fresh worker processes, one per GPU, started as CHILDREN before this process has imported torch
@@ -367,6 +389,10 @@ def main():
         import torch.distributed as dist_mod
         dist = dist_mod
         dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("process group of %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
+        if args.backend == "nccl" and torch.cuda.device_count() < world:
+            raise SystemExit("%d ranks on %d visible GPUs: one rank per GPU is the contract of --gpus N" % (world, torch.cuda.device_count()))
 
     is_mpc = args.config.endswith("_mpc")
     stream = (args.mode == "stream") and not is_mpc
@@ -407,6 +433,20 @@ def main():
 
     rows_dev = {}
     gathered = {}
+    seen_devices = {}
+
+    def gather_device_ids():
+        # which GPU each rank really computes on, through the same collective backend as the result rows and inside the timed
+        # region (16 bytes per rank): (index torch selected, PCI bus id of the device libempc.so runs on).  Two ranks on one GPU or
+        # a rank that fell back to another device show up in the line (`rccl_ranks_seen`) instead of in a quietly wrong value.
+        p = torch.cuda.get_device_properties(local_dev) if torch.cuda.is_available() else None
+        bus = (getattr(p, "pci_bus_id", -1) if p is not None else -1)
+        uuid_hash = (zlib.crc32(str(getattr(p, "uuid", "")).encode()) & 0x7FFFFFFF) if p is not None else -1
+        mine = torch.tensor([float(rank), float(torch.cuda.current_device() if torch.cuda.is_available() else -1), float(bus), float(uuid_hash)],
+                            dtype=torch.float64, device=coll_dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        seen_devices["rows"] = [[int(v) for v in e.cpu().tolist()] for e in every]
 
     def gather_step(stream_rows=False):
         # the only exchange of the algorithm: every rank's result rows to rank 0.  RCCL: rows are packed on the device and
@@ -476,6 +516,7 @@ def main():
         solver.stream_run(args.maxiter)
         if dist is not None:
             gather_step(stream_rows=True)
+            gather_device_ids()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -492,6 +533,8 @@ def main():
             st = one_step()
             for k, v in st.items():
                 agg[k] = agg.get(k, 0) + v
+        if dist is not None:
+            gather_device_ids()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -524,10 +567,16 @@ def main():
     if rank == 0:
         words = algorithmic_words(d.nx, d.ndx, d.nu)
         value = iters_total / B / elapsed
+        import device_code_id as dci
+        code_id = dci.device_code_id(empc.LIB_PATH)
+        # the rollout kernel's algorithmic bytes: SURVEY.md section 8(d)'s per-(trajectory, knot) figure, once per launch -- the
+        # step lengths of the line search share K / k / xs / us and only the accepted trial is a result (VERDICT r04 item 8:
+        # charging the inputs to each of the ten step lengths made the figure 3.8 x the bytes the counters see)
+        na = max(solver.stats_na(), 1)
         # dominant kernel of the timed region (HIP-event durations recorded on the solver's stream)
         kern = {"linearize": (agg["ms_linearize"], agg["n_linearize"], agg["linearize_units"]),
                 "backward": (agg["ms_backward"], agg["n_backward"], agg["backward_units"]),
-                "rollout": (agg["ms_rollout"], agg["n_rollout"], agg["rollout_units"])}
+                "rollout": (agg["ms_rollout"], agg["n_rollout"], agg["rollout_units"] / na)}
         dom = max(kern, key=lambda k: kern[k][0])
         ms, nlaunch, units = kern[dom]
         bytes_per_launch = units / max(nlaunch, 1) * words[dom] * 8.0
@@ -535,16 +584,10 @@ def main():
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         # HBM bytes per launch of the dominant kernel from the committed PMC passes of this workload at a full batch
         # (FETCH_SIZE / WRITE_SIZE, tools/run_profiles.sh): read from profiles/, not measured in this run
-        # (tools/gpu_r4.sh profiles: separate --pmc passes over THIS command line in stream mode, summarised over the
+        # (tools/gpu_r5.sh profiles: separate --pmc passes over THIS command line in stream mode, summarised over the
         #  launches with a full grid only; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md).  No file for the
         #  workload / batch at hand: null.
-        pmc = {}
-        prof = os.path.join(ROOT, "profiles", "r04_pmc_%s.json" % args.config)
-        if os.path.exists(prof) and B == 1024 and not is_mpc:
-            try:
-                pmc = json.load(open(prof)).get("kernels", {})
-            except Exception:
-                pmc = {}
+        pmc, pmc_file, pmc_note = committed_counters(args.config, B, is_mpc, code_id)
         traffic = (pmc.get(dom) or {}).get("hbm_bytes_per_launch")
         per_launch = {k: {"avg_ms": kern[k][0] / max(kern[k][1], 1), "launches": kern[k][1],
                           "algorithmic_GBs": (kern[k][2] / max(kern[k][1], 1) * words[k] * 8.0) / (kern[k][0] / max(kern[k][1], 1) * 1e-3) / 1e9
@@ -587,6 +630,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
+            "device_code_id": code_id,
             "config": {"workload": workload, "mode": "mpc" if is_mpc else args.mode,
                        "nx": d.nx, "ndx": d.ndx, "nu": d.nu, "parallelism": "batch-sharded x%d" % world},
             "trajectory_iters_per_s": iters_total / elapsed,
@@ -598,11 +642,12 @@ def main():
             "ms_per_sweep": elapsed * 1e3 / max(agg["sweeps"], 1),
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_copy_bandwidth": achieved / HBM_COPY_GBS, "traffic": traffic,
-                         "traffic_source": "profiles/r04_pmc_%s.json (committed PMC passes over a stream run, full-batch launches only)" % args.config if traffic else None,
+                         "traffic_source": ("%s (committed PMC passes over a stream run, full-batch launches only); %s" % (pmc_file, pmc_note)) if traffic else pmc_note,
+                         "counters_commit": None if not pmc_file else json.load(open(os.path.join(ROOT, pmc_file))).get("commit"),
                          "achieved_from_counter_bytes_GBs": (traffic / (avg_ms * 1e-3) / 1e9) if (traffic and avg_ms > 0) else None,
                          "algorithmic_bytes_per_unit": words[dom] * 8, "units_per_launch": units / max(nlaunch, 1),
-                         "unit_definition": "(trajectory, step length, knot): one launch rolls out all %d step lengths of "
-                                            "the line search" % solver.stats_na() if dom == "rollout" else "(trajectory, knot)",
+                         "unit_definition": "(trajectory, knot); a rollout launch tries all %d step lengths of the line search on it" % na
+                                            if dom == "rollout" else "(trajectory, knot)",
                          "avg_launch_ms": avg_ms,
                          "limiter": limiter_text(dom, pmc)},
             "kernels": per_launch,
@@ -617,8 +662,15 @@ def main():
                                           "unit": "TFLOP/s", "frac": per_launch[dom]["fp64_frac_of_78.6TF"],
                                           "flop_per_unit": per_launch[dom]["fp64_flop_per_unit"],
                                           "valu_active_frac_of_wave_cycles": per_launch[dom]["valu_active_frac_of_wave_cycles"],
-                                          "source": "profiles/r04_pmc_%s.json" % args.config}
+                                          "source": pmc_file}
         if dist is not None:
+            devs = seen_devices.get("rows", [])
+            distinct = len(set((r[1], r[2], r[3]) for r in devs))
+            out["rccl_ranks_seen"] = {"backend": args.backend, "ranks": len(devs), "distinct_devices": distinct,
+                                      "rank_device_busid": [[r[0], r[1], r[2]] for r in devs]}
+            if args.backend == "nccl" and (len(devs) != args.gpus or distinct != args.gpus):
+                raise SystemExit("multi-GPU self-check failed: %d ranks on %d distinct GPUs, --gpus %d: %s" %
+                                 (len(devs), distinct, args.gpus, json.dumps(out["rccl_ranks_seen"])))
             out["ranks_seen"] = ranks_seen
             out["ranks_matching_golden_vector"] = ranks_golden_ok
             out["per_rank"] = per_rank

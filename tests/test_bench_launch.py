@@ -30,3 +30,30 @@ def test_single_rank_mismatch_is_refused():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
                        timeout=120, env=env)
     assert r.returncode != 0 and "does not match WORLD_SIZE" in (r.stdout + r.stderr)
+
+
+def test_counter_summaries_are_used_only_for_the_device_code_they_were_taken_on(tmp_path, monkeypatch):
+    """roofline.traffic / roofline.compute come from a committed PMC summary only when its `device_code_id` is the id of the
+    library that is running; the committed round-4 summaries carry no id and are refused"""
+    import json
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench
+    import device_code_id as dci
+    lib = os.path.join(ROOT, "eagle-mpc_amd", "libempc.so")
+    if not os.path.exists(lib):
+        pytest.skip("libempc.so is not built")
+    cid = dci.device_code_id(lib)
+    assert cid and len(cid) == 16 and cid == dci.device_code_id(lib)
+    k, f, note = bench.committed_counters("eagle_catch", 1024, False, cid)
+    assert k == {} and f is None and "no committed counter pass matches" in note  # until a round-5 pass of THIS build is committed
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    (prof / "r05_pmc_eagle_catch.json").write_text(json.dumps({"device_code_id": cid, "commit": "abc", "kernels": {"backward": {"hbm_bytes_per_launch": 1.0}}}))
+    (prof / "r04_pmc_eagle_catch.json").write_text(json.dumps({"kernels": {"backward": {"hbm_bytes_per_launch": 2.0}}}))
+    k, f, note = bench.committed_counters("eagle_catch", 1024, False, cid)
+    assert k["backward"]["hbm_bytes_per_launch"] == 1.0 and f.endswith("r05_pmc_eagle_catch.json") and "abc" in note
+    k, f, note = bench.committed_counters("eagle_catch", 1024, False, "0" * 16)
+    assert k == {} and f is None
+    assert bench.committed_counters("eagle_catch", 512, False, cid)[0] == {}

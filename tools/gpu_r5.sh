@@ -1,20 +1,23 @@
-# GPU box, round 4: ONE script for everything this round measures.  Usage (through gpurun, from the repo root):
-#   tools/gpu_r4.sh check        whole GPU suite, then the default bench line
-#   tools/gpu_r4.sh ab           bench lines with the baked-robot kernels on (default) and off (EMPC_BAKED=0), eagle_catch +
+# GPU box, round 5: ONE script for everything this round measures (grown from round 4's).  Usage (through gpurun, from the repo root):
+#   tools/gpu_r5.sh check        whole GPU suite, then the default bench line
+#   tools/gpu_r5.sh ab           bench lines with the baked-robot kernels on (default) and off (EMPC_BAKED=0), eagle_catch +
 #                                displacement + push_slide, no CPU baseline (kernel comparison only)
-#   tools/gpu_r4.sh tests        GPU suite only
-#   tools/gpu_r4.sh profiles     rocprofv3 kernel stats + PMC passes behind profiles/r04_*
-#   tools/gpu_r4.sh final        check + profiles + lines (then: bash tools/keep_r04.sh <tag> copies the summaries to profiles/)
-#   tools/gpu_r4.sh lines        bench lines of hover and the three closed-loop MPC configurations
-#   tools/gpu_r4.sh slots        occupancy experiment (slots in flight x build variants)
-#   tools/gpu_r4.sh stamps       in-kernel cycle stamps (libempc_stamps.so)
+#   tools/gpu_r5.sh tests        GPU suite only
+#   tools/gpu_r5.sh profiles     rocprofv3 kernel stats + PMC passes behind profiles/r05_*
+#   tools/gpu_r5.sh final        check + profiles + lines (then: bash tools/keep_r05.sh <tag> copies the summaries to profiles/)
+#   tools/gpu_r5.sh lines        bench lines of hover and the three closed-loop MPC configurations
+#   tools/gpu_r5.sh slots        occupancy experiment (slots in flight x build variants)
+#   tools/gpu_r5.sh stamps       in-kernel cycle stamps (libempc_stamps.so)
+#   tools/gpu_r5.sh variants     prepared variant libraries (libempc_<tag>.so): parity core of the suite + bench lines, each against the shipped one
+# EMPC_COMMIT (exported by tools/gpurun_r5.sh) names the commit of the snapshot: it is written into every summary this script leaves.
 set -uo pipefail
 ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)}"
 cd "$ROOT"
 mkdir -p gpurun_out
 MODE="${1:-check}"
-TAG="${2:-r04}"
+TAG="${2:-r05}"
 nproc; lscpu | grep -E "Model name" | head -2
+echo "commit ${EMPC_COMMIT:-unknown} device code $(python3 tools/device_code_id.py)"
 
 bench_line() {  # name, env, args...
   local name="$1"; shift
@@ -51,19 +54,21 @@ case "$MODE" in
     done
     ;;
   profiles)
-    # what is kept under profiles/r04_*: the bench line, the rocprofv3 kernel-trace summary of the same command and four
+    # what is kept under profiles/r05_*: the bench line, the rocprofv3 kernel-trace summary of the same command and four
     # --pmc passes (HBM reads, HBM writes, FP64 instruction mix, wavefront activity) over a short stream run
     export TMPDIR=/tmp
     O="$ROOT/gpurun_out/${TAG}_prof"; rm -rf "$O"; mkdir -p "$O"
     for CFG in ${CONFIGS:-eagle_catch displacement push_slide}; do
       T=$(python3 -c "import bench, empc_loader as l; e = l.load(); r, dt = bench.CONFIGS['$CFG']; t = e.Trajectory(); t.autoSetup(e.yaml_path(r)); print(t.createProblem(dt, True, 'IntegratedActionModelEuler').T)")
       STEPS=20; [ "$CFG" = push_slide ] && STEPS=5
-      timeout 900 python3 bench.py --config $CFG --steps $STEPS --warmup 1 --no-secondary > $O/bench_$CFG.json 2> $O/bench_$CFG.err; echo "bench $CFG rc $?"
+      timeout 900 python3 bench.py --config $CFG --gpus 1 --steps $STEPS --warmup 5 --no-secondary > $O/bench_$CFG.json 2> $O/bench_$CFG.err; echo "bench $CFG rc $?"
       tail -c 400 $O/bench_$CFG.json; echo
-      ARGS="--config $CFG --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-single-batch --no-slots-sweep"
+      # the kernel-trace summary is taken over the DRIVER'S command (python3 bench.py --gpus 1 --steps 20 --warmup 5) so that its
+      # per-kernel averages reproduce the bench line's roofline.frac; the counter passes use a shorter queue
+      ARGS="--config $CFG --gpus 1 --steps $STEPS --warmup 5 --no-cpu-baseline --no-secondary --no-single-batch --no-slots-sweep"
       rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$CFG -- python3 bench.py $ARGS > $O/bench_under_rocprof_$CFG.json 2> $O/stats_$CFG.err
       python3 tools/profile_summarize.py stats $O/stats_$CFG $O/kernel_stats_$CFG.csv | head -12
-      PARGS="--config $CFG --steps 2 --warmup 0 --no-cpu-baseline --no-secondary --no-single-batch --no-slots-sweep"
+      PARGS="--config $CFG --steps 4 --warmup 0 --no-cpu-baseline --no-secondary --no-single-batch --no-slots-sweep"
       rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/p_fetch_$CFG -- python3 bench.py $PARGS > /dev/null 2> $O/p_fetch_$CFG.err
       rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/p_write_$CFG -- python3 bench.py $PARGS > /dev/null 2> $O/p_write_$CFG.err
       rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES --output-format csv -d $O/p_fp64_$CFG -- python3 bench.py $PARGS > /dev/null 2> $O/p_fp64_$CFG.err
@@ -98,7 +103,7 @@ PY
     done
     ;;
   lines)
-    # the bench lines of the other configurations (profiles/r04_bench_<config>.json)
+    # the bench lines of the other configurations (profiles/r05_bench_<config>.json)
     for cfg in ${CONFIGS:-hover carrot_mpc rail_mpc weighted_mpc}; do
       bench_line "$cfg" "EMPC_X=0" --config $cfg --no-cpu-baseline --no-secondary --no-slots-sweep
     done
@@ -128,6 +133,26 @@ PY
         bench_line "${cfg}_gap_early" "EMPC_LIB_PATH=$ROOT/eagle-mpc_amd/libempc_gap.so" --config $cfg --no-cpu-baseline --no-secondary --no-slots-sweep --steps 10
       done
     fi
+    ;;
+  variants)
+    # every prepared variant library (eagle-mpc_amd/libempc_<tag>.so, empc_variants.hpp switches; built on the CPU side, shipped
+    # with the snapshot): the parity core of the GPU suite through that library, then bench lines against the shipped one.
+    # VARIANTS="gap r4b ..." restricts the list; QUICK_TESTS is the parity core (phase parity, step-wise parity, golden vectors,
+    # failure exits, box solvers, stream bitwise)
+    QT="${QUICK_TESTS:-tests/test_gpu_parity.py tests/test_gpu_teacher_forced.py tests/test_gpu_eagle_catch.py tests/test_gpu_branches.py tests/test_gpu_box_solvers.py tests/test_gpu_stream.py tests/test_gpu_baked.py}"
+    for cfg in ${CONFIGS:-eagle_catch displacement push_slide}; do
+      bench_line "${cfg}_shipped" "EMPC_X=0" --config $cfg --no-cpu-baseline --no-secondary --no-slots-sweep --steps 10
+    done
+    for lib in $ROOT/eagle-mpc_amd/libempc_*.so; do
+      v=$(basename $lib .so); v=${v#libempc_}
+      [ "$v" = stamps ] && continue
+      if [ -n "${VARIANTS:-}" ] && ! echo " $VARIANTS " | grep -q " $v "; then continue; fi
+      echo "=== variant $v ($(python3 tools/device_code_id.py $lib))"
+      EMPC_LIB_PATH=$lib timeout 1500 python -m pytest $QT -q -m gpu -x 2>&1 | tail -6 | tee "gpurun_out/${TAG}_pytest_${v}.log"
+      for cfg in ${CONFIGS:-eagle_catch displacement push_slide}; do
+        bench_line "${cfg}_${v}" "EMPC_LIB_PATH=$lib" --config $cfg --no-cpu-baseline --no-secondary --no-slots-sweep --steps 10
+      done
+    done
     ;;
   stamps)
     # phase-level launches: product library first (ms per launch), then the diagnostic build with in-kernel cycle stamps

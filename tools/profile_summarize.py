@@ -151,8 +151,13 @@ def pmc(config, out, B, T, NA, dirs):
             if full and k != "k_linearize_all":
                 rows[k][c].append(v)
     mean = lambda k, c: (sum(rows[k][c]) / len(rows[k][c])) if rows[k].get(c) else None
-    units = {"linearize": B * (T + 1), "backward": B * T, "rollout": B * NA * (T + 1)}
+    # (rollout: units are (trajectory, knot) from round 5 on -- one launch tries NA step lengths on each; bench.py counts the same way)
+    units = {"linearize": B * (T + 1), "backward": B * T, "rollout": B * (T + 1)}
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import device_code_id as dci
     res = {"config": config, "B": B, "T": T, "NA": NA, "kernels": {},
+           # which kernels these counters describe: bench.py uses the file only when the id equals that of the library it loaded
+           "device_code_id": dci.device_code_id(), "commit": os.environ.get("EMPC_COMMIT"), "library": os.environ.get("EMPC_LIB_PATH") or "eagle-mpc_amd/libempc.so",
            "method": "rocprofv3 --kernel-trace --pmc <one counter group per pass> over `bench.py --mode stream`; launches with the full grid only"}
     groups = {"linearize": [k for k in ("k_linearize", "k_linearize_full") if k in rows], "backward": ["k_backward"], "rollout": ["k_rollout"]}
     for name, ks in groups.items():
