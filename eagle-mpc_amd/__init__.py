@@ -425,7 +425,9 @@ class IterationRecord:
 
 
 class CallbackVerbose:
-    """crocoddyl.CallbackVerbose: one line per iteration (iter, cost, stop, grad, xreg, ureg, step, feasibility)."""
+    """crocoddyl.CallbackVerbose: one line per iteration (iter, cost, stop, grad, xreg, ureg, step, feasibility).
+    ``lines`` keeps the iteration lines only (one per iteration, what tests and log readers index); the header that is reprinted
+    every ten iterations goes to the stream but not into ``lines``."""
 
     def __init__(self, stream=None):
         self.stream = stream
@@ -450,6 +452,7 @@ class SolverSbFDDP:
     """
 
     SOLVER_TYPE = T.SOLVER_SBFDDP
+    TRACE_BUDGET_BYTES = 256 << 20  # device memory the callbacks' iteration trace may take without being asked for
 
     def __init__(self, problem, squashing_model=None, *, batch=1, device=0, params=None):
         """SolverSbFDDP(problem, squashing_model) as in the reference (include/eagle_mpc/sbfddp.hpp:39-40,
@@ -501,6 +504,13 @@ class SolverSbFDDP:
         if self._callbacks:
             need = 3 * (int(maxiter) + 1) + 8
             if getattr(self, "_trace_cap", 0) < need:
+                # the ring lives on the device: batch x records x 96 B.  Callbacks replay trajectory 0 only, but the ring is per
+                # trajectory; beyond TRACE_BUDGET_BYTES the caller must size it (enable_trace) or drop the callbacks
+                nbytes = self.batch * need * 96
+                if nbytes > self.TRACE_BUDGET_BYTES:
+                    raise EmpcError("callbacks on a batch of %d with maxiter %d need a %.0f MB iteration trace on the device "
+                                    "(budget %.0f MB): call enable_trace(records) yourself, lower maxiter, or use a batch-1 solver "
+                                    "for the verbose run" % (self.batch, maxiter, nbytes / 1e6, self.TRACE_BUDGET_BYTES / 1e6))
                 self.enable_trace(need)
 
     def _replay_callbacks(self):

@@ -103,7 +103,21 @@ EMPC_HD double frsqrt(double x) {
 // sqrt(x), x >= 0
 EMPC_HD double fsqrt(double x) {
 #if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+#if EMPC_FSQRT_BITS
+  // the failure value from the bit pattern: under -fno-honor-nans (the baked units) `x == x` folds to true and a product with
+  // a NaN constant is poison, so neither may decide or make the result
+  if (!(x > 1e-300)) {
+    unsigned long long u;
+    __builtin_memcpy(&u, &x, sizeof(u));
+    const bool nan_or_negative = (u & 0x7fffffffffffffffull) > 0x7ff0000000000000ull || ((u >> 63) != 0 && (u << 1) != 0);
+    u = nan_or_negative ? 0x7ff8000000000000ull : 0ull;
+    double r_;
+    __builtin_memcpy(&r_, &u, sizeof(r_));
+    return r_;
+  }
+#else
   if (!(x > 1e-300)) return (x == x && x >= 0.0) ? 0.0 : x * __builtin_nan("");
+#endif
   const double r = frsqrt(x);
   const double s = x * r;
   return fma(fma(-s, s, x), 0.5 * r, s);

@@ -24,3 +24,8 @@
 #ifndef EMPC_BOXQP_ONE_EXIT
 #define EMPC_BOXQP_ONE_EXIT 0
 #endif
+// fsqrt's failure value (negative or NaN argument) made from the bit pattern instead of `x == x` and `x * NaN`, which the
+// -fno-honor-nans build of the baked units may fold (never observed to; prepared with the other changes that wait for hardware)
+#ifndef EMPC_FSQRT_BITS
+#define EMPC_FSQRT_BITS 0
+#endif

@@ -119,3 +119,4 @@ def test_one_bit_off_the_table_falls_back_and_update_problem_repicks(empc, probl
         d.model.mass[1] = mass
     s.update_problem()
     assert s.kernel_family.startswith("baked")
+
