@@ -34,7 +34,7 @@ def factory(empc, problem, prm, cls=None):
 def save(name, rep):
     try:
         os.makedirs(OUT, exist_ok=True)
-        with open(os.path.join(OUT, "r04_stepwise_%s.json" % name), "w") as f:
+        with open(os.path.join(OUT, "r05_stepwise_%s.json" % name), "w") as f:
             json.dump(rep, f, indent=1, default=lambda o: o.tolist() if hasattr(o, "tolist") else str(o))
         print("stepwise %s: waived %.3f (free run %.3f), accepted chaotic trials %d of which prefix-checked %d" % (
             name, rep.get("waived_fraction", -1), rep["free_run"].get("waived_fraction", -1), rep.get("accepted_trials_chaotic", 0),
@@ -54,10 +54,14 @@ def waived_fraction(rep):
     return waived / max(rep["decisions_checked"], 1)
 
 
-def check(rep, max_waived=0.10):
+def check(rep, max_waived=0.10, min_asserted=0):
     """every pair went through the comparison, nothing unexplained in the reverse direction, and the waivers stay a bounded
-    minority (a collapse of the harness into 'everything excused' fails here)"""
+    minority (a collapse of the harness into 'everything excused' fails here); `min_asserted`: an absolute floor on the
+    iterations that DID carry the numerical assertions (a loose relative bound alone lets a test pass on a handful)"""
     assert rep["decisions_checked"] == rep["pairs"] > 0
+    asserted = rep["decisions_checked"] * (1.0 - waived_fraction(rep))
+    rep["decisions_asserted"] = asserted
+    assert asserted >= min_asserted, (asserted, min_asserted)
     assert rep["free_run"]["unexplained"] == 0
     rep["waived_fraction"] = waived_fraction(rep)
     fr = rep["free_run"]
@@ -72,7 +76,7 @@ def test_eagle_catch_perturbed_64(empc, problems):
     prm = ob.default_params()
     x0s = empc.perturbed_x0s(problem.x0, 64, nq=d.model.nq)
     rep = sw.stepwise_parity(factory(empc, problem, prm), d, prm, x0s, chunk=1024, tape_every=11)
-    check(rep, max_waived=0.10)
+    check(rep, max_waived=0.10, min_asserted=3000)  # (measured r04: 3 513 iterates, 93 skipped as exploded)
     save("eagle_catch_64", rep)
     assert rep["pairs"] > 2000 and rep["tapes_checked"] > 250
 
@@ -160,6 +164,8 @@ def test_long_running_shipped_files(empc, rel):
     try:
         # (perturbed hovers: most rollouts explode in their first iteration on both sides -- DESIGN.md, divergence study -- and
         #  iterate on at costs of 1e13: those iterates are skipped as exploded)
-        check(rep, max_waived=0.70 if "hexacopter370" in rel else 0.15)
+        # (r04: 358 iterates on the hover, 216 of them skipped: at least 100 must carry the assertions; the same kernels on a hover
+        #  whose iterates do not explode: tests/test_zz_gpu_round5.py::test_gentle_workloads_leave_nothing_waived)
+        check(rep, max_waived=0.70 if "hexacopter370" in rel else 0.15, min_asserted=100 if "hexacopter370" in rel else 0)
     finally:
         save(rel.replace("/", "_").replace(".yaml", ""), rep)

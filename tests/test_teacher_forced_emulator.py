@@ -41,3 +41,28 @@ def test_select_alone_follows_the_oracle(empc, problems, emu):
     pairs = [(b, i) for b in range(2) for i in range(len(paths[b]["iterates"]))]
     checked = sw.select_in_isolation(lambda n: sw.EmuBackend(emu, d, prm, n), d, prm, x0s, paths, pairs)
     assert checked == len(pairs)
+
+
+@pytest.mark.parametrize("workload", ["hover_gentle", "contact6d_baumgarte_gentle"])
+def test_gentle_workloads_leave_nothing_waived(empc, emu, tmp_path, workload):
+    """Workloads on which NO iterate explodes (the step-wise tests of the perturbed hover and of ContactModel6D waive
+    up to 70 % / 35 % of their iterations as exploded or chaotic): hexacopter370 hover from states perturbed by 0.002 and the
+    ContactModel6D variant of eagle_catch with Baumgarte gains (11, 5) -- every iteration of both sides' paths carries the
+    numerical assertions (measured here: waived 0.000 on 167 and 238 iterations).  The GPU edition with larger batches:
+    tests/test_zz_gpu_round5.py."""
+    from conftest import contact_variant
+    from test_gpu_teacher_forced import check
+    if workload == "hover_gentle":
+        t = empc.Trajectory()
+        t.autoSetup(empc.yaml_path("hexacopter370/trajectories/hover.yaml"))
+        problem = t.createProblem(40, True, "IntegratedActionModelEuler")
+        rollouts, kw, floor = 4, dict(tape_every=43, tol_tape=1e-8, tight=1e-12, do_same_minimum=False), 60
+    else:
+        _, problem = contact_variant(empc, tmp_path, "ContactModel6D", (11.0, 5.0))
+        rollouts, kw, floor = 2, dict(tape_every=41, do_same_minimum=False), 150
+    d = problem.desc
+    prm = ob.default_params()
+    x0s = empc.perturbed_x0s(problem.x0, rollouts, nq=d.model.nq, amplitude=0.002)
+    rep = sw.stepwise_parity(lambda n, p2: sw.EmuBackend(emu, d, p2 if p2 is not None else prm, n), d, prm, x0s, chunk=64, **kw)
+    check(rep, max_waived=0.05, min_asserted=floor)
+    print(workload, "pairs", rep["pairs"], "waived", rep["waived_fraction"], "asserted", rep["decisions_asserted"])
