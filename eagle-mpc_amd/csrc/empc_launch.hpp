@@ -161,7 +161,7 @@ __device__ __forceinline__ void lin_block(const DevBuffers& D, const int block, 
   // A unit that fills its wavefront (LPU = 64: the 11-dof class with contact dynamics) has a wave-uniform unit index: say so,
   // and the trajectory index, the record pointer and the unit's LDS block live in scalar registers.  (Besides the registers
   // it saves, this keeps those long-lived values out of the vector-register live-range splitting that, under the pressure
-  // of these instantiations, left the record pointer defined in lane 0 only -- DESIGN.md, round 4, "GPU memory fault".)
+  // of these instantiations, left the record pointer defined in lane 0 only -- LABNOTES.md, round 4, "GPU memory fault".)
   if constexpr (LPU == 64) u = __builtin_amdgcn_readfirstlane(u);
   bool active = i0 + u < nlist;
   int b = active ? (D.lin_list ? D.lin_list[i0 + u] : i0 + u) : (D.lin_list ? D.lin_list[i0] : i0);

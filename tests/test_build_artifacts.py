@@ -58,7 +58,7 @@ def test_chain_kernels_stay_out_of_scratch():
 
 
 def test_no_split_copy_in_front_of_an_exec_restore_in_linearize():
-    """the hazard behind the GPU memory fault of round 4: none of its shape in any linearize or calc
+    """the hazard behind the GPU memory fault of round 4 (LABNOTES.md section 3.0b): none of its shape in any linearize or calc
     kernel of the library (the per-knot kernels with the largest register footprints)"""
     import isa_exec_copy_scan as scan
     need("empc_inst_6_6_contact6.o", "empc_inst_4_6_contact6.o")  # (the two instantiations that showed it)

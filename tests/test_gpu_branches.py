@@ -365,7 +365,7 @@ def test_shortest_horizons_and_single_iterations(empc, name, dt):
         for key, mine in (("xs", np.array(s.xs)), ("us_squash", np.array(s.us_squash))):
             # knot by knot: a knot on which the oracle's own two builds differ by more than 1e-3 holds the squashed image of a
             # control from a trial that was blowing up (sigma of 1e22: both square roots cancel, what is left is rounding noise
-            # of any magnitude, DESIGN.md deviations) -- such knots carry no bound
+            # of any magnitude, LABNOTES.md deviations) -- such knots carry no bound
             noise_k = np.abs(rf[key] - r[key]).reshape(len(r[key]), -1).max(axis=1)
             err_k = np.abs(mine - r[key]).reshape(len(r[key]), -1).max(axis=1)
             # ... and nothing behind the first such knot is comparable either: the trial that set it was blowing up, and where

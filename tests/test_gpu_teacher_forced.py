@@ -169,7 +169,7 @@ def test_long_running_shipped_files(empc, rel):
     rep = sw.stepwise_parity(factory(empc, problem, prm), d, prm, x0s, tape_every=43, do_same_minimum="hover" in rel,
                              tol_tape=1e-8, tight=1e-12)
     try:
-        # (perturbed hovers: most rollouts explode in their first iteration on both sides -- DESIGN.md, divergence study -- and
+        # (perturbed hovers: most rollouts explode in their first iteration on both sides -- LABNOTES.md, divergence study -- and
         #  iterate on at costs of 1e13: those iterates are skipped as exploded)
         # (r04: 358 iterates on the hover, 216 of them skipped: at least 100 must carry the assertions; the same kernels on a hover
         #  whose iterates do not explode: tests/test_zz_gpu_round5.py::test_gentle_workloads_leave_nothing_waived)

@@ -35,7 +35,7 @@ def test_small_class_contact_phase_parity(empc, tmp_path, robot, contact, gains)
 @pytest.mark.parametrize("robot,contact,gains", [("hexacopter370", "ContactModel3D", (0.0, 0.0)), ("hexacopter680_flying_arm_2", "ContactModel6D", (5.0, 2.0))])
 def test_small_class_contact_stepwise(empc, tmp_path, robot, contact, gains):
     """Every iteration of the oracle's paths reproduced by the device and the other way round (tests/stepwise.py); the cold
-    starts of the hover files explode on both sides (divergence study): the bound on the waived share is the
+    starts of the hover files explode on both sides (LABNOTES.md, divergence study): the bound on the waived share is the
     perturbed hover's"""
     _, problem = small_class_contact_variant(empc, tmp_path, robot, contact, gains)
     d = problem.desc

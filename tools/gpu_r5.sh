@@ -126,7 +126,7 @@ PY
     bash "$0" abgap "$TAG"
     ;;
   abgap)
-    # the prepared rollout experiment: shipped library against libempc_gap.so (-DEMPC_ROLL_GAP_EARLY)
+    # the prepared rollout experiment (LABNOTES.md section 6.1): shipped library against libempc_gap.so (-DEMPC_ROLL_GAP_EARLY)
     if [ -f "$ROOT/eagle-mpc_amd/libempc_gap.so" ]; then
       for cfg in eagle_catch displacement push_slide; do
         bench_line "${cfg}_shipped" "EMPC_X=0" --config $cfg --no-cpu-baseline --no-secondary --no-slots-sweep --steps 10

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Static scan of the built kernels for one code-generation hazard seen in round 4 ("GPU memory fault"):
+"""Static scan of the built kernels for one code-generation hazard seen in round 4 (LABNOTES.md, "GPU memory fault"):
 
 the register allocator splits the live range of a long-lived vector register and leaves the split's copy
 (`v_mov_b64 vA, vB`) as the LAST instruction of a block that runs under a narrowed EXEC mask (an `if (lane == 0)` body), right

@@ -2,7 +2,7 @@
 """Static instruction mix of the loops of a kernel (from `llvm-objdump -d --symbolize-operands` of the built object).
 
 For the chain kernels the time of a launch is (knots) x (cycles per knot), and a wave64 FP64 instruction costs ~5 issue cycles
-whether or not it depends on its predecessor: the instruction count of the knot loop is the first-order
+whether or not it depends on its predecessor (LABNOTES.md section 3.1): the instruction count of the knot loop is the first-order
 model of the kernel.  This prints, for every backward branch (a loop) of the selected kernels, the number of instructions
 between the loop head and the branch by class: FP64 vector, MFMA, other vector, LDS, global / scratch memory, scalar loads,
 other scalar, waits, barriers.  Nested loops are listed separately (the outer one includes the inner one's body once).
