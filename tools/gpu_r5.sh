@@ -123,7 +123,7 @@ PY
     bash "$0" check "$TAG"
     bash "$0" profiles "$TAG"
     bash "$0" lines "$TAG"
-    bash "$0" abgap "$TAG"
+    bash "$0" variants "$TAG"
     ;;
   abgap)
     # the prepared rollout experiment (LABNOTES.md section 6.1): shipped library against libempc_gap.so (-DEMPC_ROLL_GAP_EARLY)
