@@ -4,15 +4,19 @@ the pool).  Builds tests/csrc/lane_emulator.cpp with -fsanitize=address,undefine
 shapes through both forms of the backward and rollout bodies and the lean / full linearize bodies.
 
     LD_PRELOAD="$(g++ -print-file-name=libasan.so) $(g++ -print-file-name=libstdc++.so.6)" ASAN_OPTIONS=detect_leaks=0 \
-        python tools/asan_emulator.py
+        python tools/asan_emulator.py [MACRO[=value] ...]
+Macros select a build-time variant of the kernel bodies (empc_variants.hpp), e.g. EMPC_BWD_R4B=1 EMPC_BOXQP_ONE_EXIT=1: the
+16-byte record moves of that variant read rows that end inside the next record (tape slack), which is what ASan checks here.
 """
 import subprocess
 import sys, os, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
-LIB = '/tmp/liblane_emulator_asan.so'
-subprocess.check_call(['g++', '-O1', '-g', '-std=c++20', '-pthread', '-fPIC', '-shared', '-fsanitize=address,undefined', '-fno-omit-frame-pointer',
+MACROS = [a for a in sys.argv[1:] if a.startswith("EMPC_")]
+LIB = '/tmp/liblane_emulator_asan%s.so' % "".join("_" + m.replace("=", "") for m in MACROS)
+subprocess.check_call(['g++', '-O1', '-g', '-std=c++20', '-pthread', '-fPIC', '-shared', '-fsanitize=address,undefined', '-fno-omit-frame-pointer'] + ["-D" + m for m in MACROS] + [
                        '-I' + os.path.join(ROOT, 'include'), os.path.join(ROOT, 'tests', 'csrc', 'lane_emulator.cpp'), '-o', LIB])
+print("sanitizer build with", MACROS or "the default switches", flush=True)
 import empc_loader, oracle_binding as ob
 empc = empc_loader.load()
 L = C.CDLL(LIB)

@@ -8,6 +8,7 @@
 #   tools/gpu_r5.sh lines        bench lines of hover and the three closed-loop MPC configurations
 #   tools/gpu_r5.sh slots        occupancy experiment (slots in flight x build variants)
 #   tools/gpu_r5.sh stamps       in-kernel cycle stamps (libempc_stamps.so)
+#   tools/gpu_r5.sh probes       tools/probes/*: layout + cost of v_mfma_f64_4x4x4 (not used by the product yet), pipeline latencies
 #   tools/gpu_r5.sh variants     prepared variant libraries (libempc_<tag>.so): parity core of the suite + bench lines, each against the shipped one
 # EMPC_COMMIT (exported by tools/gpurun_r5.sh) names the commit of the snapshot: it is written into every summary this script leaves.
 set -uo pipefail
@@ -124,6 +125,8 @@ PY
     bash "$0" profiles "$TAG"
     bash "$0" lines "$TAG"
     bash "$0" variants "$TAG"
+    bash "$0" probes "$TAG"
+    bash "$0" stamps "$TAG"
     ;;
   abgap)
     # the prepared rollout experiment (LABNOTES.md section 6.1): shipped library against libempc_gap.so (-DEMPC_ROLL_GAP_EARLY)
@@ -153,6 +156,12 @@ PY
         bench_line "${cfg}_${v}" "EMPC_LIB_PATH=$lib" --config $cfg --no-cpu-baseline --no-secondary --no-slots-sweep --steps 10
       done
     done
+    ;;
+  probes)
+    # one-wavefront probes of instructions the product does not use yet (built on the CPU side, shipped with the snapshot)
+    for pb in mfma_f64_4x4_probe latency_probe; do
+      [ -x "$ROOT/tools/probes/$pb" ] && { echo "== $pb"; timeout 120 "$ROOT/tools/probes/$pb"; echo "rc $?"; }
+    done 2>&1 | tee "gpurun_out/${TAG}_probes.log" | tail -${TAIL:-120}
     ;;
   stamps)
     # phase-level launches: product library first (ms per launch), then the diagnostic build with in-kernel cycle stamps
