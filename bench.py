@@ -391,8 +391,6 @@ def main():
         dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
         if dist.get_world_size() != args.gpus:
             raise SystemExit("process group of %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
-        if args.backend == "nccl" and torch.cuda.device_count() < world:
-            raise SystemExit("%d ranks on %d visible GPUs: one rank per GPU is the contract of --gpus N" % (world, torch.cuda.device_count()))
 
     is_mpc = args.config.endswith("_mpc")
     stream = (args.mode == "stream") and not is_mpc

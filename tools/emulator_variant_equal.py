@@ -20,12 +20,14 @@ _ip = C.POINTER(C.c_int)
 def load(path):
     tep.EMU = path
     return tep.emu.__wrapped__(empc)
+SCALE = 1.0  # size of the random candidate (tests/test_emulator_parity.py candidate): 1.0 = far from hover (most trial rollouts of the
+             # arm files overflow: compared as NaN == NaN), 0.15 = near hover (every trial finite); both are run
 def run(emu, problem, name):
     d = problem.desc; prm = ob.default_params()
     emu.emu_set_linearize_version(2); emu.emu_set_backward_version(4); emu.emu_set_rollout_version(6)
     e = C.c_void_p(emu.emu_create(C.byref(d), C.byref(prm), 1))
     T, nx, nu, nv = d.T, d.nx, d.nu, d.model.nv
-    xs, us = tep.candidate(d, 3)
+    xs, us = tep.candidate(d, 3, scale=SCALE)
     emu.emu_set_warmstart(e, ob.P(xs), ob.P(us)); emu.emu_phase_setup(e, 0.1, 0, 1e-9, 0)
     tape = np.zeros((T+1, emu.emu_rec(e))); acc = np.zeros((T+1, nv))
     emu.emu_phase_linearize(e, ob.P(tape), ob.P(acc))
@@ -51,11 +53,12 @@ for name in ("displacement","eagle_catch","push_slide","hover"):
     for integ in ("IntegratedActionModelEuler","IntegratedActionModelRK4"):
         if integ.endswith("RK4") and name in ("push_slide","hover"): continue
         problem = tr.createProblem(CONFIGS[name][1], True, integ)
-        ra, rb = run(a, problem, name), run(b, problem, name)
-        same = all(all(np.array_equal(x, y, equal_nan=True) for x, y in zip(p, q)) for p, q in zip(ra, rb))
-        moved = max(np.abs(p[0][-1]).max() for p in ra[1:])
-        all_same = all_same and same
-        print(name, integ, "bitwise equal:", same, "| finite:", all(np.isfinite(p[2]).all() for p in ra[1:]))
+        for SCALE in (1.0, 0.15):
+            ra, rb = run(a, problem, name), run(b, problem, name)
+            same = all(all(np.array_equal(x, y, equal_nan=True) for x, y in zip(p, q)) for p, q in zip(ra, rb))
+            all_same = all_same and same
+            print(name, integ, "candidate scale", SCALE, "bitwise equal:", same, "| finite trial rollouts: %d of %d" % (
+                sum(int(np.isfinite(p[2]).all() and np.isfinite(p[0]).all()) for p in ra[1:]), len(ra) - 1), flush=True)
 
 def box_solve(emu, tr, dt, warm, solver_type, maxiter=30):
     problem = tr.createProblem(dt, False, "IntegratedActionModelEuler")
