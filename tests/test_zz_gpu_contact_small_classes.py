@@ -32,18 +32,21 @@ def test_small_class_contact_phase_parity(empc, tmp_path, robot, contact, gains)
     phase_parity(empc, problem, robot + "/" + contact)
 
 
+@pytest.mark.parametrize("amplitude", [0.02, 0.002])
 @pytest.mark.parametrize("robot,contact,gains", [("hexacopter370", "ContactModel3D", (0.0, 0.0)), ("hexacopter680_flying_arm_2", "ContactModel6D", (5.0, 2.0))])
-def test_small_class_contact_stepwise(empc, tmp_path, robot, contact, gains):
-    """Every iteration of the oracle's paths reproduced by the device and the other way round (tests/stepwise.py); the cold
-    starts of the hover files explode on both sides (LABNOTES.md, divergence study): the bound on the waived share is the
-    perturbed hover's"""
+def test_small_class_contact_stepwise(empc, tmp_path, robot, contact, gains, amplitude):
+    """Every iteration of the oracle's paths reproduced by the device and the other way round (tests/stepwise.py).  Bounds on
+    the waived share: no hardware measurement exists yet, so they come from the same driver on the CPU lane emulator of these
+    kernel bodies (round 5: 0.257 on the hexacopter370 variant at amplitude 0.02 -- 27 of 113 iterates explode on both sides, the
+    cold-start behaviour of the hover files, LABNOTES.md divergence study -- and 0.000 on the three other cases) + 0.10; the
+    gentle perturbation leaves nothing to waive.  To be replaced by measured + 0.05 after the first hardware run."""
     _, problem = small_class_contact_variant(empc, tmp_path, robot, contact, gains)
     d = problem.desc
     prm = ob.default_params()
-    x0s = empc.perturbed_x0s(problem.x0, 3, nq=d.model.nq, amplitude=0.02)
+    x0s = empc.perturbed_x0s(problem.x0, 3, nq=d.model.nq, amplitude=amplitude)
     x0s[0] = problem.x0
     rep = sw.stepwise_parity(factory(empc, problem, prm), d, prm, x0s, maxiter=40, tape_every=13, do_same_minimum=False)
-    check(rep, max_waived=0.7)
+    check(rep, max_waived=0.36 if (robot == "hexacopter370" and amplitude == 0.02) else 0.10, min_asserted=30)
 
 
 def test_small_class_contact_solves_are_finite_and_batch_independent(empc, tmp_path):
