@@ -53,6 +53,7 @@ KernelTable empc_table_4_6_contact_mixed();
 KernelTable empc_table_6_6();
 KernelTable empc_table_6_6_contact();
 KernelTable empc_table_6_6_contact6();
+KernelTable empc_table_6_6_contact_mixed();  // (opt-in: EMPC_EXPERIMENTAL_CONTACT)
 // instantiations over the baked constants of a shipped robot (csrc/baked/, tools/bake_models.py): picked by find_table when
 // the problem's model and platform equal the baked tables bit for bit
 KernelTable empc_table_baked_arm3();

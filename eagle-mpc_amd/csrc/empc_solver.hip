@@ -122,6 +122,12 @@ static bool find_table(const DevProblem& P, int nb, int nrot, bool contact, int 
   else if (nb == 6 && nrot == 6 && !contact) k = empc_table_6_6();
   else if (nb == 6 && nrot == 6 && contact && contact_rows != 6 && contact_rows != empc::CT_MIXED) k = empc_table_6_6_contact();
   else if (nb == 6 && nrot == 6 && contact && contact_rows == 6) k = empc_table_6_6_contact6();
+  else if (nb == 6 && nrot == 6 && contact && contact_rows == empc::CT_MIXED && !experimental_contact()) {
+    find_table_reason = "stages of both contact types on the (6,6) robot class: kernels not yet verified on hardware; "
+                        "set EMPC_EXPERIMENTAL_CONTACT=1 to run them";
+    return false;
+  }
+  else if (nb == 6 && nrot == 6 && contact && contact_rows == empc::CT_MIXED) k = empc_table_6_6_contact_mixed();
   else return false;
   return true;
 }

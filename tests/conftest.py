@@ -140,6 +140,22 @@ def arm5_contact_variant(empc, tmp_path, contact="ContactModel3D", gains=(0.0, 0
     return tr, tr.createProblem(dt, True, "IntegratedActionModelEuler")
 
 
+def arm5_mixed_contact_variant(empc, tmp_path, gains6=(5.0, 2.0), dt=26):
+    """push_slide's robot with TWO contact stages appended, a ContactModel3D "push" and a ContactModel6D "hold": stages of both
+    contact types on the (6, 6) robot class (empc_inst_6_6_contact_mixed.hip; opt-in, EMPC_EXPERIMENTAL_CONTACT=1)."""
+    src = open(empc.yaml_path(CONFIGS["push_slide"][0])).read()
+    src = src.replace("duration: 2000 #ms", "duration: 780 #ms")
+    assert src.count("duration: 780 #ms") == 1
+    push = ARM5_CONTACT_STAGE % dict(contact="ContactModel3D", orientation="", g0=0.0, g1=0.0)
+    hold = (ARM5_CONTACT_STAGE % dict(contact="ContactModel6D", orientation='          orientation: [0, 0, 0, 1]\n',
+                                      g0=float(gains6[0]), g1=float(gains6[1]))).replace('- name: "push"', '- name: "hold"')
+    f = tmp_path / ("arm5_mixed_%g_%g.yaml" % tuple(gains6))
+    f.write_text(src.rstrip("\n") + "\n" + push.rstrip("\n") + "\n" + hold)
+    tr = empc.Trajectory()
+    tr.autoSetup(str(f))
+    return tr, tr.createProblem(dt, True, "IntegratedActionModelEuler")
+
+
 SMALL_CLASS_CONTACT_STAGE = '''
     - name: "touch"
       duration: 400 #ms

@@ -101,6 +101,20 @@ def test_small_class_contact_kernel_bodies_vs_oracle(empc, emu, tmp_path, monkey
     kernel_bodies(emu, problem, "eagle_catch", 2, 4, 6)  # ("eagle_catch": phases only, no emulated solve)
 
 
+def test_arm5_mixed_contact_kernel_bodies_vs_oracle(empc, emu, tmp_path, monkeypatch):
+    """Stages of BOTH contact types on the (6, 6) robot class (empc_inst_6_6_contact_mixed.hip): refused with the reason until the
+    opt-in is set (never run on hardware), accepted with it; tape / gains / rollouts of the kernel bodies against the oracle."""
+    from conftest import arm5_mixed_contact_variant
+    _, problem = arm5_mixed_contact_variant(empc, tmp_path)
+    d = problem.desc
+    assert {d.sets[d.knot_set[t]].contacts[0].type for t in range(d.T + 1) if d.sets[d.knot_set[t]].ncontacts > 0} == {empc.T.CONTACT_3D, empc.T.CONTACT_6D}
+    monkeypatch.delenv("EMPC_EXPERIMENTAL_CONTACT", raising=False)
+    assert not empc.solver_supported(problem) and "EMPC_EXPERIMENTAL_CONTACT" in empc.last_error()
+    monkeypatch.setenv("EMPC_EXPERIMENTAL_CONTACT", "1")
+    assert empc.solver_supported(problem), empc.last_error()
+    kernel_bodies(emu, problem, "eagle_catch", 2, 4, 6)  # ("eagle_catch": phases only, no emulated solve)
+
+
 def test_unweighted_quadratic_barrier_kernel_bodies(empc, emu, tmp_path):
     """ActivationModelQuadraticBarrier (bounds, no weights; src/factory/activation.cpp:53-68) through the kernel bodies"""
     from conftest import unweighted_barrier_variant

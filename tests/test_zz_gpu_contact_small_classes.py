@@ -61,3 +61,18 @@ def test_small_class_contact_solves_are_finite_and_batch_independent(empc, tmp_p
     for b in range(4):
         one.solve([], [], 30, x0s=x0s[b:b + 1])
         assert np.array_equal(one.xs_batch[0], s.xs_batch[b]) and one.iter_batch[0] == s.iter_batch[b]
+
+
+def test_arm5_mixed_contact(empc, tmp_path):
+    """stages of both contact types on the (6, 6) robot class (empc_inst_6_6_contact_mixed.hip, opt-in): phase parity and
+    step-wise parity on the push_slide robot with a ContactModel3D and a ContactModel6D stage appended"""
+    from conftest import arm5_mixed_contact_variant
+    _, problem = arm5_mixed_contact_variant(empc, tmp_path)
+    assert empc.solver_supported(problem), empc.last_error()
+    phase_parity(empc, problem, "arm5/mixed")
+    d = problem.desc
+    prm = ob.default_params()
+    x0s = empc.perturbed_x0s(problem.x0, 3, nq=d.model.nq, amplitude=0.002)
+    x0s[0] = problem.x0
+    rep = sw.stepwise_parity(factory(empc, problem, prm), d, prm, x0s, maxiter=40, tape_every=13, do_same_minimum=False)
+    check(rep, max_waived=0.10, min_asserted=20)
