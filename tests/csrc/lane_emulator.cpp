@@ -445,6 +445,34 @@ static void emu_solve(Emu& e, int maxiter, int is_feasible) {
   emu_run_sweeps<DM>(e);
 }
 
+#ifdef EMU_BAKED
+// -DEMU_BAKED: the kernel bodies instantiated over the BAKED robot tables (csrc/baked/empc_baked_models.hpp), the family the
+// shipped library runs for every shipped robot.  emu_create refuses a robot that differs from its table by one bit.  A build of
+// its own (tests/test_emulator_parity.py::test_baked_family_equals_runtime_family builds it on demand): the default emulator
+// keeps the runtime-model family and its compile time.
+template <class M>
+static bool emu_baked_is(const Emu* e) {
+  const BakedTree& t = M::tree();
+  const EmpcModelDesc& m = e->H.P.model;
+  if (m.nbodies != t.nbodies || m.nq != t.nq || m.nv != t.nv || e->H.P.n_rotors != t.n_rotors) return false;
+  auto same = [](const double* a, const double* b, int n) { return std::memcmp(a, b, sizeof(double) * n) == 0; };
+  for (int b = 0; b < m.nbodies; ++b) {
+    if (m.parent[b] != t.parent[b]) return false;
+    if (!same(m.jplace_R[b], t.jplace_R[b], 9) || !same(m.jplace_p[b], t.jplace_p[b], 3) || !same(m.axis[b], t.axis[b], 3) ||
+        !same(&m.mass[b], &t.mass[b], 1) || !same(m.com[b], t.com[b], 3) || !same(m.inertia[b], t.inertia[b], 9))
+      return false;
+  }
+  return same(m.gravity, t.gravity, 3) && same(e->H.P.tau_f, t.tau_f, 6 * e->H.P.n_rotors) && same(e->H.P.u_lb, t.u_lb, e->H.P.nu) &&
+         same(e->H.P.u_ub, t.u_ub, e->H.P.nu);
+}
+#define DISPATCH(e, FN, ...)                                                                         \
+  do {                                                                                               \
+    if (emu_baked_is<BakedHex370Arm3>(e)) FN<Dims<4, 6, BakedHex370Arm3>>(__VA_ARGS__);              \
+    else if (emu_baked_is<BakedHextiltArm5>(e)) FN<Dims<6, 6, BakedHextiltArm5>>(__VA_ARGS__);       \
+    else if (emu_baked_is<BakedHex370>(e)) FN<Dims<1, 6, BakedHex370>>(__VA_ARGS__);                 \
+    else { std::fprintf(stderr, "emulator (baked build): robot is not one of the baked tables\n"); } \
+  } while (0)
+#else
 #define DISPATCH(e, FN, ...)                                                    \
   do {                                                                          \
     if (e->nb == 1 && e->nrot == 6) FN<Dims<1, 6>>(__VA_ARGS__);                \
@@ -454,6 +482,7 @@ static void emu_solve(Emu& e, int maxiter, int is_feasible) {
     else if (e->nb == 6 && e->nrot == 6) FN<Dims<6, 6>>(__VA_ARGS__);           \
     else { std::fprintf(stderr, "emulator: unsupported dims\n"); }             \
   } while (0)
+#endif
 
 template <class DM>
 static void emu_node(Emu& e, int t, const double* x, const double* u, double smooth, double* xnext, double* acc, double* cost,
@@ -502,6 +531,13 @@ void* emu_create(const EmpcProblemDesc* d, const EmpcSolverParams* prm, int B) {
   e->NA = prm->n_alphas;
   e->nb = d->model.nbodies;
   e->nrot = d->n_rotors;
+#ifdef EMU_BAKED
+  if (!(emu_baked_is<BakedHex370Arm3>(e) || emu_baked_is<BakedHextiltArm5>(e) || emu_baked_is<BakedHex370>(e))) {
+    std::fprintf(stderr, "emu_create (baked build): robot is not one of the baked tables\n");
+    delete e;
+    return nullptr;
+  }
+#endif
   DISPATCH(e, emu_alloc, *e);
   std::memset(e->st.data(), 0, sizeof(TrajState) * B);
   return e;
@@ -641,6 +677,7 @@ void emu_set_gains(void* h, const double* K, const double* k) {
 int emu_stream_row_doubles(void* h) {
   Emu* e = static_cast<Emu*>(h);
   int n = 0;
+  // (the row layout depends on the dimensions only, not on the model family)
   if (e->nb == 1 && e->nrot == 6) n = emu_row_doubles<Dims<1, 6>>(*e);
   else if (e->nb == 1 && e->nrot == 4) n = emu_row_doubles<Dims<1, 4>>(*e);
   else if (e->nb == 3 && e->nrot == 6) n = emu_row_doubles<Dims<3, 6>>(*e);

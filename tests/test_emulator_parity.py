@@ -115,6 +115,66 @@ def test_arm5_mixed_contact_kernel_bodies_vs_oracle(empc, emu, tmp_path, monkeyp
     kernel_bodies(emu, problem, "eagle_catch", 2, 4, 6)  # ("eagle_catch": phases only, no emulated solve)
 
 
+@pytest.fixture(scope="module")
+def emu_baked(empc):
+    """the lane emulator built over the BAKED robot tables (-DEMU_BAKED, tests/csrc/lane_emulator.cpp): the kernel family the
+    shipped library runs for every shipped robot"""
+    global EMU
+    src = os.path.join(ROOT, "tests", "csrc", "lane_emulator.cpp")
+    lib = os.path.join(ROOT, "tests", "csrc", "liblane_emulator_baked.so")
+    hdrs = [os.path.join(ROOT, "eagle-mpc_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "eagle-mpc_amd", "csrc")) if f.endswith(".hpp")]
+    hdrs += [os.path.join(ROOT, "eagle-mpc_amd", "csrc", "baked", "empc_baked_models.hpp"), os.path.join(ROOT, "include", "empc_types.h"), src]
+    if not os.path.exists(lib) or any(os.path.getmtime(h) > os.path.getmtime(lib) for h in hdrs):
+        subprocess.check_call(["g++", "-O2", "-std=c++20", "-pthread", "-fPIC", "-shared", "-DEMU_BAKED", "-I" + os.path.join(ROOT, "include"), src, "-o", lib])
+    keep, EMU = EMU, lib
+    try:
+        return emu.__wrapped__(empc)
+    finally:
+        EMU = keep
+
+
+@pytest.mark.parametrize("name", ["displacement", "eagle_catch", "push_slide", "hover"])
+def test_baked_family_equals_runtime_family(empc, problems, emu, emu_baked, name):
+    """The kernel bodies instantiated over the baked constants of a shipped robot (what libempc.so runs by default) against the
+    runtime-model instantiation of the same source, on the CPU: tape, gains, Vx, expected-improvement sums and six step lengths
+    of the rollout from a random candidate with open gaps -- bit for bit (on the host a product with a structural zero is
+    still computed, so the two families perform the same operations; on the device the baked one folds them away and the
+    families agree to rounding, tests/test_gpu_baked.py).  Covers the generated tables and the BakedView / BakedPlatform code
+    paths without a GPU."""
+    _, problem = problems[name]
+    d = problem.desc
+    prm = ob.default_params()
+    T, nx, nu, nv = d.T, d.nx, d.nu, d.model.nv
+    out = []
+    for L in (emu, emu_baked):
+        L.emu_set_linearize_version(2)
+        L.emu_set_backward_version(4)
+        L.emu_set_rollout_version(6)
+        e = C.c_void_p(L.emu_create(C.byref(d), C.byref(prm), 1))
+        assert e.value, "the baked build refused a shipped robot"
+        xs, us = candidate(d, 5, scale=0.3)
+        L.emu_set_warmstart(e, ob.P(xs), ob.P(us))
+        L.emu_phase_setup(e, 0.1, 0, 1e-9, 0)
+        tape, acc = np.zeros((T + 1, L.emu_rec(e))), np.zeros((T + 1, nv))
+        L.emu_phase_linearize(e, ob.P(tape), ob.P(acc))
+        K, k, Vx, dg = np.zeros((T, nu, d.ndx)), np.zeros((T, nu)), np.zeros((T + 1, d.ndx)), np.zeros(2)
+        ok, fe, ce = np.zeros(1, dtype=np.int32), np.zeros(1, dtype=np.int32), np.zeros(1)
+        L.emu_phase_backward(e, ob.P(K), ob.P(k), ob.P(Vx), ob.P(dg), ok.ctypes.data_as(_ip), fe.ctypes.data_as(_ip), ob.P(ce))
+        res = [tape, acc, K, k, Vx, dg, ok, ce]
+        finite = 0
+        for ai in (1, 3, 5, 7, 8, 9):
+            xt, ut, ct, dv, okr = np.zeros((T + 1, nx)), np.zeros((T, nu)), np.zeros(1), np.zeros(1), np.zeros(1, dtype=np.int32)
+            L.emu_phase_rollout(e, ai, ob.P(xt), ob.P(ut), ob.P(ct), ob.P(dv), okr.ctypes.data_as(_ip))
+            res += [xt, ut, ct, dv, okr]
+            finite += int(np.isfinite(xt).all(axis=1).sum())
+        L.emu_destroy(e)
+        out.append((res, finite))
+    (a, fa), (b, fb) = out
+    assert np.isfinite(a[0]).all() and a[6][0] == 1 and fa == fb and fa > 2 * (T + 1)  # (at least two trials finite to the end)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y, equal_nan=True)
+
+
 def test_unweighted_quadratic_barrier_kernel_bodies(empc, emu, tmp_path):
     """ActivationModelQuadraticBarrier (bounds, no weights; src/factory/activation.cpp:53-68) through the kernel bodies"""
     from conftest import unweighted_barrier_variant
