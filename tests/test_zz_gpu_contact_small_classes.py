@@ -2,6 +2,8 @@
 (1, 4) iris, (3, 6) hexacopter680_flying_arm_2 -- with ContactModel3D and ContactModel6D (src/factory/contacts.cpp:26-79 builds
 a contact for any robot).  The problems are hover files with a contact stage at the base link
 appended (conftest.small_class_contact_variant).  Kernel instantiations: empc_inst_{1_6,1_4,3_6}_contact.hip."""
+import os
+
 import numpy as np
 import pytest
 
@@ -11,7 +13,13 @@ from conftest import SMALL_CLASSES, small_class_contact_variant
 from test_gpu_parity import phase_parity
 from test_gpu_teacher_forced import check, factory
 
-pytestmark = pytest.mark.gpu
+# These instantiations have never run on hardware, and round 4's only GPU memory fault came from a contact instantiation the lane
+# emulator had no complaint about: a fault here would take the whole `pytest -m gpu` process down with it.  So the file is skipped
+# unless asked for (tools/gpu_r5.sh runs it in a pytest process of its own); after its first green run on an MI355X the opt-in of
+# the kernels (EMPC_EXPERIMENTAL_CONTACT) and this guard go away together.
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(os.environ.get("EMPC_RUN_EXPERIMENTAL_GPU_TESTS", "") in ("", "0"),
+                                 reason="kernels never run on hardware: set EMPC_RUN_EXPERIMENTAL_GPU_TESTS=1 (tools/gpu_r5.sh experimental)")]
 
 
 @pytest.fixture(autouse=True)

@@ -8,6 +8,7 @@
 #   tools/gpu_r5.sh lines        bench lines of hover and the three closed-loop MPC configurations
 #   tools/gpu_r5.sh slots        occupancy experiment (slots in flight x build variants)
 #   tools/gpu_r5.sh stamps       in-kernel cycle stamps (libempc_stamps.so)
+#   tools/gpu_r5.sh experimental GPU tests of the opt-in problem classes (never run on hardware), in their own pytest process
 #   tools/gpu_r5.sh probes       tools/probes/*: layout + cost of v_mfma_f64_4x4x4 (not used by the product yet), pipeline latencies
 #   tools/gpu_r5.sh variants     prepared variant libraries (libempc_<tag>.so): parity core of the suite + bench lines, each against the shipped one
 # EMPC_COMMIT (exported by tools/gpurun_r5.sh) names the commit of the snapshot: it is written into every summary this script leaves.
@@ -125,6 +126,7 @@ PY
     bash "$0" profiles "$TAG"
     bash "$0" lines "$TAG"
     bash "$0" variants "$TAG"
+    bash "$0" experimental "$TAG"
     bash "$0" probes "$TAG"
     bash "$0" stamps "$TAG"
     ;;
@@ -156,6 +158,11 @@ PY
         bench_line "${cfg}_${v}" "EMPC_LIB_PATH=$lib" --config $cfg --no-cpu-baseline --no-secondary --no-slots-sweep --steps 10
       done
     done
+    ;;
+  experimental)
+    # GPU tests of kernels that have never run on hardware (opt-in problem classes), in a pytest process of their own: a fault
+    # here must not take the suite with it
+    EMPC_RUN_EXPERIMENTAL_GPU_TESTS=1 timeout 1200 python -m pytest tests/test_zz_gpu_contact_small_classes.py -q -m gpu --durations=5 2>&1 | tail -30 | tee "gpurun_out/${TAG}_pytest_experimental.log"
     ;;
   probes)
     # one-wavefront probes of instructions the product does not use yet (built on the CPU side, shipped with the snapshot)
