@@ -17,4 +17,15 @@ done
 [ -f "gpurun_out/${TAG}_pytest.log" ] && cp "gpurun_out/${TAG}_pytest.log" "profiles/r05_pytest_gpu.log"
 mkdir -p profiles/r05_stepwise
 cp gpurun_out/parity/r05_stepwise_*.json profiles/r05_stepwise/ 2>/dev/null || true
-ls -la profiles | grep r05_ | head -40
+# round 5: first-run reports, variant A/B lines, probes, stamps
+for f in r05_margin_profile.json r05_poisoned_inputs_displacement.json r05_poisoned_inputs_eagle_catch.json; do
+  [ -s "gpurun_out/parity/$f" ] && cp "gpurun_out/parity/$f" "profiles/$f"
+done
+for f in gpurun_out/${TAG}_pytest_*.log gpurun_out/${TAG}_probes.log gpurun_out/${TAG}_stamps.log; do
+  [ -s "$f" ] && cp "$f" "profiles/r05_$(basename "$f" | sed "s/^${TAG}_//")"
+done
+mkdir -p profiles/r05_variants
+for f in gpurun_out/${TAG}_bench_*_shipped.json gpurun_out/${TAG}_bench_*_r4b.json gpurun_out/${TAG}_bench_*_gap.json gpurun_out/${TAG}_bench_*_bits.json; do
+  [ -s "$f" ] && cp "$f" "profiles/r05_variants/$(basename "$f" | sed "s/^${TAG}_//")"
+done
+ls -la profiles | grep r05_ | head -60
