@@ -68,3 +68,31 @@ def test_no_split_copy_in_front_of_an_exec_restore_in_linearize():
                 continue
             far = [h for h in scan.scan(lines) if h[2] - h[0] >= scan.FAR]
             assert not far, (os.path.basename(obj), name, far[:3])
+
+
+def test_nan_guards_survive_the_nan_free_build_of_the_baked_units():
+    """The baked translation units are compiled -fno-honor-nans -fno-signed-zeros (Makefile BAKEDFLAGS) so that products with a
+    robot's structural zeros fold; the solver's NaN / overflow guards are tests on the bit pattern (is_nan, bad_number:
+    empc_dev_math.hpp) precisely so that this flag cannot fold them.  Checked on the machine code: every
+    model-touching kernel of a baked unit carries as many 64-bit integer compares (and v_cmp_class) as its runtime-model sibling,
+    which is built without the flag -- and more than none where the source has guards (the rollouts)."""
+    import isa_exec_copy_scan as scan
+    guard = re.compile(r"\bv_cmpx?_[a-z]+_u64|\bv_cmp_class_f64")
+    pairs = [("empc_inst_baked_arm3.o", "empc_inst_4_6.o", "BakedHex370Arm3"), ("empc_inst_baked_arm3_contact.o", "empc_inst_4_6_contact.o", "BakedHex370Arm3"),
+             ("empc_inst_baked_arm5.o", "empc_inst_6_6.o", "BakedHextiltArm5")]
+    checked = with_guards = 0
+    for baked_o, runtime_o, model in pairs:
+        b, r = need(baked_o, runtime_o)
+        kb, kr = scan.disassemble(b), scan.disassemble(r)
+        count = lambda lines: sum(1 for l in lines if guard.search(l))
+        # mangled names: the model type is the only difference (N4empc15BakedHex370Arm3E <-> NS0_12RuntimeModelE / N4empc12RuntimeModelE)
+        for name, lines in kb.items():
+            if model not in name or not re.search(r"k_rollout|k_linearize|k_calc|k_plant", name):
+                continue
+            sib = [n for n in kr if re.sub(r"\d+%s" % model, "12RuntimeModel", name) == n]
+            assert len(sib) == 1, (name, baked_o)
+            nb, nr = count(lines), count(kr[sib[0]])
+            assert nb == nr, (name, nb, nr)
+            checked += 1
+            with_guards += nb > 0
+    assert checked >= 12 and with_guards >= 6, (checked, with_guards)
