@@ -365,6 +365,16 @@ def teacher_forced(backend_factory, desc, prm, x0s, paths, maxiter=100, chunk=10
             amp = 1.0
             where = "rollout %d iterate %d (pass %d iter %d)" % (b, i, it["phase"], it["iter"])
             # ---- after calcDiff + computeDirection -------------------------------------------------------------------
+            # (an iterate that has exploded is set aside BEFORE the outcome of computeDirection is compared: with joint angles of
+            #  1e7 rad the two sides' tapes differ in every digit, and so may the number of regularisation retries -- found by the
+            #  round-5 emulator soak, seed 53: eagle_catch iterate at cost 4e17 on which the oracle's LLT fails at every
+            #  regularisation and the device's passes at 1e3)
+            if (float(np.abs(it["xs"][:, 7:]).max()) > BLOWN_UP or abs(p["cost"]) > COST_EXPLODED or float(np.abs(it["xs"][:, :3]).max()) > BLOWN_UP):
+                rep["blown_up_iterates"] = rep.get("blown_up_iterates", 0) + 1
+                rep["iterates_skipped_exploded"] = rep.get("iterates_skipped_exploded", 0) + 1
+                assert np.isfinite(g.cost) or not np.isfinite(p["cost"]), where
+                rep["decisions_checked"] += 1
+                continue
             if bool(g.bwd_failed) != (not p["direction_ok"]):
                 # computeDirection gives up (regularisation at its maximum) on one side only: legitimate when the oracle's own
                 # builds disagree on the retries for this iterate (a Quu pivot tied to rounding precision)

@@ -24,7 +24,7 @@ from conftest import CONFIGS
 
 def main():
     n, seed = int(sys.argv[1]), int(sys.argv[2])
-    out = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles", "r04_stepwise_emulator_soak.jsonl")
+    out = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles", "r05_stepwise_emulator_soak.jsonl")
     emu = sw.load_emulator()
     for name in ("displacement", "eagle_catch", "push_slide", "hover"):
         rel, dt = CONFIGS[name]
@@ -56,7 +56,7 @@ def variants():
     import tempfile
     from conftest import arm5_contact_variant, contact_variant, mixed_contact_variant, small_class_contact_variant
     n, seed = int(sys.argv[2]), int(sys.argv[3])
-    out = os.path.join(ROOT, "profiles", "r04_stepwise_emulator_soak.jsonl")
+    out = os.path.join(ROOT, "profiles", "r05_stepwise_emulator_soak.jsonl")
     emu = sw.load_emulator()
     tmp = pathlib.Path(tempfile.mkdtemp())
     tr = empc.Trajectory()
