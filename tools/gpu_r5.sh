@@ -144,7 +144,7 @@ PY
     # with the snapshot): the parity core of the GPU suite through that library, then bench lines against the shipped one.
     # VARIANTS="gap r4b ..." restricts the list; QUICK_TESTS is the parity core (phase parity, step-wise parity, golden vectors,
     # failure exits, box solvers, stream bitwise)
-    QT="${QUICK_TESTS:-tests/test_gpu_parity.py tests/test_gpu_teacher_forced.py tests/test_gpu_eagle_catch.py tests/test_gpu_branches.py tests/test_gpu_box_solvers.py tests/test_gpu_stream.py tests/test_gpu_baked.py}"
+    QT="${QUICK_TESTS:-tests/test_gpu_parity.py tests/test_gpu_teacher_forced.py tests/test_gpu_eagle_catch.py tests/test_gpu_branches.py tests/test_gpu_box_solvers.py tests/test_gpu_stream.py tests/test_gpu_baked.py tests/test_gpu_contact_arm5.py tests/test_gpu_contact_options.py tests/test_gpu_all_problems.py}"
     for cfg in ${CONFIGS:-eagle_catch displacement push_slide}; do
       bench_line "${cfg}_shipped" "EMPC_X=0" --config $cfg --no-cpu-baseline --no-secondary --no-slots-sweep --steps 10
     done
