@@ -365,10 +365,11 @@ def teacher_forced(backend_factory, desc, prm, x0s, paths, maxiter=100, chunk=10
             amp = 1.0
             where = "rollout %d iterate %d (pass %d iter %d)" % (b, i, it["phase"], it["iter"])
             # ---- after calcDiff + computeDirection -------------------------------------------------------------------
-            # (an iterate that has exploded is set aside BEFORE the outcome of computeDirection is compared: with joint angles of
-            #  1e7 rad the two sides' tapes differ in every digit, and so may the number of regularisation retries -- found by the
+            # (an iterate that has exploded is set aside BEFORE the outcome of computeDirection is compared: the tapes of the two
+            #  sides still agree to 1e-14, but the Riccati recursion inverts Quu of 1e17-sized terms at a condition number that
+            #  turns the last bit into the leading digit, and so the number of regularisation retries may differ -- found by the
             #  round-5 emulator soak, seed 53: eagle_catch iterate at cost 4e17 on which the oracle's LLT fails at every
-            #  regularisation and the device's passes at 1e3)
+            #  regularisation (pivot -1.7e8 among entries of 2e11) and the device's passes at 1e3)
             if (float(np.abs(it["xs"][:, 7:]).max()) > BLOWN_UP or abs(p["cost"]) > COST_EXPLODED or float(np.abs(it["xs"][:, :3]).max()) > BLOWN_UP):
                 rep["blown_up_iterates"] = rep.get("blown_up_iterates", 0) + 1
                 rep["iterates_skipped_exploded"] = rep.get("iterates_skipped_exploded", 0) + 1
