@@ -395,8 +395,8 @@ def teacher_forced(backend_factory, desc, prm, x0s, paths, maxiter=100, chunk=10
                 rep["blown_up_iterates"] = rep.get("blown_up_iterates", 0) + 1
             if xmax > BLOWN_UP or abs(p["cost"]) > COST_EXPLODED or float(np.abs(it["xs"][:, :3]).max()) > BLOWN_UP:
                 # joint angles / rates beyond 1e3 (3 is normal): a rollout that has already exploded (cost 1e13) and iterates on at
-                # that level until the iteration limit.  The device's sin / cos are specified for |x| << 2^20 pi/2 (Cody-Waite
-                # reduction, empc_dev_math.hpp) and every cost term cancels at 1e13: nothing here is comparable at rounding level.
+                # that level until the iteration limit.  Every cost term cancels at 1e13 and the Riccati recursion is ill-conditioned
+                # to the last bit there: nothing is comparable at rounding level (the scalar functions themselves stay accurate).
                 # Counted, finite outputs required, not compared.
                 rep["iterates_skipped_exploded"] = rep.get("iterates_skipped_exploded", 0) + 1
                 assert np.isfinite(g.cost) or not np.isfinite(p["cost"]), where
