@@ -66,3 +66,21 @@ def test_gentle_workloads_leave_nothing_waived(empc, emu, tmp_path, workload):
     rep = sw.stepwise_parity(lambda n, p2: sw.EmuBackend(emu, d, p2 if p2 is not None else prm, n), d, prm, x0s, chunk=64, **kw)
     check(rep, max_waived=0.05, min_asserted=floor)
     print(workload, "pairs", rep["pairs"], "waived", rep["waived_fraction"], "asserted", rep["decisions_asserted"])
+
+
+def test_exploded_iterate_with_different_direction_outcome_is_set_aside(empc, problems, emu):
+    """Regression of the harness (round-5 soak, seed 53): a rollout whose iterates explode (cost 4e17, joint angles of 8e7 rad)
+    reaches an iterate on which the oracle's computeDirection gives up at every regularisation while the device's succeeds at
+    1e3 -- tapes equal to 1e-14, the ill-conditioned recursion differs.  Such an iterate is counted as exploded, not asserted
+    on; everything else of the rollout still goes through the comparison."""
+    _, problem = problems["eagle_catch"]
+    d = problem.desc
+    prm = ob.default_params()
+    x0s = empc.perturbed_x0s(problem.x0, 8, nq=d.model.nq, seed=53)[4:5]
+    paths = sw.oracle_paths(d, prm, x0s)
+    assert len(paths[0]["iterates"]) > 114
+    # (the twelve iterates around the one in question: the whole path costs 100 s of oracle variants on the CPU)
+    paths[0]["iterates"] = paths[0]["iterates"][106:118]
+    rep = sw.teacher_forced(lambda n: sw.EmuBackend(emu, d, prm, n), d, prm, x0s, paths, chunk=64, tape_every=5)
+    assert rep["decisions_checked"] == rep["pairs"] == len(paths[0]["iterates"]) >= 9
+    assert rep.get("iterates_skipped_exploded", 0) >= 1
