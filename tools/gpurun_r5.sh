@@ -4,7 +4,7 @@
 # The call's console goes to gpurun_out/<tag>_call.log; a tree with uncommitted changes is marked "<sha>+dirty".
 set -uo pipefail
 cd "$(dirname "${BASH_SOURCE[0]}")/.."
-MODE="${1:-check}"; TAG="${2:-r05}"; TMO="${3:-2700}"; shift 3 2>/dev/null || true
+MODE="${1:-check}"; TAG="${2:-r05}"; TMO="${3:-2700}"; shift $(( $# < 3 ? $# : 3 ))
 SHA=$(git rev-parse --short HEAD)
 [ -n "$(git status --porcelain -- eagle-mpc_amd include bench.py tests tools oracle | head -1)" ] && SHA="${SHA}+dirty"
 mkdir -p gpurun_out
