@@ -434,13 +434,23 @@ def main():
     seen_devices = {}
 
     def gather_device_ids():
-        # which GPU each rank really computes on, through the same collective backend as the result rows and inside the timed
-        # region (16 bytes per rank): (index torch selected, PCI bus id of the device libempc.so runs on).  Two ranks on one GPU or
-        # a rank that fell back to another device show up in the line (`rccl_ranks_seen`) instead of in a quietly wrong value.
-        p = torch.cuda.get_device_properties(local_dev) if torch.cuda.is_available() else None
-        bus = (getattr(p, "pci_bus_id", -1) if p is not None else -1)
-        uuid_hash = (zlib.crc32(str(getattr(p, "uuid", "")).encode()) & 0x7FFFFFFF) if p is not None else -1
-        mine = torch.tensor([float(rank), float(torch.cuda.current_device() if torch.cuda.is_available() else -1), float(bus), float(uuid_hash)],
+        # which GPU each rank really computed on, through the same collective backend as the result rows, AFTER the closing
+        # barrier (outside the timed interval): (rank, device index, PCI bus number, hash of the full bus id) of the device
+        # libempc.so's solver memory lives on (empc_solver_device_info: hipPointerGetAttributes of its problem image), and
+        # torch's own selection beside it.  Two ranks on one GPU, or a solver that fell back to another device than the one torch
+        # (and so RCCL) uses, show up in the line (`rccl_ranks_seen`) instead of in a quietly wrong value.
+        try:
+            dev, busid = solver.device_info()
+        except Exception:  # (CPU dry runs over gloo have no solver handle on a device)
+            dev, busid = -1, ""
+        tdev = torch.cuda.current_device() if torch.cuda.is_available() else -1
+        tbus = ""
+        if torch.cuda.is_available():
+            tp = torch.cuda.get_device_properties(tdev)
+            tbus = "%04x:%02x:%02x" % (getattr(tp, "pci_domain_id", 0), getattr(tp, "pci_bus_id", 0), getattr(tp, "pci_device_id", 0))
+        same = float(dev == tdev and (not tbus or busid.lower().startswith(tbus)))
+        bus_num = int(busid.split(":")[1], 16) if busid.count(":") >= 2 else -1
+        mine = torch.tensor([float(rank), float(dev), float(bus_num), float(zlib.crc32(busid.encode()) & 0x7FFFFFFF), same],
                             dtype=torch.float64, device=coll_dev)
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
@@ -514,12 +524,13 @@ def main():
         solver.stream_run(args.maxiter)
         if dist is not None:
             gather_step(stream_rows=True)
-            gather_device_ids()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         elapsed = time.perf_counter() - t0
         agg = solver.stats()
+        if dist is not None:
+            gather_device_ids()
     else:
         for _ in range(args.warmup):
             one_step()
@@ -531,12 +542,12 @@ def main():
             st = one_step()
             for k, v in st.items():
                 agg[k] = agg.get(k, 0) + v
-        if dist is not None:
-            gather_device_ids()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         elapsed = time.perf_counter() - t0
+        if dist is not None:
+            gather_device_ids()
     iters_rank = float(agg["total_iters"])
     ranks_seen, ranks_golden_ok = 1, None
     per_rank = None
@@ -665,8 +676,10 @@ def main():
             devs = seen_devices.get("rows", [])
             distinct = len(set((r[1], r[2], r[3]) for r in devs))
             out["rccl_ranks_seen"] = {"backend": args.backend, "ranks": len(devs), "distinct_devices": distinct,
-                                      "rank_device_busid": [[r[0], r[1], r[2]] for r in devs]}
-            if args.backend == "nccl" and (len(devs) != args.gpus or distinct != args.gpus):
+                                      "rank_device_busnumber": [[r[0], r[1], r[2]] for r in devs],
+                                      "solver_device_is_torch_device": [bool(r[4]) for r in devs],
+                                      "source": "empc_solver_device_info (where the solver's memory lives), gathered after the timed region"}
+            if args.backend == "nccl" and (len(devs) != args.gpus or distinct != args.gpus or not all(r[4] for r in devs)):
                 raise SystemExit("multi-GPU self-check failed: %d ranks on %d distinct GPUs, --gpus %d: %s" %
                                  (len(devs), distinct, args.gpus, json.dumps(out["rccl_ranks_seen"])))
             out["ranks_seen"] = ranks_seen

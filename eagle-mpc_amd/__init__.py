@@ -112,6 +112,7 @@ def lib():
     L.empc_solver_stream_run.argtypes = [C.c_void_p, C.c_int]
     L.empc_solver_stream_results.argtypes = [C.c_void_p, _dp, _ip]
     L.empc_solver_stream_results_device.argtypes = [C.c_void_p, C.c_void_p]
+    L.empc_solver_device_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_char_p, C.c_int]
     L.empc_plant_set_state.argtypes = [C.c_void_p, _dp]
     L.empc_plant_get_state.argtypes = [C.c_void_p, _dp]
     L.empc_plant_step.argtypes = [C.c_void_p, C.c_double, _dp, C.c_int]
@@ -828,6 +829,12 @@ class SolverSbFDDP:
     def stream_results_device(self, device_ptr):
         """the result rows copied device to device to `device_ptr` (n_jobs x stream_row_doubles() doubles)"""
         _check(lib().empc_solver_stream_results_device(self._h, C.c_void_p(device_ptr)))
+
+    def device_info(self):
+        """(HIP device index the solver's memory lives on, its PCI bus id) -- asked of the library, not echoed from the constructor"""
+        dev, bus = C.c_int(-1), C.create_string_buffer(32)
+        _check(lib().empc_solver_device_info(self._h, C.byref(dev), bus, 32))
+        return dev.value, bus.value.decode()
 
     def solve_stream(self, x0s, maxiter=100):
         self.stream_begin(x0s)

@@ -972,6 +972,18 @@ int empc_solver_stream_results_device(EmpcSolver* s, double* dst_device) {
   EMPC_CATCH(RET_INT)
 }
 
+int empc_solver_device_info(EmpcSolver* s, int* device_index, char* pci_bus_id, int pci_len) {
+  EMPC_TRY
+  if (!s) throw std::invalid_argument("NULL argument");
+  // where the solver's device memory really lives (not what the caller asked for): attributes of its problem image
+  hipPointerAttribute_t at;
+  HIP_CHECK(hipPointerGetAttributes(&at, s->dP));
+  if (device_index) *device_index = at.device;
+  if (pci_bus_id && pci_len > 0) HIP_CHECK(hipDeviceGetPCIBusId(pci_bus_id, pci_len, at.device));
+  return EMPC_OK;
+  EMPC_CATCH(RET_INT)
+}
+
 // ---- step-wise entry points (include/empc.h): one iteration from any iterate -------------------------------------------
 int empc_solver_get_states(EmpcSolver* s, EmpcTrajState* states) {
   EMPC_TRY

@@ -217,6 +217,10 @@ int empc_solver_stream_results(EmpcSolver* s, double* rows /* n_jobs x row */, i
 /* the same rows copied device to device (dst_device: n_jobs x row doubles of DEVICE memory, e.g. the send buffer of the
  * multi-GPU gather): nothing of the payload touches the host */
 int empc_solver_stream_results_device(EmpcSolver* s, double* dst_device);
+/* the HIP device the solver's memory lives on (queried from its problem image, not echoed from empc_solver_create) and that
+ * device's PCI bus id "domain:bus:device.function" (pci_bus_id may be NULL; pci_len >= 16) -- the multi-GPU self-check of
+ * bench.py compares it across ranks (one rank per GPU) */
+int empc_solver_device_info(EmpcSolver* s, int* device_index, char* pci_bus_id, int pci_len);
 
 /* offsets (in doubles) of the blocks inside one tape record */
 typedef struct EmpcTapeLayout {

@@ -29,7 +29,13 @@ def test_shipped_device_code_is_the_hardware_verified_one():
     if not glob.glob(os.path.join(BUILD, "csrc", "empc_inst_*.o")) or not os.path.isfile("/opt/rocm/lib/llvm/bin/llvm-readelf"):
         pytest.skip("built objects or the LLVM tools are missing")
     import codeobj_compare as cc
+    objs = glob.glob(os.path.join(BUILD, "**", "*.o"), recursive=True)
+    before = {o: os.stat(o).st_mtime_ns for o in objs}
     n, diff, unknown, missing = cc.check_manifest(MANIFEST, BUILD)
+    import kernel_resources as kr
+    kr.notes(sorted(glob.glob(os.path.join(BUILD, "csrc", "empc_inst_*.o")))[0])
+    # the inspectors work on copies: certifying the shipped objects must not touch them (make would relink libempc.so)
+    assert before == {o: os.stat(o).st_mtime_ns for o in objs}
     man = json.load(open(MANIFEST))
     assert n == man["kernels"] and not missing, (n, man["kernels"], missing)
     assert not diff, "device code differs from the tree verified on hardware (%s): %s" % (man["commit"], list(cc.demangle(diff).values())[:6])

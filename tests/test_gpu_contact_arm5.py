@@ -37,7 +37,7 @@ def test_arm5_contact_stepwise(empc, tmp_path, contact, gains):
     x0s[0] = problem.x0
     rep = sw.stepwise_parity(factory(empc, problem, prm), d, prm, x0s, maxiter=60, tape_every=23)
     save("arm5_contact_%s_%g" % (contact, gains[0]), rep)
-    check(rep)
+    check(rep, max_exploded=5)  # (measured r04 on hardware: 0 exploded)
 
 
 @pytest.mark.parametrize("contact,gains", [VARIANTS[0], VARIANTS[2]])

@@ -68,7 +68,7 @@ def test_mixed_contact_stepwise(empc, tmp_path):
     x0s[0] = problem.x0
     rep = sw.stepwise_parity(factory(empc, problem, prm), d, prm, x0s, tape_every=31)
     save("contact_mixed", rep)
-    check(rep)
+    check(rep, max_exploded=5)  # (measured r04 on hardware: 0 exploded)
 
 
 def test_mixed_contact_solve(empc, tmp_path):

@@ -54,7 +54,7 @@ def waived_fraction(rep):
     return waived / max(rep["decisions_checked"], 1)
 
 
-def check(rep, max_waived=0.10, min_asserted=0, max_exploded=None):
+def check(rep, max_waived=0.10, min_asserted=0, *, max_exploded):
     """every pair went through the comparison, nothing unexplained in the reverse direction, and the waivers stay a bounded
     minority (a collapse of the harness into 'everything excused' fails here); `min_asserted`: an absolute floor on the
     iterations that DID carry the numerical assertions (a loose relative bound alone lets a test pass on a handful)"""
@@ -62,8 +62,8 @@ def check(rep, max_waived=0.10, min_asserted=0, max_exploded=None):
     asserted = rep["decisions_checked"] * (1.0 - waived_fraction(rep))
     rep["decisions_asserted"] = asserted
     assert asserted >= min_asserted, (asserted, min_asserted)
-    if max_exploded is not None:  # (the measured count of the last hardware run + ~20 %)
-        assert rep.get("iterates_skipped_exploded", 0) <= max_exploded, (rep.get("iterates_skipped_exploded"), max_exploded)
+    # (the measured count of the last hardware run + ~20 %; mandatory: exploded iterates are compared for nothing but finiteness)
+    assert rep.get("iterates_skipped_exploded", 0) <= max_exploded, (rep.get("iterates_skipped_exploded"), max_exploded)
     assert rep["free_run"]["unexplained"] == 0
     rep["waived_fraction"] = waived_fraction(rep)
     fr = rep["free_run"]

@@ -54,7 +54,7 @@ def test_small_class_contact_stepwise(empc, tmp_path, robot, contact, gains, amp
     x0s = empc.perturbed_x0s(problem.x0, 3, nq=d.model.nq, amplitude=amplitude)
     x0s[0] = problem.x0
     rep = sw.stepwise_parity(factory(empc, problem, prm), d, prm, x0s, maxiter=40, tape_every=13, do_same_minimum=False)
-    check(rep, max_waived=0.36 if (robot == "hexacopter370" and amplitude == 0.02) else 0.10, min_asserted=30)
+    check(rep, max_waived=0.36 if (robot == "hexacopter370" and amplitude == 0.02) else 0.10, min_asserted=30, max_exploded=40)
 
 
 def test_small_class_contact_solves_are_finite_and_batch_independent(empc, tmp_path):
@@ -83,4 +83,4 @@ def test_arm5_mixed_contact(empc, tmp_path):
     x0s = empc.perturbed_x0s(problem.x0, 3, nq=d.model.nq, amplitude=0.002)
     x0s[0] = problem.x0
     rep = sw.stepwise_parity(factory(empc, problem, prm), d, prm, x0s, maxiter=40, tape_every=13, do_same_minimum=False)
-    check(rep, max_waived=0.10, min_asserted=20)
+    check(rep, max_waived=0.10, min_asserted=20, max_exploded=10)

@@ -25,7 +25,9 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 
 def code_object(obj, d):
     fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "k.co")
-    r = subprocess.run([LLVM + "/llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, obj], capture_output=True, text=True)
+    # an explicit output file: with none, llvm-objcopy rewrites its input in place (same content, new mtime -> make relinks)
+    r = subprocess.run([LLVM + "/llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, obj, os.path.join(d, "copy.o")],
+                       capture_output=True, text=True)
     if r.returncode != 0:
         return None  # an object without device code (the host driver)
     subprocess.run([LLVM + "/clang-offload-bundler", "--unbundle", "--type=o", "--input=" + fat,

@@ -22,7 +22,7 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 def kernels(obj):
     with tempfile.TemporaryDirectory() as d:
         fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "k.co")
-        subprocess.run([LLVM + "/llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, obj], check=True)
+        subprocess.run([LLVM + "/llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, obj, os.path.join(d, "copy.o")], check=True)
         subprocess.run([LLVM + "/clang-offload-bundler", "--unbundle", "--type=o", "--input=" + fat,
                         "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co], check=True)
         txt = subprocess.run([LLVM + "/llvm-objdump", "-d", "--symbolize-operands", co], capture_output=True, text=True).stdout

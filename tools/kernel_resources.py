@@ -22,7 +22,7 @@ def demangle(names):
 def notes(obj):
     with tempfile.TemporaryDirectory() as d:
         fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "k.co")
-        subprocess.run([LLVM + "/llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, obj], check=True)
+        subprocess.run([LLVM + "/llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, obj, os.path.join(d, "copy.o")], check=True)  # never in place
         subprocess.run([LLVM + "/clang-offload-bundler", "--unbundle", "--type=o", "--input=" + fat,
                         "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co], check=True)
         return subprocess.run([LLVM + "/llvm-readelf", "--notes", co], capture_output=True, text=True).stdout
