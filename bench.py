@@ -258,10 +258,19 @@ def cpu_baseline_and_parity(empc, solver, problem, d, x0s, B, maxiter, unit):
                     "same_minimum_rollouts": sm.get("converged_on_oracle"), "passed": True}
     except AssertionError as e:  # the bench line reports it; tests/test_gpu_teacher_forced.py is where it fails a run
         stepwise = {"passed": False, "error": str(e)[:400]}
+    # the contract of the north star on the unperturbed rollout, in the form smoke() asserts (tests/parity_criteria.py): same
+    # minimiser from a common restart <= 1e-4, plain-solve cost within 1e-5 relative, identical iterations; plain xs / us reported
+    # with a 2e-4 tripwire next to the oracle-vs-its-own-FMA-build yardstick
+    try:
+        contract = pc.north_star_contract(empc, ob, sw, problem, gpu["xs"][0], gpu["us"][0], float(gpu["cost"][0]), int(gpu["iter"][0]),
+                                          x0=x0s[0], maxiter=maxiter)
+    except Exception as e:  # the line reports it; smoke() and tests/test_gpu_eagle_catch.py are where it fails a run
+        contract = {"passed": False, "failures": ["%s: %s" % (type(e).__name__, str(e)[:300])]}
     out["parity"] = {"reference": "oracle/liboracle.so (CPU restatement; parity unpinned, DESIGN.md)", "tolerance": 1e-4,
                      "rollouts_compared": n_sample,
                      "unperturbed_rollout_max_abs_err": float(per_roll[0]),
                      "unperturbed_rollout_iterations_equal": bool(gpu["iter"][0] == ref["iter"][0]),
+                     "contract": contract,
                      "free_running_batch_statistics_reported_not_judged": stats, "sample_checks": smp,
                      "same_problem": bool(smp["oracle_cost_at_gpu_point_rel_err_max"] is not None and
                                           smp["oracle_cost_at_gpu_point_rel_err_max"] <= 1e-9 and

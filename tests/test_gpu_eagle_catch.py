@@ -42,9 +42,12 @@ def test_eagle_catch_perturbed_batch_256(empc, problems):
     # under the oracle's dynamics, wherever the GPU reports convergence
     assert smp["converged_on_gpu_in_sample"] > 0
     assert smp["oracle_cost_at_gpu_point_rel_err_max"] <= 1e-9 and smp["oracle_dynamics_defect_at_gpu_point_max"] <= 1e-8, smp
-    # rollout 0 is the YAML initial state itself: the committed golden vector, plain north-star bound
-    assert gpu["iter"][0] == ref["iter"][0]
-    assert np.abs(gpu["xs"][0] - ref["xs"][0]).max() < 1e-4 and np.abs(gpu["us"][0] - ref["us"][0]).max() < 1e-4
+    # rollout 0 is the YAML initial state itself: the north-star contract (tests/parity_criteria.py: same minimiser from a common
+    # restart <= 1e-4, plain-solve cost within 1e-5 relative, identical iterations; plain xs / us under the 2e-4 tripwire)
+    import stepwise as sw
+    c = pc.north_star_contract(empc, ob, sw, problem, gpu["xs"][0], gpu["us"][0], float(gpu["cost"][0]), int(gpu["iter"][0]))
+    print("north-star contract on the unperturbed rollout:", c)
+    assert c["passed"], c["failures"]
     # nothing blows up on the rollouts neither side solves
     assert np.isfinite(gpu["xs"]).all() and np.isfinite(gpu["us"]).all()
     # Tripwires on the free-running batch.  The step-wise suite carries the parity claim; these catch a DRIFT of the free-running
