@@ -65,6 +65,11 @@ struct Bwd4Smem {
   static constexpr int KS = 16 * MTN + 1;       // row stride of -K
   // Q rows: the A-operand fetch of the Vxx stage touches 16 MTN rows, the accumulator store rows < nm rounded up to 4
   static constexpr int QROWS = (16 * MTN > (nm + 3) / 4 * 4) ? 16 * MTN : (nm + 3) / 4 * 4;
+  // EMPC_BWD_SYMTILES: a 16 x 16 tile (mt, nt) of Q / of Vxx whose every entry is the mirror image of an entry of a computed
+  // tile and is read by nobody: below the diagonal tiles and entirely left of column n (lower-left of Qxx, or Qux)
+  static constexpr bool tile_skipped(int mt, int nt) { return EMPC_BWD_SYMTILES && nt < mt && 16 * nt + 15 < n; }
+  // entry (i, j) of the n x n value-function Hessian lies in a skipped tile
+  static constexpr bool entry_skipped(int i, int j) { return tile_skipped(i / 16, j / 16); }
   static constexpr int OFF_REC = 0;                                   // the record, flat, in whole 64-double rows
   // Aliases inside the record area (LDS per wavefront decides how many trajectories a CU holds: 4 only below 40 KB, and the
   // 11-dof class was at 53 KB = 3 per CU = two rounds of workgroups for 1024 trajectories):
@@ -77,7 +82,9 @@ struct Bwd4Smem {
   static constexpr int OFF_HINV = OFF_W + WROWS * WS;                 // m x m
   static constexpr int OFF_PRO = OFF_REC;                             // prologue reductions: 3 x 64
   static_assert(OFF_HINV + m * m <= DM::OFF_LX, "W and Hinv must fit in front of the part of the record that stays live");
-#if EMPC_BWD_R4B
+#if EMPC_BWD_GLDS
+  static constexpr int OFF_V = (DM::REC + 127) / 128 * 128 + 2;       // behind record buffer 0 and its zero word
+#elif EMPC_BWD_R4B
   static constexpr int OFF_V = (DM::REC + 127) / 128 * 128;           // [16 MTN][VS], zero outside n x n
 #else
   static constexpr int OFF_V = (DM::REC + 63) / 64 * 64;              // [16 MTN][VS], zero outside n x n
@@ -90,7 +97,13 @@ struct Bwd4Smem {
   static constexpr int OFF_RED = OFF_KF + 2 * m;                      // 3 x 32 partial sums
   static constexpr int OFF_FLAG = OFF_RED + 96;
   static constexpr int OFF_ZERO = OFF_FLAG + 2;                       // a word that holds 0.0 (H entries outside the matrix)
-  static constexpr int SIZE = (OFF_ZERO + 2 + 1) / 2 * 2;
+  static constexpr int SIZE0 = (OFF_ZERO + 2 + 1) / 2 * 2;
+  // EMPC_BWD_GLDS: two record buffers of RB doubles (whole 1-KiB pieces of the LDS-DMA) + a zero word each at [RB]; buffer 0 is the
+  // record area above (OFF_V lies behind its zero word), buffer 1 follows everything else
+  static constexpr int RB = (DM::REC + 127) / 128 * 128;
+  static constexpr bool GLDS = EMPC_BWD_GLDS && 4 * sizeof(double) * (SIZE0 + RB + 2) <= 160 * 1024;
+  static constexpr int OFF_REC2 = SIZE0;
+  static constexpr int SIZE = GLDS ? SIZE0 + RB + 2 : SIZE0;
   static_assert(4 * sizeof(double) * SIZE <= 160 * 1024, "four trajectories (one per SIMD) must fit the LDS of a CU: a class beyond that runs in two rounds");
 };
 
@@ -172,7 +185,7 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = 16 * mt + 4 * r + lq, j = 16 * nt + lj;
-          int idx = SM::OFF_ZERO;
+          int idx = SM::GLDS ? SM::RB : SM::OFF_ZERO;  // (GLDS: offsets relative to the current record buffer, zero word behind it)
           if (i < n && j < nm)
             idx = DM::OFF_HX + i * nm + j;
           else if (i < n && j == nm)
@@ -185,6 +198,8 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
         }
     // zero padding, written once: everything but the record area
     for (int i = lane; i < SM::SIZE - SM::OFF_V; i += NL) smem[SM::OFF_V + i] = 0.0;
+    if constexpr (SM::GLDS)
+      if (lane == 0) smem[SM::RB] = 0.0;  // zero word of record buffer 0 (the one of buffer 1 lies in the range above)
   });
   ex.sync();
 #if EMPC_BWD_R4B
@@ -204,7 +219,7 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
       }
       const int j = i + idx;
       sy_w[sl][q][0] = on ? i * WS + j : -1;
-      sy_w[sl][q][1] = j * WS + i;
+      sy_w[sl][q][1] = SM::entry_skipped(j, i) ? i * WS + j : j * WS + i;  // (i <= j: (i, j) itself is never in a skipped tile)
       sy_v[sl][q][0] = i * VS + j;
       sy_v[sl][q][1] = (i == j) ? -1 : j * VS + i;  // -1 marks a diagonal entry: regularised, written once
     }
@@ -255,6 +270,10 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
       ex.sync();
     }
     // first record of the sweep
+    if constexpr (SM::GLDS) {
+      ex.async_wait();  // (a pass that failed left the copy of a record it never used in flight)
+      ex.template async_rows<SM::RB / 128>(smem + SM::OFF_REC, tape + (size_t)(T - 1) * REC);  // into buffer 0
+    }
 #if EMPC_BWD_R4B
     Bwd4Pair pre[Exec::SLOTS][PRE];
     ex.each([&](int lane, int sl) {
@@ -291,8 +310,31 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
         for (int i = 0; i < m; ++i) D.kff[((size_t)b * T + tk) * m + i] = Kc[sl][i];
       }
     };
+    // EMPC_BWD_GLDS: the knot body exists twice, once per record buffer (a lambda over the buffer index, called alternately), so
+    // that every LDS address of a knot is base + immediate as in the default build; `BWD_KNOT_EXIT` leaves the knot loop
+#if EMPC_BWD_GLDS
+#define BWD_KNOT_EXIT return false
+    auto knot = [&](const int t, auto RBUF) -> bool {
+      constexpr int rbuf = decltype(RBUF)::value;  // the buffer that holds this knot's record; the next record goes to the other
+      double* const rec = smem + ((SM::GLDS && rbuf) ? SM::OFF_REC2 : SM::OFF_REC);  // (a class without the second buffer stages through registers)
+      double* const W = rec + SM::OFF_W;
+      double* const Hinv = rec + SM::OFF_HINV;
+#else
+#define BWD_KNOT_EXIT break
     for (int t = T - 1; t >= 0; --t) {
+#endif
       BWD_STAMP(7);
+      if constexpr (SM::GLDS) {
+        // the record of this knot was requested a whole knot ago, straight into buffer `rbuf`; the other buffer (the previous
+        // knot's record, W, Hinv: all dead) takes the next one.  Stores first: they share the counter the wait reads.
+        ex.async_wait();
+        ex.each([&](int lane, int sl) {
+          if (t < T - 1) flush_outputs(t + 1, lane, sl);
+        });
+#if EMPC_BWD_GLDS
+        if (t > 0) ex.template async_rows<SM::RB / 128>(smem + (rbuf ? SM::OFF_REC : SM::OFF_REC2), tape + (size_t)(t - 1) * REC);
+#endif
+      } else
       ex.each([&](int lane, int sl) {
 #if EMPC_BWD_R4B
 #pragma unroll
@@ -324,7 +366,8 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
 #pragma unroll
           for (int nt = 0; nt < NTQ; ++nt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) accQ[sl][mt][nt][r] = smem[hidx[sl][mt][nt][r]];
+            for (int r = 0; r < 4; ++r)
+              if (!SM::tile_skipped(mt, nt)) accQ[sl][mt][nt][r] = (SM::GLDS ? rec : smem)[hidx[sl][mt][nt][r]];
       });
       // W = V' A, A = [Fx Fu] (flat in the record, row stride nm).  k rows >= n meet the zero columns of V; columns >= nm are
       // finite garbage that ends in columns nobody uses (column nm is replaced by Vx' below).
@@ -384,7 +427,8 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
 #pragma unroll
           for (int mt = 0; mt < MTQ; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < NTQ; ++nt) ex.mfma(aopQ[ks & 1], mt, bopQ[ks & 1], nt, accQ, mt, nt);
+            for (int nt = 0; nt < NTQ; ++nt)
+              if (!SM::tile_skipped(mt, nt)) ex.mfma(aopQ[ks & 1], mt, bopQ[ks & 1], nt, accQ, mt, nt);
         }
       }
       // whole tiles into the padded Q array (column nm = Qx | Qu)
@@ -415,8 +459,19 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
           // H of the QP and the inverse of its free block live in LDS (W is dead between the symmetrise stage of the previous
           // knot and the Vxx stage of this one): 2 m^2 doubles in the registers of one lane put the whole kernel into scratch
           double* Hq = W;
+#if EMPC_BOX_LDS
+          // the QP's vectors behind Hinv, still in front of the live tail of the record (Lx, Lu, gap)
+          static_assert(SM::OFF_HINV + m * m + 9 * m <= DM::OFF_LX, "box-QP working set inside the dead part of the record area");
+          double* const qq = Hinv + m * m;
+          double* const lbq = qq + m;
+          double* const ubq = qq + 2 * m;
+          double* const xq = qq + 3 * m;
+          int* const fm = reinterpret_cast<int*>(qq + 4 * m);
+          double* const ws = qq + 5 * m;  // g, xnew, dx, held free set
+#else
           double qq[m], lbq[m], ubq[m], xq[m];
           int fm[m];
+#endif
           const double* usg = D.us + ((size_t)b * T + t) * m;
           const double* kprev = D.kff + ((size_t)b * T + t) * m;  // k_[t] of the previous iteration: the QP's warm start
 #pragma unroll
@@ -429,7 +484,11 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
             xq[i] = kprev[i];
           }
           const bool okq = box_qp_lane<m>(Hq, qq, lbq, ubq, xq, fm, Hinv, P.prm.boxqp_maxiter, P.prm.boxqp_th_acceptstep,
-                                          P.prm.boxqp_th_grad, P.prm.boxqp_reg);
+                                          P.prm.boxqp_th_grad, P.prm.boxqp_reg
+#if EMPC_BOX_LDS
+                                          , ws
+#endif
+          );
           flag[0] = okq ? 0.0 : 1.0;
 #pragma unroll
           for (int i = 0; i < m; ++i) {
@@ -509,7 +568,7 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
       BWD_STAMP(10);
       if (flag[0] != 0.0) {
         fail = true;
-        break;
+        BWD_KNOT_EXIT;
       }
       BWD_STAMP(3);
       // Vx = Qx + K^T Quuk - 2 K^T Qu from the lane's own column; Vxx = Qxx + (Qxu)(-K) on the matrix cores: the Qxx tiles
@@ -551,7 +610,8 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
 #pragma unroll
           for (int mt = 0; mt < MTN; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < MTN; ++nt) ex.mfma(aopV[ks & 1], mt, bopV[ks & 1], nt, accQ, mt, nt);
+            for (int nt = 0; nt < MTN; ++nt)
+              if (!SM::tile_skipped(mt, nt)) ex.mfma(aopV[ks & 1], mt, bopV[ks & 1], nt, accQ, mt, nt);
         }
       }
       ex.each([&](int lane, int sl) {
@@ -562,7 +622,7 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
           for (int nt = 0; nt < MTN; ++nt)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-              if (16 * mt + 4 * r < n && 16 * nt < n) W[(16 * mt + 4 * r + lq) * WS + 16 * nt + lj] = accQ[sl][mt][nt][r];
+              if (16 * mt + 4 * r < n && 16 * nt < n && !SM::tile_skipped(mt, nt)) W[(16 * mt + 4 * r + lq) * WS + 16 * nt + lj] = accQ[sl][mt][nt][r];
       });
       BWD_STAMP(12);
       ex.sync();
@@ -598,8 +658,9 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
         for (int q = 0; q < NS; ++q) {
           const int i = lane + q * NL, ic = i < n * n ? i : 0;
           const int rr = ic / n, cc = ic % n;
-          wa[q] = W[rr * WS + cc];
-          wb[q] = W[cc * WS + rr];
+          // (EMPC_BWD_SYMTILES: an entry of a tile that was not computed is replaced by its mirror image, on both sides)
+          wa[q] = W[SM::entry_skipped(rr, cc) ? cc * WS + rr : rr * WS + cc];
+          wb[q] = W[SM::entry_skipped(cc, rr) ? rr * WS + cc : cc * WS + rr];
         }
         BWD_FENCE();
 #pragma unroll
@@ -660,11 +721,21 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
       BWD_STAMP(14);
       if (badAny) {
         fail = true;
-        break;
+        BWD_KNOT_EXIT;
       }
       BWD_STAMP(6);
       if (t == 0) ex.each([&](int lane, int sl) { flush_outputs(0, lane, sl); });
+#if EMPC_BWD_GLDS
+      return true;
+    };
+    for (int t = T - 1; t >= 0; t -= 2) {
+      if (!knot(t, std::integral_constant<int, 0>{})) break;
+      if (t >= 1 && !knot(t - 1, std::integral_constant<int, 1>{})) break;
     }
+#else
+    }
+#endif
+#undef BWD_KNOT_EXIT
 #if defined(EMPC_STAMPS) && defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
     if (b == 0)
       ex.each([&](int lane, int sl) {
@@ -703,6 +774,7 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
       break;
     }
   }
+  if constexpr (SM::GLDS) ex.async_wait();  // (a failed pass leaves a copy in flight: nothing may land after the wavefront is gone)
   ex.each([&](int lane, int sl) {
     if (lane == 0) {
       st.cost = cost;

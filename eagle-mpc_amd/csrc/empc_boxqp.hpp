@@ -10,18 +10,41 @@
 
 namespace empc {
 
+// EMPC_BOX_LDS: g, xnew, dx and the held free set in caller-provided memory `ws` (3 M doubles + M ints; LDS in the backward pass)
+// ... and the QP is a real function (s_swappc) instead of ~8k instructions inlined into the knot loop: its register demand no
+// longer adds to everything that is live across it (Qxx accumulators, prefetched record, offset tables), which is what put the
+// box instantiation at 469 spilled registers / 1.5 KB of scratch per lane; the trajectories that take the plain gains (gaps
+// still open) run the plain pass's code.  Measured statically (9-DoF): 0 spilled VGPRs, 20 B scratch (the call frame).
+#if EMPC_BOX_LDS && defined(__HIPCC__)
+#define EMPC_BOXQP_NOINLINE __attribute__((noinline))
+#else
+#define EMPC_BOXQP_NOINLINE
+#endif
+#if EMPC_BOX_LDS
+#define EMPC_BOXQP_WORK(ws)   \
+  double* const g = (ws);     \
+  double* const xnew = (ws) + M; \
+  double* const dx = (ws) + 2 * M; \
+  int* const prev_mask = reinterpret_cast<int*>((ws) + 3 * M);
+#define EMPC_BOXQP_WS_PARAM , double* ws
+#else
+#define EMPC_BOXQP_WORK(ws) \
+  double g[M], xnew[M], dx[M]; \
+  int prev_mask[M];
+#define EMPC_BOXQP_WS_PARAM
+#endif
+
 // H: full M x M (row-major), symmetric positive definite on the free block.  x: in = warm start, out = solution.
 // free_mask[i] = 1 for free components; Hinv: inverse of the free block, zero rows / columns for clamped components.
 // Returns false when a factorisation fails (crocoddyl throws "backward_error").
 #if EMPC_BOXQP_ONE_EXIT
 // (commit b94f9cd: one exit, unrolled loops -- fewer spilled registers in the box backward pass; never run on hardware)
 template <int M>
-EMPC_HD bool box_qp_lane(const double* H, const double* q, const double* lb, const double* ub, double* x, int* free_mask, double* Hinv,
-                         int maxiter, double th_acceptstep, double th_grad, double reg) {
+EMPC_BOXQP_NOINLINE EMPC_HD bool box_qp_lane(const double* H, const double* q, const double* lb, const double* ub, double* x, int* free_mask, double* Hinv,
+                         int maxiter, double th_acceptstep, double th_grad, double reg EMPC_BOXQP_WS_PARAM) {
   // crocoddyl::BoxQP builds its own ten step lengths 2^-n whatever the outer solver's line search uses
   constexpr int n_alphas = 10;
-  double g[M], xnew[M], dx[M];
-  int prev_mask[M];
+  EMPC_BOXQP_WORK(ws)
   bool have_inv = false, ok = true;
 #pragma unroll
   for (int i = 0; i < M; ++i) {
@@ -141,12 +164,11 @@ EMPC_HD bool box_qp_lane(const double* H, const double* q, const double* lb, con
 
 #else
 template <int M>
-EMPC_HD bool box_qp_lane(const double* H, const double* q, const double* lb, const double* ub, double* x, int* free_mask, double* Hinv,
-                         int maxiter, double th_acceptstep, double th_grad, double reg) {
+EMPC_BOXQP_NOINLINE EMPC_HD bool box_qp_lane(const double* H, const double* q, const double* lb, const double* ub, double* x, int* free_mask, double* Hinv,
+                         int maxiter, double th_acceptstep, double th_grad, double reg EMPC_BOXQP_WS_PARAM) {
   // crocoddyl::BoxQP builds its own ten step lengths 2^-n whatever the outer solver's line search uses
   constexpr int n_alphas = 10;
-  double g[M], xnew[M], dx[M];
-  int prev_mask[M];
+  EMPC_BOXQP_WORK(ws)
   bool have_inv = false, ok = true;
 #pragma unroll
   for (int i = 0; i < M; ++i) {

@@ -215,6 +215,36 @@ __global__ void __launch_bounds__(BLK) EMPC_LIN_ATTR k_linearize_all(DevBuffers 
 }
 
 // workgroup-wide executor: barriers are real workgroup barriers
+// EMPC_BWD_GLDS: ROWS pieces of 1 KiB (128 doubles) from global memory straight into LDS (LDS-DMA, no register destination): lane l
+// of piece q moves the 16 bytes at src_lane + 128 q (src_lane = src + 2 l) to dst + 128 q + 2 l -- the hardware adds lane x 16 to
+// the wave-uniform LDS base in M0.  Inline assembly on purpose: hipcc tracks the builtin form (__builtin_amdgcn_global_load_lds) as
+// an LDS write and waits vmcnt(0) at the next ds_read of ANY LDS address (checked in the ISA) -- the exposed HBM latency this
+// variant exists to hide; an asm load is absent from its bookkeeping and the kernel retires it with s_waitcnt vmcnt(0) one knot
+// later.  One statement per record: M0 (compiler-reserved) is saved, advanced by 1 KiB per piece and restored inside it, the
+// s_nop separates each M0 write from the instruction that reads it; the source address advances in the same registers.
+// operands: %0 saved M0, %1 the lane's source address (advanced in place), %2 scratch SGPR pair holding 0x400, %3 LDS byte address
+#define EMPC_GLDS_HEAD "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_mov_b64 %2, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+#define EMPC_GLDS_NEXT "v_lshl_add_u64 %1, %1, 0, %2\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+#define EMPC_GLDS_TAIL "s_mov_b32 m0, %0"
+#define EMPC_GLDS_ASM(body)                                                                                       \
+  asm volatile(EMPC_GLDS_HEAD body EMPC_GLDS_TAIL : "=&s"(keep), "+v"(g), "=&s"(inc) : "s"(l) : "memory", "scc")
+template <int ROWS>
+__device__ __forceinline__ void glds_rows(double* dst, const double* src_lane) {
+  static_assert(ROWS == 4 || ROWS == 7 || ROWS == 9, "record sizes of the robot classes this variant is built for");
+  const double* g = src_lane;
+  const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)dst);
+  unsigned keep;
+  unsigned long long inc;
+#define N3 EMPC_GLDS_NEXT EMPC_GLDS_NEXT EMPC_GLDS_NEXT
+  if constexpr (ROWS == 4)
+    asm volatile(EMPC_GLDS_HEAD N3 EMPC_GLDS_TAIL : "=&s"(keep), "+v"(g), "=&s"(inc) : "s"(l) : "memory", "scc");
+  else if constexpr (ROWS == 7)
+    asm volatile(EMPC_GLDS_HEAD N3 N3 EMPC_GLDS_TAIL : "=&s"(keep), "+v"(g), "=&s"(inc) : "s"(l) : "memory", "scc");
+  else
+    asm volatile(EMPC_GLDS_HEAD N3 N3 EMPC_GLDS_NEXT EMPC_GLDS_NEXT EMPC_GLDS_TAIL : "=&s"(keep), "+v"(g), "=&s"(inc) : "s"(l) : "memory", "scc");
+#undef N3
+}
+
 struct BlockExec {
   int lane;
   static constexpr int SLOTS = 1;
@@ -242,6 +272,18 @@ struct BlockExec {
 #else
     return __syncthreads_or(f(lane, 0) ? 1 : 0) != 0;
 #endif
+  }
+  // EMPC_BWD_GLDS: ROWS pieces of 1 KiB from global memory straight into LDS (glds_rows above); async_wait() retires them
+  template <int ROWS>
+  __device__ __forceinline__ void async_rows(double* dst, const double* src) {
+    __builtin_amdgcn_sched_barrier(0);
+    glds_rows<ROWS>(dst, src + 2 * lane);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __device__ __forceinline__ void async_wait() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched
+    __builtin_amdgcn_sched_barrier(0);
   }
   // one v_mfma_f64_16x16x4_f64 of the wavefront: acc[im][in] += A-operand a[ia] x B-operand b[ib] (per-lane values)
   template <class A, class B, class C>
@@ -284,6 +326,18 @@ struct WaveExec {
   template <class F>
   __device__ __forceinline__ bool any(F&& f) {
     return __builtin_amdgcn_ballot_w64(f(lane, 0)) != 0;
+  }
+  // EMPC_BWD_GLDS: ROWS pieces of 1 KiB from global memory straight into LDS (glds_rows above); async_wait() retires them
+  template <int ROWS>
+  __device__ __forceinline__ void async_rows(double* dst, const double* src) {
+    __builtin_amdgcn_sched_barrier(0);
+    glds_rows<ROWS>(dst, src + 2 * lane);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __device__ __forceinline__ void async_wait() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched
+    __builtin_amdgcn_sched_barrier(0);
   }
   template <class A, class B, class C>
   __device__ __forceinline__ void mfma(A& a, int ia, B& b, int ib, C& c, int im, int in) {

@@ -29,3 +29,24 @@
 #ifndef EMPC_FSQRT_BITS
 #define EMPC_FSQRT_BITS 0
 #endif
+
+// ---- round 6: performance variants (VERDICT r05 "next round" items 4-5), all verified on the lane emulator only ---------------
+// backward: tiles of Q and of Vxx that lie wholly below the diagonal blocks and left of column n (lower-left of Qxx, Qux) are
+// not computed: Q is symmetric and nothing reads Qux; the symmetrise stage takes the upper entry alone where the lower one was
+// skipped (0.5 (a + a) == a).  9-DoF: 52 -> 44 MFMAs per knot; 11-DoF: 96 -> 81.  Moves the rounding of Vxx[16.., ..15].
+#ifndef EMPC_BWD_SYMTILES
+#define EMPC_BWD_SYMTILES 0
+#endif
+// backward: the next knot's record goes from HBM straight into a second LDS record buffer by LDS-DMA (global_load_lds_dwordx4,
+// 1 KiB per wave-instruction) instead of through 18 prefetch registers per lane + 18 ds_write per knot: -36 VGPRs, no staging
+// instructions.  Arithmetic untouched (bit-identical on the emulator, whose executor delivers the copy only at the wait).  Only
+// for robot classes whose four trajectories per CU still fit the LDS with the second buffer (9-DoF: 27 -> 37 KB; not 11-DoF).
+#ifndef EMPC_BWD_GLDS
+#define EMPC_BWD_GLDS 0
+#endif
+// box solvers (SolverBoxFDDP / SolverBoxDDP): the working set of the one-lane box QP -- q, the bounds, the iterate, the gradient,
+// the trial point, the step and the free sets, 8 m-vectors -- lives in LDS (behind W / Hinv in the dead part of the record area)
+// instead of in 7 x m x 2 registers of every lane of the kernel; the Cholesky factor stays in registers.  Arithmetic untouched.
+#ifndef EMPC_BOX_LDS
+#define EMPC_BOX_LDS 0
+#endif

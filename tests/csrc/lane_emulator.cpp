@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <thread>
 #include <cstring>
+#include <limits>
 #include <vector>
 
 #include "../../eagle-mpc_amd/csrc/empc_prep.hpp"
@@ -33,6 +34,23 @@ struct CpuExec {
     bool r = false;
     for (int l = 0; l < nl; ++l) r = f(l, l) || r;
     return r;
+  }
+  // EMPC_BWD_GLDS: LDS-DMA modelled as what the kernel may rely on and nothing more -- at issue the destination is POISONED (a
+  // reader of the old contents, or of the new ones before the wait, meets NaN), the bytes arrive at async_wait()
+  struct Pending {
+    double* dst;
+    const double* src;
+    int n;
+  };
+  std::vector<Pending> pending;
+  template <int ROWS>
+  void async_rows(double* dst, const double* src) {
+    for (int i = 0; i < 128 * ROWS; ++i) dst[i] = std::numeric_limits<double>::quiet_NaN();
+    pending.push_back({dst, src, 128 * ROWS});
+  }
+  void async_wait() {
+    for (const Pending& p : pending) std::memcpy(p.dst, p.src, sizeof(double) * p.n);
+    pending.clear();
   }
   // v_mfma_f64_16x16x4_f64 semantics on per-lane operands: A[i = l % 16][k = l / 16], B[k = l / 16][j = l % 16],
   // D[i = 4 r + l / 16][j = l % 16] (layout verified on gfx950 by tools/probes/mfma_f64_layout.hip)

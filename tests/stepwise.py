@@ -24,7 +24,10 @@ import numpy as np
 import oracle_binding as ob
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-EMU = os.path.join(ROOT, "tests", "csrc", "liblane_emulator.so")
+# EMU_MACROS="EMPC_BWD_SYMTILES=1 ...": the emulator of a build-time VARIANT of the kernel bodies (empc_variants.hpp), in a library
+# of its own -- any emulator test or tool runs on a variant this way (tools/variant_verdicts.py)
+EMU_MACROS = os.environ.get("EMU_MACROS", "").split()
+EMU = os.path.join(ROOT, "tests", "csrc", "liblane_emulator%s.so" % ("".join("_" + m.replace("=", "").replace("EMPC_", "").lower() for m in EMU_MACROS)))
 T = ob.T
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -50,7 +53,7 @@ def load_emulator():
     csrc = os.path.join(ROOT, "eagle-mpc_amd", "csrc")
     hdrs = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".hpp")] + [os.path.join(ROOT, "include", "empc_types.h")]
     if not os.path.exists(EMU) or any(os.path.getmtime(h) > os.path.getmtime(EMU) for h in hdrs + [src]):
-        subprocess.check_call(["g++", "-O2", "-std=c++20", "-pthread", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"), src,
+        subprocess.check_call(["g++", "-O2", "-std=c++20", "-pthread", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include")] + ["-D" + m for m in EMU_MACROS] + [src,
                                "-o", EMU])
     L = C.CDLL(EMU)
     L.emu_create.restype = C.c_void_p

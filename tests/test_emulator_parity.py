@@ -11,7 +11,10 @@ import pytest
 import oracle_binding as ob
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-EMU = os.path.join(ROOT, "tests", "csrc", "liblane_emulator.so")
+# EMU_MACROS="EMPC_BWD_SYMTILES=1 ...": the emulator of a build-time VARIANT of the kernel bodies (empc_variants.hpp), in a library
+# of its own -- any emulator test or tool runs on a variant this way (tools/variant_verdicts.py)
+EMU_MACROS = os.environ.get("EMU_MACROS", "").split()
+EMU = os.path.join(ROOT, "tests", "csrc", "liblane_emulator%s.so" % ("".join("_" + m.replace("=", "").replace("EMPC_", "").lower() for m in EMU_MACROS)))
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
 
@@ -22,7 +25,7 @@ def emu(empc):
     hdrs = [os.path.join(ROOT, "eagle-mpc_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "eagle-mpc_amd", "csrc"))
             if f.endswith(".hpp")] + [os.path.join(ROOT, "include", "empc_types.h")]
     if not os.path.exists(EMU) or any(os.path.getmtime(h) > os.path.getmtime(EMU) for h in hdrs + [src]):
-        subprocess.check_call(["g++", "-O2", "-std=c++20", "-pthread", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"), src,
+        subprocess.check_call(["g++", "-O2", "-std=c++20", "-pthread", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include")] + ["-D" + m for m in EMU_MACROS] + [src,
                                "-o", EMU])
     L = C.CDLL(EMU)
     L.emu_create.restype = C.c_void_p
@@ -121,11 +124,11 @@ def emu_baked(empc):
     shipped library runs for every shipped robot"""
     global EMU
     src = os.path.join(ROOT, "tests", "csrc", "lane_emulator.cpp")
-    lib = os.path.join(ROOT, "tests", "csrc", "liblane_emulator_baked.so")
+    lib = EMU.replace(".so", "_baked.so")
     hdrs = [os.path.join(ROOT, "eagle-mpc_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "eagle-mpc_amd", "csrc")) if f.endswith(".hpp")]
     hdrs += [os.path.join(ROOT, "eagle-mpc_amd", "csrc", "baked", "empc_baked_models.hpp"), os.path.join(ROOT, "include", "empc_types.h"), src]
     if not os.path.exists(lib) or any(os.path.getmtime(h) > os.path.getmtime(lib) for h in hdrs):
-        subprocess.check_call(["g++", "-O2", "-std=c++20", "-pthread", "-fPIC", "-shared", "-DEMU_BAKED", "-I" + os.path.join(ROOT, "include"), src, "-o", lib])
+        subprocess.check_call(["g++", "-O2", "-std=c++20", "-pthread", "-fPIC", "-shared", "-DEMU_BAKED", "-I" + os.path.join(ROOT, "include")] + ["-D" + m for m in EMU_MACROS] + [src, "-o", lib])
     keep, EMU = EMU, lib
     try:
         return emu.__wrapped__(empc)

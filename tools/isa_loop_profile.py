@@ -97,6 +97,12 @@ def main():
             for op, _ in instr[a:b + 1]:
                 mix[classify(op)] = mix.get(classify(op), 0) + 1
             print("  loop +%d..+%d: %d instructions  %s" % (a, b, b - a + 1, " ".join("%s %d" % kv for kv in sorted(mix.items()))))
+            if os.environ.get("MNEMONICS") and (a, b) == sorted(loops, key=lambda ab: ab[0] - ab[1])[0]:
+                # MNEMONICS=1: the largest loop broken down by mnemonic (what the "other vector" and scalar instructions are)
+                mn = {}
+                for op, _ in instr[a:b + 1]:
+                    mn[op] = mn.get(op, 0) + 1
+                print("    " + "  ".join("%s %d" % kv for kv in sorted(mn.items(), key=lambda kv: -kv[1]) if kv[1] >= 3))
 
 
 if __name__ == "__main__":
