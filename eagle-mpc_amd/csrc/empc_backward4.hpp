@@ -44,6 +44,17 @@ namespace empc {
   } while (0)
 #endif
 
+// A value pinned in program order: an empty volatile asm statement that reads and "writes" it.  `each`'s scheduling fences only bind
+// the machine scheduler; the selection DAG orders pure arithmetic by register pressure and moves it across them (seen in the ISA:
+// the reciprocal square roots of the Cholesky columns sank below the matrix-core instructions they were meant to run under).
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+#define BWD_PIN(x) asm volatile("" : "+v"(x))
+#else
+#define BWD_PIN(x) \
+  do {             \
+  } while (0)
+#endif
+
 // two doubles that travel together (one 16-byte global load, one 16-byte LDS write): records are 128-byte aligned
 // (a native vector type on the device: an array of 16-byte structs indexed by an unrolled loop stays in scratch memory)
 #if defined(__HIPCC__)
@@ -70,6 +81,10 @@ struct Bwd4Smem {
   static constexpr bool tile_skipped(int mt, int nt) { return EMPC_BWD_SYMTILES && nt < mt && 16 * nt + 15 < n; }
   // entry (i, j) of the n x n value-function Hessian lies in a skipped tile
   static constexpr bool entry_skipped(int i, int j) { return tile_skipped(i / 16, j / 16); }
+  // EMPC_BWD_MFMA4: row groups (four rows = one accumulator register of a tile) that hold data
+  static constexpr int RGN = (n + 3) / 4, RGQ = (nm + 3) / 4;
+  // ... and a row group of Q that nobody reads: rows of Qux / Quu (all >= n) in a column tile left of column n
+  static constexpr bool group_skipped(int rg, int nt) { return tile_skipped(rg / 4, nt) || (EMPC_BWD_MFMA4 && 4 * rg >= n && 16 * nt + 15 < n); }
   static constexpr int OFF_REC = 0;                                   // the record, flat, in whole 64-double rows
   // Aliases inside the record area (LDS per wavefront decides how many trajectories a CU holds: 4 only below 40 KB, and the
   // 11-dof class was at 53 KB = 3 per CU = two rounds of workgroups for 1024 trajectories):
@@ -367,7 +382,8 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
           for (int nt = 0; nt < NTQ; ++nt)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-              if (!SM::tile_skipped(mt, nt)) accQ[sl][mt][nt][r] = (SM::GLDS ? rec : smem)[hidx[sl][mt][nt][r]];
+              if (!SM::group_skipped(4 * mt + r, nt) && (!EMPC_BWD_MFMA4 || 4 * mt + r < SM::RGQ))
+                accQ[sl][mt][nt][r] = (SM::GLDS ? rec : smem)[hidx[sl][mt][nt][r]];
       });
       // W = V' A, A = [Fx Fu] (flat in the record, row stride nm).  k rows >= n meet the zero columns of V; columns >= nm are
       // finite garbage that ends in columns nobody uses (column nm is replaced by Vx' below).
@@ -380,8 +396,213 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
 #pragma unroll
             for (int r = 0; r < 4; ++r) accW[sl][mt][nt][r] = 0.0;
       });
+#if EMPC_BWD_OVERLAP && !EMPC_BWD_MFMA4
+      // EMPC_BWD_OVERLAP.  NTX column tiles lie wholly left of column n ("x tiles": Qxx | Qux); the others ("u tiles") hold Qxu | Quu |
+      // Qx, Qu.  Phase 1: W and Q restricted to the u tiles -> LDS.  Phase 2: the x tiles, one instruction after each of the 3 m
+      // pieces of computeGains (m Cholesky columns, m rows forward, m rows backward); what is left of either list runs at the end.
+      constexpr int NTX = n / 16;
+      if constexpr (!BOX && NTX > 0) {
+        auto loadW = [&](double (&aop)[2][Exec::SLOTS][MTN], double (&bop)[2][Exec::SLOTS][NTQ], int ks, int buf, int nt0, int nt1) {
+          ex.each([&](int lane, int sl) {
+            const int li = lane % 16, lq = lane / 16;
+#pragma unroll
+            for (int mt = 0; mt < MTN; ++mt) aop[buf][sl][mt] = V[(16 * mt + li) * VS + 4 * ks + lq];
+#pragma unroll
+            for (int nt = 0; nt < NTQ; ++nt)
+              if (nt >= nt0 && nt < nt1) bop[buf][sl][nt] = rec[DM::OFF_A + (4 * ks + lq) * nm + 16 * nt + li];
+          });
+        };
+        auto loadQ = [&](double (&aop)[2][Exec::SLOTS][MTQ], double (&bop)[2][Exec::SLOTS][NTQ], int ks, int buf, int nt0, int nt1) {
+          ex.each([&](int lane, int sl) {
+            const int li = lane % 16, lq = lane / 16;
+#pragma unroll
+            for (int mt = 0; mt < MTQ; ++mt) aop[buf][sl][mt] = rec[DM::OFF_A + (4 * ks + lq) * nm + 16 * mt + li];
+            const double vxk = vx[4 * ks + lq];
+#pragma unroll
+            for (int nt = 0; nt < NTQ; ++nt)
+              if (nt >= nt0 && nt < nt1) bop[buf][sl][nt] = (16 * nt + li == nm) ? vxk : accW[sl][ks / 4][nt][ks % 4];
+          });
+        };
+        // ---- phase 1: u tiles ----------------------------------------------------------------------------------------
+        {
+          double aopW[2][Exec::SLOTS][MTN], bopW[2][Exec::SLOTS][NTQ];
+          loadW(aopW, bopW, 0, 0, NTX, NTQ);
+#pragma unroll
+          for (int ks = 0; ks < KSN; ++ks) {
+            if (ks + 1 < KSN) loadW(aopW, bopW, ks + 1, (ks + 1) & 1, NTX, NTQ);
+#pragma unroll
+            for (int mt = 0; mt < MTN; ++mt)
+#pragma unroll
+              for (int nt = NTX; nt < NTQ; ++nt) ex.mfma(aopW[ks & 1], mt, bopW[ks & 1], nt, accW, mt, nt);
+          }
+        }
+        {
+          double aopQ[2][Exec::SLOTS][MTQ], bopQ[2][Exec::SLOTS][NTQ];
+          loadQ(aopQ, bopQ, 0, 0, NTX, NTQ);
+#pragma unroll
+          for (int ks = 0; ks < KSN; ++ks) {
+            if (ks + 1 < KSN) loadQ(aopQ, bopQ, ks + 1, (ks + 1) & 1, NTX, NTQ);
+#pragma unroll
+            for (int mt = 0; mt < MTQ; ++mt)
+#pragma unroll
+              for (int nt = NTX; nt < NTQ; ++nt)
+                if (!SM::tile_skipped(mt, nt)) ex.mfma(aopQ[ks & 1], mt, bopQ[ks & 1], nt, accQ, mt, nt);
+          }
+        }
+        ex.each([&](int lane, int sl) {
+          const int lj = lane % 16, lq = lane / 16;
+#pragma unroll
+          for (int mt = 0; mt < MTQ; ++mt)
+#pragma unroll
+            for (int nt = NTX; nt < NTQ; ++nt)
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (16 * mt + 4 * r < nm) Q[(16 * mt + 4 * r + lq) * QS + 16 * nt + lj] = accQ[sl][mt][nt][r];
+        });
+        ex.sync();
+        BWD_STAMP(2);
+        // ---- phase 2: the x tiles between the pieces of computeGains ------------------------------------------------------
+        double Lq[Exec::SLOTS][m * (m + 1) / 2], rhs[Exec::SLOTS][m];
+        bool pd[Exec::SLOTS];
+        ex.each([&](int lane, int sl) {
+#pragma unroll
+          for (int i = 0; i < m; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) Lq[sl][i * (i + 1) / 2 + j] = Q[(n + i) * QS + n + j];
+#pragma unroll
+          for (int i = 0; i < m; ++i) rhs[sl][i] = Q[((lane < n) ? lane : (n + i)) * QS + ((lane < n) ? (n + i) : nm)];
+          BWD_FENCE();
+#pragma unroll
+          for (int i = 0; i < m; ++i) Lq[sl][i * (i + 1) / 2 + i] += ureg;
+          pd[sl] = true;
+        });
+        // piece c of computeGains: chol_packed's column c | chol_solve_packed's forward row c - m | its backward row 3 m - 1 - c
+        // (empc_dev_model.hpp: the same operations in the same order on every entry)
+        auto piece = [&](int c) {
+          ex.each([&](int lane, int sl) {
+            double* L = Lq[sl];
+            double* b_ = rhs[sl];
+            if (c < m) {
+              const int j = c;
+              double s_ = L[j * (j + 1) / 2 + j];
+#pragma unroll
+              for (int k = 0; k < m; ++k)
+                if (k < j) s_ -= L[j * (j + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
+              if (!(s_ > 0.0) || is_nan(s_)) pd[sl] = false;
+              const double inv = frsqrt(s_);
+              L[j * (j + 1) / 2 + j] = inv;
+#pragma unroll
+              for (int i = 0; i < m; ++i)
+                if (i > j) {
+                  double t_ = L[i * (i + 1) / 2 + j];
+#pragma unroll
+                  for (int k = 0; k < m; ++k)
+                    if (k < j) t_ -= L[i * (i + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
+                  L[i * (i + 1) / 2 + j] = t_ * inv;
+                  BWD_PIN(L[i * (i + 1) / 2 + j]);
+                }
+              BWD_PIN(L[j * (j + 1) / 2 + j]);
+              if (c == m - 1 && lane == 0) flag[0] = pd[sl] ? 0.0 : 1.0;
+            } else if (c < 2 * m) {
+              const int i = c - m;
+              if (lane <= n) {
+                double s_ = b_[i];
+#pragma unroll
+                for (int k = 0; k < m; ++k)
+                  if (k < i) s_ -= L[i * (i + 1) / 2 + k] * b_[k];
+                b_[i] = s_ * L[i * (i + 1) / 2 + i];
+                BWD_PIN(b_[i]);
+              }
+            } else {
+              const int i = 3 * m - 1 - c;
+              if (lane <= n) {
+                double s_ = b_[i];
+#pragma unroll
+                for (int k = 0; k < m; ++k)
+                  if (k > i) s_ -= L[k * (k + 1) / 2 + i] * b_[k];
+                b_[i] = s_ * L[i * (i + 1) / 2 + i];
+                BWD_PIN(b_[i]);
+              }
+            }
+          });
+        };
+        int pc = 0;  // next piece (a compile-time constant at every use once the loops below are unrolled)
+        {
+          double aopW[2][Exec::SLOTS][MTN], bopW[2][Exec::SLOTS][NTQ];
+          loadW(aopW, bopW, 0, 0, 0, NTX);
+#pragma unroll
+          for (int ks = 0; ks < KSN; ++ks) {
+            if (ks + 1 < KSN) loadW(aopW, bopW, ks + 1, (ks + 1) & 1, 0, NTX);
+#pragma unroll
+            for (int mt = 0; mt < MTN; ++mt)
+#pragma unroll
+              for (int nt = 0; nt < NTX; ++nt) {
+                ex.mfma(aopW[ks & 1], mt, bopW[ks & 1], nt, accW, mt, nt);
+                if (pc < 3 * m) piece(pc++);
+              }
+          }
+        }
+        {
+          double aopQ[2][Exec::SLOTS][MTQ], bopQ[2][Exec::SLOTS][NTQ];
+          loadQ(aopQ, bopQ, 0, 0, 0, NTX);
+#pragma unroll
+          for (int ks = 0; ks < KSN; ++ks) {
+            if (ks + 1 < KSN) loadQ(aopQ, bopQ, ks + 1, (ks + 1) & 1, 0, NTX);
+#pragma unroll
+            for (int mt = 0; mt < MTQ; ++mt)
+#pragma unroll
+              for (int nt = 0; nt < NTX; ++nt)
+                if (!SM::tile_skipped(mt, nt)) {
+                  ex.mfma(aopQ[ks & 1], mt, bopQ[ks & 1], nt, accQ, mt, nt);
+                  if (pc < 3 * m) piece(pc++);
+                }
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < 3 * m; ++c)
+          if (c >= pc) piece(c);
+        ex.each([&](int lane, int sl) {
+          if (lane <= n) {
+#pragma unroll
+            for (int i = 0; i < m; ++i) Kc[sl][i] = rhs[sl][i];
+            if (lane < n) {
+#pragma unroll
+              for (int i = 0; i < m; ++i) Kn[i * KS + lane] = -rhs[sl][i];
+            } else {
+#pragma unroll
+              for (int i = 0; i < m; ++i) kf[i] = rhs[sl][i];
+            }
+          }
+        });
+      } else
+#endif
+      {
       // (operands of k step ks + 1 are requested from LDS before the matrix-core instructions of step ks are issued: the
       //  stage fences of `each` would otherwise expose one LDS round trip per k step)
+#if EMPC_BWD_MFMA4
+      {
+        // one instruction per (row group, column tile, k step): A = the group's four rows of V' in every block
+        double aopW[2][Exec::SLOTS][SM::RGN], bopW[2][Exec::SLOTS][NTQ];
+        auto loadW = [&](int ks, int buf) {
+          ex.each([&](int lane, int sl) {
+            const int li = lane % 16, lq = lane / 16;
+#pragma unroll
+            for (int rg = 0; rg < SM::RGN; ++rg) aopW[buf][sl][rg] = V[(4 * rg + li % 4) * VS + 4 * ks + lq];
+#pragma unroll
+            for (int nt = 0; nt < NTQ; ++nt) bopW[buf][sl][nt] = rec[DM::OFF_A + (4 * ks + lq) * nm + 16 * nt + li];
+          });
+        };
+        loadW(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < KSN; ++ks) {
+          if (ks + 1 < KSN) loadW(ks + 1, (ks + 1) & 1);
+#pragma unroll
+          for (int rg = 0; rg < SM::RGN; ++rg)
+#pragma unroll
+            for (int nt = 0; nt < NTQ; ++nt) ex.mfma4(aopW[ks & 1], rg, bopW[ks & 1], nt, accW, rg / 4, nt, rg % 4);
+        }
+      }
+#else
       {
         double aopW[2][Exec::SLOTS][MTN], bopW[2][Exec::SLOTS][NTQ];
         auto loadW = [&](int ks, int buf) {
@@ -403,11 +624,37 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
             for (int nt = 0; nt < NTQ; ++nt) ex.mfma(aopW[ks & 1], mt, bopW[ks & 1], nt, accW, mt, nt);
         }
       }
+#endif
       BWD_STAMP(1);
       // Q = H + A^T [W | Vx'].  A^T[i][k] = A[k][i]: same address pattern as the B operand above.  B operand = the W
       // accumulators themselves (register r of tile (mt, nt) holds row 4 mt' + r ... of k step ks = 4 mt + r), with column
       // nm taken from Vx' (zero beyond n).  Rows >= n of W are exact zeros (zero rows of V), so the garbage A^T values of
       // k >= n contribute nothing.
+#if EMPC_BWD_MFMA4
+      {
+        double aopQ[2][Exec::SLOTS][SM::RGQ], bopQ[2][Exec::SLOTS][NTQ];
+        auto loadQ = [&](int ks, int buf) {
+          ex.each([&](int lane, int sl) {
+            const int li = lane % 16, lq = lane / 16;
+#pragma unroll
+            for (int rg = 0; rg < SM::RGQ; ++rg) aopQ[buf][sl][rg] = rec[DM::OFF_A + (4 * ks + lq) * nm + 4 * rg + li % 4];
+            const double vxk = vx[4 * ks + lq];
+#pragma unroll
+            for (int nt = 0; nt < NTQ; ++nt) bopQ[buf][sl][nt] = (16 * nt + li == nm) ? vxk : accW[sl][ks / 4][nt][ks % 4];
+          });
+        };
+        loadQ(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < KSN; ++ks) {
+          if (ks + 1 < KSN) loadQ(ks + 1, (ks + 1) & 1);
+#pragma unroll
+          for (int rg = 0; rg < SM::RGQ; ++rg)
+#pragma unroll
+            for (int nt = 0; nt < NTQ; ++nt)
+              if (!SM::group_skipped(rg, nt)) ex.mfma4(aopQ[ks & 1], rg, bopQ[ks & 1], nt, accQ, rg / 4, nt, rg % 4);
+        }
+      }
+#else
       {
         double aopQ[2][Exec::SLOTS][MTQ], bopQ[2][Exec::SLOTS][NTQ];
         auto loadQ = [&](int ks, int buf) {
@@ -431,6 +678,7 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
               if (!SM::tile_skipped(mt, nt)) ex.mfma(aopQ[ks & 1], mt, bopQ[ks & 1], nt, accQ, mt, nt);
         }
       }
+#endif
       // whole tiles into the padded Q array (column nm = Qx | Qu)
       ex.each([&](int lane, int sl) {
         const int lj = lane % 16, lq = lane / 16;
@@ -538,6 +786,7 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
           }
         }
       });
+      }
       BWD_STAMP(8);
       ex.sync();
       BWD_STAMP(9);
@@ -591,6 +840,30 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
         }
       });
       BWD_STAMP(11);
+#if EMPC_BWD_MFMA4
+      {
+        double aopV[2][Exec::SLOTS][SM::RGN], bopV[2][Exec::SLOTS][MTN];
+        auto loadV = [&](int ks, int buf) {
+          ex.each([&](int lane, int sl) {
+            const int li = lane % 16, lq = lane / 16;
+#pragma unroll
+            for (int rg = 0; rg < SM::RGN; ++rg) aopV[buf][sl][rg] = Q[(4 * rg + li % 4) * QS + n + 4 * ks + lq];
+#pragma unroll
+            for (int mt = 0; mt < MTN; ++mt) bopV[buf][sl][mt] = Kn[(4 * ks + lq) * KS + 16 * mt + li];
+          });
+        };
+        loadV(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < KSM; ++ks) {
+          if (ks + 1 < KSM) loadV(ks + 1, (ks + 1) & 1);
+#pragma unroll
+          for (int rg = 0; rg < SM::RGN; ++rg)
+#pragma unroll
+            for (int nt = 0; nt < MTN; ++nt)
+              if (!SM::group_skipped(rg, nt)) ex.mfma4(aopV[ks & 1], rg, bopV[ks & 1], nt, accQ, rg / 4, nt, rg % 4);
+        }
+      }
+#else
       {
         double aopV[2][Exec::SLOTS][MTN], bopV[2][Exec::SLOTS][MTN];
         auto loadV = [&](int ks, int buf) {
@@ -614,6 +887,7 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
               if (!SM::tile_skipped(mt, nt)) ex.mfma(aopV[ks & 1], mt, bopV[ks & 1], nt, accQ, mt, nt);
         }
       }
+#endif
       ex.each([&](int lane, int sl) {
         const int lj = lane % 16, lq = lane / 16;
 #pragma unroll
@@ -728,9 +1002,14 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
 #if EMPC_BWD_GLDS
       return true;
     };
-    for (int t = T - 1; t >= 0; t -= 2) {
-      if (!knot(t, std::integral_constant<int, 0>{})) break;
-      if (t >= 1 && !knot(t - 1, std::integral_constant<int, 1>{})) break;
+    if constexpr (SM::GLDS) {
+      for (int t = T - 1; t >= 0; t -= 2) {
+        if (!knot(t, std::integral_constant<int, 0>{})) break;
+        if (t >= 1 && !knot(t - 1, std::integral_constant<int, 1>{})) break;
+      }
+    } else {  // (a class without room for the second buffer: one copy of the body, records staged through registers as ever)
+      for (int t = T - 1; t >= 0; --t)
+        if (!knot(t, std::integral_constant<int, 0>{})) break;
     }
 #else
     }

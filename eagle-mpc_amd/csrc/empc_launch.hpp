@@ -226,8 +226,6 @@ __global__ void __launch_bounds__(BLK) EMPC_LIN_ATTR k_linearize_all(DevBuffers 
 #define EMPC_GLDS_HEAD "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_mov_b64 %2, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
 #define EMPC_GLDS_NEXT "v_lshl_add_u64 %1, %1, 0, %2\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
 #define EMPC_GLDS_TAIL "s_mov_b32 m0, %0"
-#define EMPC_GLDS_ASM(body)                                                                                       \
-  asm volatile(EMPC_GLDS_HEAD body EMPC_GLDS_TAIL : "=&s"(keep), "+v"(g), "=&s"(inc) : "s"(l) : "memory", "scc")
 template <int ROWS>
 __device__ __forceinline__ void glds_rows(double* dst, const double* src_lane) {
   static_assert(ROWS == 4 || ROWS == 7 || ROWS == 9, "record sizes of the robot classes this variant is built for");
@@ -285,6 +283,12 @@ struct BlockExec {
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched
     __builtin_amdgcn_sched_barrier(0);
   }
+  // EMPC_BWD_MFMA4: one v_mfma_f64_4x4x4_4b_f64: register r of accumulator tile (im, in) += A-operand a[ia] x B-operand b[ib], four
+  // independent 4 x 4 x 4 products (block = (lane % 16) / 4)
+  template <class A, class B, class C>
+  __device__ __forceinline__ void mfma4(A& a, int ia, B& b, int ib, C& c, int im, int in, int r) {
+    c[0][im][in][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[0][ia], b[0][ib], c[0][im][in][r], 0, 0, 0);
+  }
   // one v_mfma_f64_16x16x4_f64 of the wavefront: acc[im][in] += A-operand a[ia] x B-operand b[ib] (per-lane values)
   template <class A, class B, class C>
   __device__ __forceinline__ void mfma(A& a, int ia, B& b, int ib, C& c, int im, int in) {
@@ -338,6 +342,12 @@ struct WaveExec {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched
     __builtin_amdgcn_sched_barrier(0);
+  }
+  // EMPC_BWD_MFMA4: one v_mfma_f64_4x4x4_4b_f64: register r of accumulator tile (im, in) += A-operand a[ia] x B-operand b[ib], four
+  // independent 4 x 4 x 4 products (block = (lane % 16) / 4)
+  template <class A, class B, class C>
+  __device__ __forceinline__ void mfma4(A& a, int ia, B& b, int ib, C& c, int im, int in, int r) {
+    c[0][im][in][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[0][ia], b[0][ib], c[0][im][in][r], 0, 0, 0);
   }
   template <class A, class B, class C>
   __device__ __forceinline__ void mfma(A& a, int ia, B& b, int ib, C& c, int im, int in) {

@@ -50,3 +50,22 @@
 #ifndef EMPC_BOX_LDS
 #define EMPC_BOX_LDS 0
 #endif
+// backward: the three dense products on v_mfma_f64_4x4x4_4b_f64 (four independent 4 x 4 x 4 products per instruction) instead of
+// v_mfma_f64_16x16x4_f64.  With the documented operand layout -- A / B: lane = 16 k + 4 block + i (resp. j), D: lane = 16 i + 4 block
+// + j -- one such instruction is ONE ROW GROUP (register r, four rows) of a 16 x 16 x 4 tile whose A operand carries the same four
+// rows in every block: accumulators, B operands (W stays in registers as the B operand of the Q product) and every LDS array keep
+// their layout, only the A fetch changes (row 4 g + lane % 4) and row groups of pure padding are never issued: n = 18 uses 5 of 8,
+// n + m = 27 uses 7 of 8.  9-DoF: 140 instructions of 512 flop (35 tile equivalents) for 52 tiles of 2048 flop; with
+// EMPC_BWD_SYMTILES 132 (33) for 44.  Pays only if the instruction issues in 16 cycles on gfx950 (its 16 x 16 x 4 sibling: 64):
+// tools/probes/mfma_f64_4x4_probe.hip measures that and the layout; the lane emulator models the layout above.
+#ifndef EMPC_BWD_MFMA4
+#define EMPC_BWD_MFMA4 0
+#endif
+// backward: the dense products are issued in two phases -- first the column tiles that reach column n (they give Qxu, Quu, Qx, Qu:
+// all that computeGains reads), then, BETWEEN the column steps of the Cholesky factorisation and the rows of the two substitutions,
+// one matrix-core instruction at a time, the tiles that only feed Qxx (needed by the Vxx update afterwards).  The matrix pipe
+// (64 cycles per instruction) then runs under the ~400 vector instructions of the LLT instead of in front of them.  Same
+// operations on the same operands: bit-identical.  Squash-box instantiations of the 16 x 16 x 4 form only (not BOX, not MFMA4).
+#ifndef EMPC_BWD_OVERLAP
+#define EMPC_BWD_OVERLAP 0
+#endif

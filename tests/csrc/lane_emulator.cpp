@@ -52,6 +52,21 @@ struct CpuExec {
     for (const Pending& p : pending) std::memcpy(p.dst, p.src, sizeof(double) * p.n);
     pending.clear();
   }
+  // v_mfma_f64_4x4x4_4b_f64 as documented (CDNA3 ISA guide / AMD matrix instruction calculator; tools/probes/mfma_f64_4x4_probe.hip
+  // checks it on the chip): four independent products, block = (l % 16) / 4; A[block][i][k] in lane 16 k + 4 block + i,
+  // B[block][k][j] in lane 16 k + 4 block + j, D[block][i][j] in lane 16 i + 4 block + j.  If the probe disagrees only these three
+  // index maps (and the A fetch of the kernel) change.
+  template <class A, class B, class C>
+  void mfma4(A& a, int ia, B& b, int ib, C& c, int im, int in, int r) {
+    double Dm[64];
+    for (int l = 0; l < 64; ++l) {
+      const int blk = (l % 16) / 4, i = l / 16, j = l % 4;
+      double s = c[l][im][in][r];
+      for (int k = 0; k < 4; ++k) s += a[16 * k + 4 * blk + i][ia] * b[16 * k + 4 * blk + j][ib];
+      Dm[l] = s;
+    }
+    for (int l = 0; l < 64; ++l) c[l][im][in][r] = Dm[l];
+  }
   // v_mfma_f64_16x16x4_f64 semantics on per-lane operands: A[i = l % 16][k = l / 16], B[k = l / 16][j = l % 16],
   // D[i = 4 r + l / 16][j = l % 16] (layout verified on gfx950 by tools/probes/mfma_f64_layout.hip)
   template <class A, class B, class C>

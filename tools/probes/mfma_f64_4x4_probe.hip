@@ -132,22 +132,32 @@ int main() {
       if (hit[la * 64 + lb]) std::printf("  B%-2d->D%-2d", lb, dlane(la, lb));
     std::printf("\n");
   }
-  // the hypothesis the backward pass would be written to (ISA manual): lane l = 16 b + 4 k + i for A (A[b][i][k]), l = 16 b + 4 k + j
-  // for B (B[b][k][j]), l = 16 b + 4 i + j for D (D[b][i][j]) -- or with the roles of the two low index pairs swapped.  Test both.
-  const char* names[2] = {"A: l = 16 b + 4 k + i, B: l = 16 b + 4 k + j, D: l = 16 b + 4 i + j",
-                          "A: l = 16 b + 4 k + i, B: l = 16 b + 4 k + j, D: l = 16 b + 4 j + i"};
+  // Hypotheses.  [2] is the one EMPC_BWD_MFMA4 (csrc/empc_backward4.hpp) and the lane emulator (tests/csrc/lane_emulator.cpp mfma4) are
+  // written to: the block index rides on the low 16 lanes like the row / column index of the 16 x 16 x 4 form, k (A, B) and the row
+  // (D) on lane / 16.  [0] / [1]: the block on lane / 16.  If [2] is not the confirmed one, only the index maps of those two places
+  // change (and the variant loses the property that W's accumulators are the B operand of the next product unless D's row and
+  // B's k still share lane / 16).
+  const char* names[3] = {"A: l = 16 b + 4 k + i, B: l = 16 b + 4 k + j, D: l = 16 b + 4 i + j",
+                          "A: l = 16 b + 4 k + i, B: l = 16 b + 4 k + j, D: l = 16 b + 4 j + i",
+                          "A: l = 16 k + 4 b + i, B: l = 16 k + 4 b + j, D: l = 16 i + 4 b + j  (the model of EMPC_BWD_MFMA4)"};
+  auto amap = [](int h, int b_, int i, int k) { return h == 2 ? 16 * k + 4 * b_ + i : 16 * b_ + 4 * k + i; };
+  auto dmap = [](int h, int b_, int i, int j) { return h == 2 ? 16 * i + 4 * b_ + j : (h == 0 ? 16 * b_ + 4 * i + j : 16 * b_ + 4 * j + i); };
   int confirmed = -1;
-  for (int h = 0; h < 2; ++h) {
+  for (int h = 0; h < 3; ++h) {
     bool ok = true;
+    int want[64][64];
+    for (int la = 0; la < 64; ++la)
+      for (int lb = 0; lb < 64; ++lb) want[la][lb] = -1;
+    for (int b_ = 0; b_ < 4; ++b_)
+      for (int k = 0; k < 4; ++k)
+        for (int i = 0; i < 4; ++i)
+          for (int j = 0; j < 4; ++j) want[amap(h, b_, i, k)][amap(h, b_, j, k)] = dmap(h, b_, i, j);
     for (int la = 0; la < 64 && ok; ++la)
-      for (int lb = 0; lb < 64 && ok; ++lb) {
-        const int ba = la / 16, ka = (la % 16) / 4, ia = la % 4, bb = lb / 16, kb = (lb % 16) / 4, jb = lb % 4;
-        const int want = (ba == bb && ka == kb) ? (h == 0 ? 16 * ba + 4 * ia + jb : 16 * ba + 4 * jb + ia) : -1;
-        ok = dlane(la, lb) == want && !(hit[la * 64 + lb] & (hit[la * 64 + lb] - 1));
-      }
+      for (int lb = 0; lb < 64 && ok; ++lb) ok = dlane(la, lb) == want[la][lb] && !(hit[la * 64 + lb] & (hit[la * 64 + lb] - 1));
     std::printf("hypothesis %d (%s): %s\n", h, names[h], ok ? "CONFIRMED" : "no");
     if (ok) confirmed = h;
   }
+  std::printf("layout model of EMPC_BWD_MFMA4: %s\n", confirmed == 2 ? "CONFIRMED" : "NOT CONFIRMED -- do not adopt the variant before its index maps are rewritten");
   // numbers through the confirmed map
   int rc = confirmed >= 0 ? 0 : 1;
   if (confirmed >= 0) {
@@ -160,9 +170,9 @@ int main() {
     for (int b = 0; b < 4; ++b)
       for (int i = 0; i < 4; ++i)
         for (int j = 0; j < 4; ++j) {
-          const int ld = confirmed == 0 ? 16 * b + 4 * i + j : 16 * b + 4 * j + i;
+          const int ld = dmap(confirmed, b, i, j);
           double s = hc[ld];
-          for (int k = 0; k < 4; ++k) s += ha[16 * b + 4 * k + i] * hb[16 * b + 4 * k + j];
+          for (int k = 0; k < 4; ++k) s += ha[amap(confirmed, b, i, k)] * hb[amap(confirmed, b, j, k)];
           ref[ld] = s;
         }
     double *da, *db, *dc, *dd;
