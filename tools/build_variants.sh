@@ -1,0 +1,25 @@
+#!/bin/bash
+# CPU side: the variant libraries tools/gpu_r5.sh variants A/Bs against the shipped one (eagle-mpc_amd/libempc_<tag>.so, switches of
+# csrc/empc_variants.hpp; ~3 minutes each with 8 cores).  bash tools/build_variants.sh [tag ...]    JOBS=6 by default
+set -uo pipefail
+cd "$(dirname "${BASH_SOURCE[0]}")/../eagle-mpc_amd"
+declare -A V=(
+  [r4b]="-DEMPC_BWD_R4B=1"
+  [sym]="-DEMPC_BWD_SYMTILES=1"
+  [glds]="-DEMPC_BWD_GLDS=1"
+  [boxlds]="-DEMPC_BOX_LDS=1"
+  [mfma4]="-DEMPC_BWD_MFMA4=1"
+  [overlap]="-DEMPC_BWD_OVERLAP=1"
+  [r6]="-DEMPC_BWD_R4B=1 -DEMPC_BWD_SYMTILES=1 -DEMPC_BWD_GLDS=1 -DEMPC_BOX_LDS=1 -DEMPC_ANY_BALLOT=1"
+  [r6o]="-DEMPC_BWD_R4B=1 -DEMPC_BWD_SYMTILES=1 -DEMPC_BWD_GLDS=1 -DEMPC_BOX_LDS=1 -DEMPC_ANY_BALLOT=1 -DEMPC_BWD_OVERLAP=1"
+  [r6m4]="-DEMPC_BWD_R4B=1 -DEMPC_BWD_SYMTILES=1 -DEMPC_BWD_GLDS=1 -DEMPC_BOX_LDS=1 -DEMPC_ANY_BALLOT=1 -DEMPC_BWD_MFMA4=1"
+  [gap]="-DEMPC_ROLL_GAP_EARLY"
+  [bits]="-DEMPC_FSQRT_BITS=1"
+)
+TAGS="${*:-r6 r6o r6m4 r4b sym glds boxlds mfma4 overlap}"
+for t in $TAGS; do
+  [ -n "${V[$t]:-}" ] || { echo "unknown variant $t"; exit 2; }
+  echo "== $t: ${V[$t]}"
+  make -j"${JOBS:-6}" BUILD=build_$t LIB=libempc_$t.so EXTRA="${V[$t]}" 2>&1 | grep -E "error|Error" | head -5
+  ls -la libempc_$t.so | awk '{print $5, $6, $7, $8, $9}'
+done
