@@ -57,3 +57,26 @@ def test_counter_summaries_are_used_only_for_the_device_code_they_were_taken_on(
     k, f, note = bench.committed_counters("eagle_catch", 1024, False, "0" * 16)
     assert k == {} and f is None
     assert bench.committed_counters("eagle_catch", 512, False, cid)[0] == {}
+
+
+def test_gpu_launcher_builds_its_command_for_any_number_of_arguments():
+    """`shift 3` with fewer than three arguments shifted nothing and the mode / tag landed in front of `bash` as a
+    command ("check: command not found" on a scarce GPU slot).  The command line for 0, 2, 3 and 5 arguments:"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def cmd(*a):
+        r = subprocess.run(["bash", os.path.join(root, "tools", "gpurun_r5.sh")] + list(a), capture_output=True, text=True,
+                           env=dict(os.environ, DRY_RUN="1"))
+        assert r.returncode == 0, r.stderr
+        return r.stdout.strip()
+
+    import re
+    for args, mode, tag, tmo, extra in (((), "check", "r05", "2700", ""), (("tests", "r06x"), "tests", "r06x", "2700", ""),
+                                        (("tests", "r06x", "900"), "tests", "r06x", "900", ""),
+                                        (("variants", "r06v", "5000", "VARIANTS=r6o", "CONFIGS=eagle_catch"), "variants", "r06v", "5000",
+                                         "VARIANTS=r6o CONFIGS=eagle_catch")):
+        out = cmd(*args)
+        m = re.fullmatch(r"gpurun --timeout (\d+) -- EMPC_COMMIT=(\S+) (.*?) ?bash tools/gpu_r5.sh (\S+) (\S+)", out)
+        assert m, out
+        assert m.group(1) == tmo and m.group(4) == mode and m.group(5) == tag and m.group(3).strip() == extra, out

@@ -3,7 +3,7 @@
 #   tools/gpu_r5.sh ab           bench lines with the baked-robot kernels on (default) and off (EMPC_BAKED=0), eagle_catch +
 #                                displacement + push_slide, no CPU baseline (kernel comparison only)
 #   tools/gpu_r5.sh tests        GPU suite only
-#   tools/gpu_r5.sh profiles     rocprofv3 kernel stats + PMC passes behind profiles/r05_*
+#   tools/gpu_r5.sh profiles     rocprofv3 kernel stats + PMC passes behind profiles/r06_*
 #   tools/gpu_r5.sh final        check + profiles + lines (then: bash tools/keep_r05.sh <tag> copies the summaries to profiles/)
 #   tools/gpu_r5.sh lines        bench lines of hover and the three closed-loop MPC configurations
 #   tools/gpu_r5.sh slots        occupancy experiment (slots in flight x build variants)
@@ -56,7 +56,7 @@ case "$MODE" in
     done
     ;;
   profiles)
-    # what is kept under profiles/r05_*: the bench line, the rocprofv3 kernel-trace summary of the same command and four
+    # what is kept under profiles/r06_*: the bench line, the rocprofv3 kernel-trace summary of the same command and four
     # --pmc passes (HBM reads, HBM writes, FP64 instruction mix, wavefront activity) over a short stream run
     export TMPDIR=/tmp
     O="$ROOT/gpurun_out/${TAG}_prof"; rm -rf "$O"; mkdir -p "$O"

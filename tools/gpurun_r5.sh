@@ -8,6 +8,8 @@ MODE="${1:-check}"; TAG="${2:-r05}"; TMO="${3:-2700}"; shift $(( $# < 3 ? $# : 3
 SHA=$(git rev-parse --short HEAD)
 [ -n "$(git status --porcelain -- eagle-mpc_amd include bench.py tests tools oracle | head -1)" ] && SHA="${SHA}+dirty"
 mkdir -p gpurun_out
+# DRY_RUN=1: print the command line gpurun would get and stop (tests/test_bench_launch.py checks it for 0, 2 and 4+ arguments)
+if [ -n "${DRY_RUN:-}" ]; then echo "gpurun --timeout $TMO -- EMPC_COMMIT=$SHA $* bash tools/gpu_r5.sh $MODE $TAG"; exit 0; fi
 /usr/local/graft/bin/gpurun --timeout "$TMO" -- "EMPC_COMMIT=$SHA $* bash tools/gpu_r5.sh $MODE $TAG" > "gpurun_out/${TAG}_call.log" 2>&1
 rc=$?
 tail -${TAIL:-60} "gpurun_out/${TAG}_call.log"
