@@ -188,10 +188,19 @@ EMPC_HD void frame_capture(const MT& m, int f, const S* Rb, const S* pb, const S
 //   cap_frames[ncap]: operational frames to capture (indices into the model's frame table)
 // Register discipline: only the per-body forces survive the forward sweep; joint rotations are rebuilt from cs/sn
 // in the backward sweep.
+#if EMPC_ROLL_CAP_LDS
+// (EMPC_ROLL_CAP_LDS: the recursion hands a captured frame to `capture(slot, frame, Rw, pw, vb, ab)`; the classic signature below
+//  stores it in caps[slot])
+template <int NB, class S, class MT, class CapF>
+EMPC_HD void rnea_chain_f(const MT& m, const S* R0, const S* p0, const S* cs, const S* sn, const S* v,
+                          const S* a, bool gravity, int fext_b, const S* fext, S* tau, int ncap, const int* cap_frames,
+                          CapF&& capture) {
+#else
 template <int NB, class S, class MT>
 EMPC_HD void rnea_chain(const MT& m, const S* R0, const S* p0, const S* cs, const S* sn, const S* v,
                         const S* a, bool gravity, int fext_b, const S* fext, S* tau, int ncap, const int* cap_frames,
                         FrameCap<S>* caps) {
+#endif
   S f[NB][6];
   S Rw[9], pw[3], vb[6], ab[6];  // rolling: world placement, body-frame velocity / acceleration of the current body
 #pragma unroll
@@ -260,7 +269,11 @@ EMPC_HD void rnea_chain(const MT& m, const S* R0, const S* p0, const S* cs, cons
     // frame captures on this body
 #pragma unroll
     for (int c = 0; c < NCAP; ++c)
+#if EMPC_ROLL_CAP_LDS
+      if (c < ncap && m.frame_body[cap_frames[c]] == b) capture(c, cap_frames[c], Rw, pw, vb, ab);
+#else
       if (c < ncap && m.frame_body[cap_frames[c]] == b) frame_capture<S>(m, cap_frames[c], Rw, pw, vb, ab, caps[c]);
+#endif
     // f_b = I a + v x* (I v) - fext
     S Ia[6], Iv[6], c1[3], c2[3], c3[3];
     inertia_apply<S>(m, b, ab, Ia);
@@ -297,6 +310,15 @@ EMPC_HD void rnea_chain(const MT& m, const S* R0, const S* p0, const S* cs, cons
 #pragma unroll
   for (int i = 0; i < 6; ++i) tau[i] = f[0][i];
 }
+#if EMPC_ROLL_CAP_LDS
+template <int NB, class S, class MT>
+EMPC_HD void rnea_chain(const MT& m, const S* R0, const S* p0, const S* cs, const S* sn, const S* v,
+                        const S* a, bool gravity, int fext_b, const S* fext, S* tau, int ncap, const int* cap_frames,
+                        FrameCap<S>* caps) {
+  rnea_chain_f<NB, S>(m, R0, p0, cs, sn, v, a, gravity, fext_b, fext, tau, ncap, cap_frames,
+                      [&](int c, int f, const S* Rw, const S* pw, const S* vb, const S* ab) { frame_capture<S>(m, f, Rw, pw, vb, ab, caps[c]); });
+}
+#endif
 
 // Composite-rigid-body algorithm on a serial chain; output: packed lower triangle of M (idx(i,j) = i(i+1)/2 + j).
 // Composite inertias are carried as (mass, COM, rotational inertia about the COM) in body axes.

@@ -50,7 +50,11 @@ struct Roll6Smem {
   static constexpr int OFF_TAU = OFF_UT + NU * NL;            // generalized force                    (A -> C)
   static constexpr int OFF_H = OFF_TAU + NV * NL;             // bias forces                          (B -> C)
   static constexpr int OFF_CAP = OFF_H + NV * NL;             // contact frame capture, 24 doubles    (B -> C)
+#if EMPC_ROLL_CAP_LDS
+  static constexpr int OFF_ACC = OFF_CAP + NCAP * 24 * NL;    // (one 24-double slot per captured frame: B -> B's frame costs, C)
+#else
   static constexpr int OFF_ACC = OFF_CAP + 24 * NL;           // acceleration | contact force         (C -> D)
+#endif
   static constexpr int OFF_ELLF = OFF_ACC + DM::NACC * NL;    // frame-cost sum, by knot parity       (B -> D)
   static constexpr int OFF_VAL = OFF_ELLF + 2 * NL;           // activation value per cost            (D -> D)
   static constexpr int OFF_FLAG = OFF_VAL + EMPC_MAX_COSTS * NL;  // ok flag of role C
@@ -525,6 +529,29 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
 #pragma unroll
       for (int k = 0; k < NCAP; ++k) capf[k] = si.capf[k];
       const int ncap = si.ncap, ccap = si.ccap;
+#if EMPC_ROLL_CAP_LDS
+      double zero[NV], h[NV];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) zero[i] = 0.0;
+      R6_SUB(1);
+      rnea_chain_f<NB, double>(m, R0, q, cs, sn, v, zero, true, -1, nullptr, h, ncap, capf,
+                               [&](int c, int f, const double* Rw, const double* pw, const double* vb, const double* ab) {
+                                 FrameCap<double> fk;
+                                 frame_capture<double>(m, f, Rw, pw, vb, ab, fk);
+                                 double* slot = CAP + (size_t)c * 24 * NL + lane;
+#pragma unroll
+                                 for (int i = 0; i < 9; ++i) slot[i * NL] = fk.R[i];
+#pragma unroll
+                                 for (int i = 0; i < 3; ++i) slot[(9 + i) * NL] = fk.p[i];
+#pragma unroll
+                                 for (int i = 0; i < 6; ++i) slot[(12 + i) * NL] = fk.v[i];
+#pragma unroll
+                                 for (int i = 0; i < 6; ++i) slot[(18 + i) * NL] = fk.a[i];
+                               });
+      R6_SUB(2);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) HB[i * NL + lane] = h[i];
+#else
       FrameCap<double> caps[NCAP];
       double zero[NV], h[NV];
 #pragma unroll
@@ -550,6 +577,7 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
           for (int i = 0; i < 6; ++i) CAP[(18 + i) * NL + lane] = ck.a[i];
         }
       }
+#endif
       R6_SUB(3);
       // frame costs (value only), summed in cost order
       double ell_frames = 0;
@@ -557,10 +585,27 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
         const auto& c = set.costs[si.frame_ci[kf]];
         double cval = 0;
         {
+#if EMPC_ROLL_CAP_LDS
+          int fslot = 0;  // (same choice as the register form: slot 0 unless a later slot holds the cost's frame)
+#pragma unroll
+          for (int kk = 1; kk < NCAP; ++kk)
+            if (kk < ncap && capf[kk] == c.frame) fslot = kk;
+          FrameCap<double> fk;
+          {
+            const double* slot = CAP + (size_t)fslot * 24 * NL + lane;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) fk.R[i] = slot[i * NL];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) fk.p[i] = slot[(9 + i) * NL];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) fk.v[i] = slot[(12 + i) * NL];
+          }
+#else
           FrameCap<double> fk = caps[0];
 #pragma unroll
           for (int kk = 1; kk < NCAP; ++kk)
             if (kk < ncap && capf[kk] == c.frame) fk = caps[kk];
+#endif
           double r[6];
           int nr = 6;
           if (c.type == EMPC_COST_FRAME_PLACEMENT) {
@@ -687,14 +732,20 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
       if constexpr (CT) {
         if (use_contact) {
           FrameCap<double> ck;
+#if EMPC_ROLL_CAP_LDS
+          // the slot role B's register form copied from: caps[0] unless a later slot is the contact frame's (si.ccap)
+          const double* CAPc = CAP + (size_t)((si.ccap >= 1 && si.ccap < NCAP) ? si.ccap : 0) * 24 * NL;
+#else
+          const double* CAPc = CAP;
+#endif
 #pragma unroll
-          for (int i = 0; i < 9; ++i) ck.R[i] = CAP[i * NL + lane];
+          for (int i = 0; i < 9; ++i) ck.R[i] = CAPc[i * NL + lane];
 #pragma unroll
-          for (int i = 0; i < 3; ++i) ck.p[i] = CAP[(9 + i) * NL + lane];
+          for (int i = 0; i < 3; ++i) ck.p[i] = CAPc[(9 + i) * NL + lane];
 #pragma unroll
-          for (int i = 0; i < 6; ++i) ck.v[i] = CAP[(12 + i) * NL + lane];
+          for (int i = 0; i < 6; ++i) ck.v[i] = CAPc[(12 + i) * NL + lane];
 #pragma unroll
-          for (int i = 0; i < 6; ++i) ck.a[i] = CAP[(18 + i) * NL + lane];
+          for (int i = 0; i < 6; ++i) ck.a[i] = CAPc[(18 + i) * NL + lane];
           double R0[9], cs[NB], sn[NB];
           quat_to_R(x + 3, R0);
 #pragma unroll

@@ -69,3 +69,10 @@
 #ifndef EMPC_BWD_OVERLAP
 #define EMPC_BWD_OVERLAP 0
 #endif
+// rollout, role B (the longest role of a knot: bias forces + frame captures + frame costs): a captured operational frame (24
+// doubles) is written to its LDS slot where the recursion produces it instead of living in registers -- two captures = 96 VGPRs
+// merged over eight (body, slot) branches -- until the frame costs at the end of the knot; the frame costs and role C's contact
+// dynamics read the slot they need.  Same values, same arithmetic.  LDS per workgroup + 12 KB.
+#ifndef EMPC_ROLL_CAP_LDS
+#define EMPC_ROLL_CAP_LDS 0
+#endif
