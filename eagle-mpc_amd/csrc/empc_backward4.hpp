@@ -313,6 +313,10 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
     // record prefetch is issued: loads and stores share one in-order counter, so a store issued late in a knot would be
     // waited for when the prefetched record is consumed (measured: ~2k cycles per knot).
     double Kc[Exec::SLOTS][m], vfo[Exec::SLOTS], vxo[Exec::SLOTS];
+#if EMPC_BWD_FUSE
+    bool pdl[Exec::SLOTS];  // the LLT's verdict as every lane found it (the factorisation is redundant across the lanes)
+    ex.each([&](int lane, int sl) { pdl[sl] = true; });
+#endif
     auto flush_outputs = [&](int tk, int lane, int sl) {
       if (lane < n) {
         double* Kg = D.K + ((size_t)b * T + tk) * m * n;
@@ -503,6 +507,9 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
                 }
               BWD_PIN(L[j * (j + 1) / 2 + j]);
               if (c == m - 1 && lane == 0) flag[0] = pd[sl] ? 0.0 : 1.0;
+#if EMPC_BWD_FUSE
+              if (c == m - 1) pdl[sl] = pd[sl];
+#endif
             } else if (c < 2 * m) {
               const int i = c - m;
               if (lane <= n) {
@@ -772,6 +779,9 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
 #pragma unroll
         for (int i = 0; i < m; ++i) Lq[i * (i + 1) / 2 + i] += ureg;
         const bool pd = chol_packed<m>(Lq);
+#if EMPC_BWD_FUSE
+        pdl[sl] = pd;
+#endif
         if (lane == 0) flag[0] = pd ? 0.0 : 1.0;
         if (lane <= n) {
           chol_solve_packed<m>(Lq, rhs);
@@ -787,6 +797,68 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
         }
       });
       }
+#if EMPC_BWD_FUSE
+      const bool box_gains_f = BOX && is_feasible && (P.prm.solver_type == EMPC_SOLVER_BOXDDP || P.prm.solver_type == EMPC_SOLVER_BOXFDDP);
+      if (!box_gains_f) {
+        BWD_STAMP(8);
+        if (!ex.first(pdl)) {  // (identical in every lane: the first one speaks for all)
+          fail = true;
+          BWD_KNOT_EXIT;
+        }
+        // k: lane n's solved column, to every lane as scalars
+        double kk[m];
+#pragma unroll
+        for (int j = 0; j < m; ++j) kk[j] = ex.bcast(Kc, j, n);
+        BWD_STAMP(9);
+        // Quu k, one row per lane (same order of summation as the single-lane form)
+        double qkl[Exec::SLOTS];
+        ex.each([&](int lane, int sl) {
+          qkl[sl] = 0.0;
+          if (lane < m) {
+            double qrow[m];
+#pragma unroll
+            for (int j = 0; j < m; ++j) qrow[j] = Q[(n + (lane > j ? lane : j)) * QS + n + (lane > j ? j : lane)];
+            const double ql = Q[(n + lane) * QS + nm];
+            double kl = kk[0];  // k[lane]: a select per control (pinned: left alone the compiler builds a table in scratch memory)
+#pragma unroll
+            for (int j = 1; j < m; ++j) {
+              if (lane == j) kl = kk[j];
+              BWD_PIN(kl);
+            }
+            BWD_FENCE();
+            double a_ = 0;
+#pragma unroll
+            for (int j = 0; j < m; ++j) a_ += qrow[j] * kk[j];
+            const double qk = a_ + ureg * kl;
+            qkl[sl] = qk;
+            dgu_l[sl] += ql * kl;
+            dqu_l[sl] -= kl * qk;
+            qu2_l[sl] += ql * ql;
+          }
+        });
+        double qks[m];
+#pragma unroll
+        for (int l = 0; l < m; ++l) qks[l] = ex.bcast1(qkl, l);
+        BWD_STAMP(10);
+        BWD_STAMP(3);
+        ex.each([&](int lane, int sl) {
+          if (lane < n) {
+            double quv[m];
+#pragma unroll
+            for (int l = 0; l < m; ++l) quv[l] = Q[(n + l) * QS + nm];
+            double a_ = Q[lane * QS + nm];
+            BWD_FENCE();
+#pragma unroll
+            for (int l = 0; l < m; ++l) a_ += Kc[sl][l] * qks[l];
+#pragma unroll
+            for (int l = 0; l < m; ++l) a_ -= 2.0 * Kc[sl][l] * quv[l];
+            red[64 + lane] = a_;
+          }
+        });
+        ex.sync();  // -K (written by the gain solve) and red before the Vxx stage / the gap stage read them
+      } else
+#endif
+      {
       BWD_STAMP(8);
       ex.sync();
       BWD_STAMP(9);
@@ -839,6 +911,7 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
           red[64 + lane] = a_;
         }
       });
+      }
       BWD_STAMP(11);
 #if EMPC_BWD_MFMA4
       {

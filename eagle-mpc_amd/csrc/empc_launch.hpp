@@ -283,6 +283,29 @@ struct BlockExec {
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched
     __builtin_amdgcn_sched_barrier(0);
   }
+  // EMPC_BWD_FUSE: wave broadcasts.  bcast(a, j, L): a[.][j] of lane L (a compile-time lane after unrolling) as a wave-uniform
+  // value (two v_readlane_b32 -> a scalar register pair); bcast1(a, L): the same for one value per lane; first(a): lane 0's flag
+  template <class A>
+  __device__ __forceinline__ double bcast(A& a, int j, int L) {
+    return rdlane(a[0][j], L);
+  }
+  template <class A>
+  __device__ __forceinline__ double bcast1(A& a, int L) {
+    return rdlane(a[0], L);
+  }
+  template <class A>
+  __device__ __forceinline__ bool first(A& a) {
+    return __builtin_amdgcn_readfirstlane(a[0] ? 1 : 0) != 0;
+  }
+  static __device__ __forceinline__ double rdlane(double v, int L) {
+    unsigned long long u;
+    __builtin_memcpy(&u, &v, 8);
+    const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)u, L), hi = __builtin_amdgcn_readlane((int)(unsigned)(u >> 32), L);
+    u = ((unsigned long long)hi << 32) | lo;
+    double r;
+    __builtin_memcpy(&r, &u, 8);
+    return r;
+  }
   // EMPC_BWD_MFMA4: one v_mfma_f64_4x4x4_4b_f64: register r of accumulator tile (im, in) += A-operand a[ia] x B-operand b[ib], four
   // independent 4 x 4 x 4 products (block = (lane % 16) / 4)
   template <class A, class B, class C>
@@ -342,6 +365,29 @@ struct WaveExec {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched
     __builtin_amdgcn_sched_barrier(0);
+  }
+  // EMPC_BWD_FUSE: wave broadcasts.  bcast(a, j, L): a[.][j] of lane L (a compile-time lane after unrolling) as a wave-uniform
+  // value (two v_readlane_b32 -> a scalar register pair); bcast1(a, L): the same for one value per lane; first(a): lane 0's flag
+  template <class A>
+  __device__ __forceinline__ double bcast(A& a, int j, int L) {
+    return rdlane(a[0][j], L);
+  }
+  template <class A>
+  __device__ __forceinline__ double bcast1(A& a, int L) {
+    return rdlane(a[0], L);
+  }
+  template <class A>
+  __device__ __forceinline__ bool first(A& a) {
+    return __builtin_amdgcn_readfirstlane(a[0] ? 1 : 0) != 0;
+  }
+  static __device__ __forceinline__ double rdlane(double v, int L) {
+    unsigned long long u;
+    __builtin_memcpy(&u, &v, 8);
+    const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)u, L), hi = __builtin_amdgcn_readlane((int)(unsigned)(u >> 32), L);
+    u = ((unsigned long long)hi << 32) | lo;
+    double r;
+    __builtin_memcpy(&r, &u, 8);
+    return r;
   }
   // EMPC_BWD_MFMA4: one v_mfma_f64_4x4x4_4b_f64: register r of accumulator tile (im, in) += A-operand a[ia] x B-operand b[ib], four
   // independent 4 x 4 x 4 products (block = (lane % 16) / 4)

@@ -76,3 +76,10 @@
 #ifndef EMPC_ROLL_CAP_LDS
 #define EMPC_ROLL_CAP_LDS 0
 #endif
+// backward, plain gains: k (solved by lane n), Quu k (one row per lane < m) and the LLT's verdict travel to the lanes that need them
+// as wave broadcasts (v_readlane -> scalar operands) instead of through LDS: two LDS hand-overs with their barriers and ~40 LDS
+// instructions per knot become 36 v_readlane.  With one wavefront per SIMD every LDS round trip is exposed latency.  Same
+// operations in the same order.  The box-QP path keeps the LDS form.
+#ifndef EMPC_BWD_FUSE
+#define EMPC_BWD_FUSE 0
+#endif

@@ -52,6 +52,19 @@ struct CpuExec {
     for (const Pending& p : pending) std::memcpy(p.dst, p.src, sizeof(double) * p.n);
     pending.clear();
   }
+  // EMPC_BWD_FUSE: wave broadcasts (v_readlane on the device)
+  template <class A>
+  double bcast(A& a, int j, int L) {
+    return a[L][j];
+  }
+  template <class A>
+  double bcast1(A& a, int L) {
+    return a[L];
+  }
+  template <class A>
+  bool first(A& a) {
+    return a[0];
+  }
   // v_mfma_f64_4x4x4_4b_f64 as documented (CDNA3 ISA guide / AMD matrix instruction calculator; tools/probes/mfma_f64_4x4_probe.hip
   // checks it on the chip): four independent products, block = (l % 16) / 4; A[block][i][k] in lane 16 k + 4 block + i,
   // B[block][k][j] in lane 16 k + 4 block + j, D[block][i][j] in lane 16 i + 4 block + j.  If the probe disagrees only these three

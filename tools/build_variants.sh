@@ -13,10 +13,14 @@ declare -A V=(
   [r6]="-DEMPC_BWD_R4B=1 -DEMPC_BWD_SYMTILES=1 -DEMPC_BWD_GLDS=1 -DEMPC_BOX_LDS=1 -DEMPC_ANY_BALLOT=1"
   [r6o]="-DEMPC_BWD_R4B=1 -DEMPC_BWD_SYMTILES=1 -DEMPC_BWD_GLDS=1 -DEMPC_BOX_LDS=1 -DEMPC_ANY_BALLOT=1 -DEMPC_BWD_OVERLAP=1"
   [r6m4]="-DEMPC_BWD_R4B=1 -DEMPC_BWD_SYMTILES=1 -DEMPC_BWD_GLDS=1 -DEMPC_BOX_LDS=1 -DEMPC_ANY_BALLOT=1 -DEMPC_BWD_MFMA4=1"
+  [fuse]="-DEMPC_BWD_FUSE=1"
+  [rcap]="-DEMPC_ROLL_CAP_LDS=1"
+  [r6of]="-DEMPC_BWD_R4B=1 -DEMPC_BWD_SYMTILES=1 -DEMPC_BWD_GLDS=1 -DEMPC_BOX_LDS=1 -DEMPC_ANY_BALLOT=1 -DEMPC_BWD_OVERLAP=1 -DEMPC_BWD_FUSE=1"
+  [all]="-DEMPC_BWD_R4B=1 -DEMPC_BWD_SYMTILES=1 -DEMPC_BWD_GLDS=1 -DEMPC_BOX_LDS=1 -DEMPC_ANY_BALLOT=1 -DEMPC_BWD_OVERLAP=1 -DEMPC_BWD_FUSE=1 -DEMPC_ROLL_CAP_LDS=1 -DEMPC_ROLL_GAP_EARLY"
   [gap]="-DEMPC_ROLL_GAP_EARLY"
   [bits]="-DEMPC_FSQRT_BITS=1"
 )
-TAGS="${*:-r6 r6o r6m4 r4b sym glds boxlds mfma4 overlap}"
+TAGS="${*:-r6 r6o r6of all r6m4 r4b sym glds boxlds mfma4 overlap fuse rcap}"
 for t in $TAGS; do
   [ -n "${V[$t]:-}" ] || { echo "unknown variant $t"; exit 2; }
   echo "== $t: ${V[$t]}"
