@@ -317,6 +317,33 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
     bool pdl[Exec::SLOTS];  // the LLT's verdict as every lane found it (the factorisation is redundant across the lanes)
     ex.each([&](int lane, int sl) { pdl[sl] = true; });
 #endif
+#if EMPC_BWD_VPTR
+    // this lane's slots of knot T - 1 (the first knot flushed); every flush steps them back one knot.  Pinned: opaque per-lane values
+    // stay in vector registers and their increments are vector adds.
+    double *pK[Exec::SLOTS], *pVf[Exec::SLOTS], *pVx[Exec::SLOTS];
+    ex.each([&](int lane, int sl) {
+      pK[sl] = (lane == n) ? D.kff + ((size_t)b * T + (T - 1)) * m : D.K + ((size_t)b * T + (T - 1)) * m * n + (lane < n ? lane : 0);
+      pVf[sl] = D.Vf + ((size_t)b * (T + 1) + (T - 1)) * n + (lane < n ? lane : 0);
+      pVx[sl] = D.Vx + ((size_t)b * (T + 1) + (T - 1)) * n + (lane < n ? lane : 0);
+      BWD_PIN(pK[sl]);
+      BWD_PIN(pVf[sl]);
+      BWD_PIN(pVx[sl]);
+    });
+    auto flush_outputs = [&](int tk, int lane, int sl) {  // (tk: the knot the pointers stand at -- T - 1, T - 2, ... in this order)
+      if (lane < n) {
+#pragma unroll
+        for (int i = 0; i < m; ++i) pK[sl][i * n] = Kc[sl][i];
+        *pVf[sl] = vfo[sl];
+        *pVx[sl] = vxo[sl];
+      } else if (lane == n) {
+#pragma unroll
+        for (int i = 0; i < m; ++i) pK[sl][i] = Kc[sl][i];
+      }
+      pK[sl] -= (lane == n) ? m : m * n;
+      pVf[sl] -= n;
+      pVx[sl] -= n;
+    };
+#else
     auto flush_outputs = [&](int tk, int lane, int sl) {
       if (lane < n) {
         double* Kg = D.K + ((size_t)b * T + tk) * m * n;
@@ -329,6 +356,7 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
         for (int i = 0; i < m; ++i) D.kff[((size_t)b * T + tk) * m + i] = Kc[sl][i];
       }
     };
+#endif
     // EMPC_BWD_GLDS: the knot body exists twice, once per record buffer (a lambda over the buffer index, called alternately), so
     // that every LDS address of a knot is base + immediate as in the default build; `BWD_KNOT_EXIT` leaves the knot loop
 #if EMPC_BWD_GLDS

@@ -83,3 +83,9 @@
 #ifndef EMPC_BWD_FUSE
 #define EMPC_BWD_FUSE 0
 #endif
+// backward: the four output streams of a knot (K column, Vxx f, Vx per lane; k on lane n) are addressed through per-lane pointers
+// kept in vector registers and stepped back one knot per flush, instead of being rebuilt every knot from the uniform bases and
+// (b, t) in scalar registers: the kernel is short of scalar registers (65-113 spilled, each reload a v_readlane), not of vector ones.
+#ifndef EMPC_BWD_VPTR
+#define EMPC_BWD_VPTR 0
+#endif

@@ -15,12 +15,16 @@ declare -A V=(
   [r6m4]="-DEMPC_BWD_R4B=1 -DEMPC_BWD_SYMTILES=1 -DEMPC_BWD_GLDS=1 -DEMPC_BOX_LDS=1 -DEMPC_ANY_BALLOT=1 -DEMPC_BWD_MFMA4=1"
   [fuse]="-DEMPC_BWD_FUSE=1"
   [rcap]="-DEMPC_ROLL_CAP_LDS=1"
+  [vptr]="-DEMPC_BWD_VPTR=1"
+  [r6ofv]="-DEMPC_BWD_R4B=1 -DEMPC_BWD_SYMTILES=1 -DEMPC_BWD_GLDS=1 -DEMPC_BOX_LDS=1 -DEMPC_ANY_BALLOT=1 -DEMPC_BWD_OVERLAP=1 -DEMPC_BWD_FUSE=1 -DEMPC_BWD_VPTR=1"
   [r6of]="-DEMPC_BWD_R4B=1 -DEMPC_BWD_SYMTILES=1 -DEMPC_BWD_GLDS=1 -DEMPC_BOX_LDS=1 -DEMPC_ANY_BALLOT=1 -DEMPC_BWD_OVERLAP=1 -DEMPC_BWD_FUSE=1"
-  [all]="-DEMPC_BWD_R4B=1 -DEMPC_BWD_SYMTILES=1 -DEMPC_BWD_GLDS=1 -DEMPC_BOX_LDS=1 -DEMPC_ANY_BALLOT=1 -DEMPC_BWD_OVERLAP=1 -DEMPC_BWD_FUSE=1 -DEMPC_ROLL_CAP_LDS=1 -DEMPC_ROLL_GAP_EARLY"
+  [all]="-DEMPC_BWD_R4B=1 -DEMPC_BWD_SYMTILES=1 -DEMPC_BWD_GLDS=1 -DEMPC_BOX_LDS=1 -DEMPC_ANY_BALLOT=1 -DEMPC_BWD_OVERLAP=1 -DEMPC_BWD_FUSE=1 -DEMPC_BWD_VPTR=1 -DEMPC_ROLL_CAP_LDS=1 -DEMPC_ROLL_GAP_EARLY"
+  [stamps]="-DEMPC_STAMPS"
+  [stamps_r6of]="-DEMPC_STAMPS -DEMPC_BWD_R4B=1 -DEMPC_BWD_SYMTILES=1 -DEMPC_BWD_GLDS=1 -DEMPC_BOX_LDS=1 -DEMPC_ANY_BALLOT=1 -DEMPC_BWD_OVERLAP=1 -DEMPC_BWD_FUSE=1"
   [gap]="-DEMPC_ROLL_GAP_EARLY"
   [bits]="-DEMPC_FSQRT_BITS=1"
 )
-TAGS="${*:-r6 r6o r6of all r6m4 r4b sym glds boxlds mfma4 overlap fuse rcap}"
+TAGS="${*:-r6 r6o r6of r6ofv all r6m4 r4b sym glds boxlds mfma4 overlap fuse vptr rcap}"
 for t in $TAGS; do
   [ -n "${V[$t]:-}" ] || { echo "unknown variant $t"; exit 2; }
   echo "== $t: ${V[$t]}"

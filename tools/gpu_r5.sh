@@ -150,7 +150,7 @@ PY
     done
     for lib in $ROOT/eagle-mpc_amd/libempc_*.so; do
       v=$(basename $lib .so); v=${v#libempc_}
-      [ "$v" = stamps ] && continue
+      case "$v" in stamps*) continue;; esac
       if [ -n "${VARIANTS:-}" ] && ! echo " $VARIANTS " | grep -q " $v "; then continue; fi
       echo "=== variant $v ($(python3 tools/device_code_id.py $lib))"
       EMPC_LIB_PATH=$lib timeout 1500 python -m pytest $QT -q -m gpu -x 2>&1 | tail -6 | tee "gpurun_out/${TAG}_pytest_${v}.log"
@@ -174,7 +174,9 @@ PY
     # phase-level launches: product library first (ms per launch), then the diagnostic build with in-kernel cycle stamps
     for c in displacement eagle_catch; do
       echo "== $c (product)"; python3 tools/phase_bench.py --config $c --reps 3 2>&1 | grep -E "^\{"
-      echo "== $c (stamps build)"; EMPC_LIB_PATH="$ROOT/eagle-mpc_amd/libempc_stamps.so" python3 tools/phase_bench.py --config $c --reps 3 2>&1 | grep -E "^\{|stage|role"
+      for sl in $ROOT/eagle-mpc_amd/libempc_stamps*.so; do  # (libempc_stamps_<variant>.so: the same stamps inside a variant's kernels)
+        echo "== $c (stamps build $(basename $sl))"; EMPC_LIB_PATH="$sl" python3 tools/phase_bench.py --config $c --reps 3 2>&1 | grep -E "^\{|stage|role"
+      done
     done 2>&1 | tee "gpurun_out/${TAG}_stamps.log"
     ;;
   *)

@@ -11,8 +11,8 @@
 # A refused call (pool closed) ends the programme at once: no polling.
 set -uo pipefail
 cd "$(dirname "${BASH_SOURCE[0]}")/.."
-PHASES="${*:-check profiles experimental probes variants lines}"
-declare -A TMO=([check]=2400 [profiles]=3000 [experimental]=1200 [probes]=400 [variants]=5400 [lines]=1500)
+PHASES="${*:-check profiles experimental probes variants stamps lines}"
+declare -A TMO=([check]=2400 [profiles]=3000 [experimental]=1200 [probes]=400 [variants]=5400 [lines]=1500 [stamps]=900)
 for ph in $PHASES; do
   tag="r06_${ph}"
   echo "=== phase $ph (tag $tag, limit ${TMO[$ph]} s)"

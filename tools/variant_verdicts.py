@@ -32,12 +32,15 @@ VARIANTS = {
     "mfma4": (["EMPC_BWD_MFMA4=1"], "products on v_mfma_f64_4x4x4_4b", "same"),
     "overlap": (["EMPC_BWD_OVERLAP=1"], "Qxx tiles issued between the pieces of the LLT", "same"),
     "fuse": (["EMPC_BWD_FUSE=1"], "k, Quu k and the LLT's verdict as wave broadcasts instead of LDS hand-overs", "same"),
+    "vptr": (["EMPC_BWD_VPTR=1"], "output pointers per lane in vector registers (scalar-register relief)", "same"),
     "r6": (["EMPC_BWD_R4B=1", "EMPC_BWD_SYMTILES=1", "EMPC_BWD_GLDS=1", "EMPC_BOX_LDS=1", "EMPC_ANY_BALLOT=1"],
            "r4b + sym + glds + boxlds + ballot", "moves"),
     "r6o": (["EMPC_BWD_R4B=1", "EMPC_BWD_SYMTILES=1", "EMPC_BWD_GLDS=1", "EMPC_BOX_LDS=1", "EMPC_ANY_BALLOT=1", "EMPC_BWD_OVERLAP=1"],
             "r6 + overlap", "moves"),
     "r6of": (["EMPC_BWD_R4B=1", "EMPC_BWD_SYMTILES=1", "EMPC_BWD_GLDS=1", "EMPC_BOX_LDS=1", "EMPC_ANY_BALLOT=1", "EMPC_BWD_OVERLAP=1", "EMPC_BWD_FUSE=1"],
              "r6 + overlap + fuse", "moves"),
+    "r6ofv": (["EMPC_BWD_R4B=1", "EMPC_BWD_SYMTILES=1", "EMPC_BWD_GLDS=1", "EMPC_BOX_LDS=1", "EMPC_ANY_BALLOT=1", "EMPC_BWD_OVERLAP=1", "EMPC_BWD_FUSE=1",
+               "EMPC_BWD_VPTR=1"], "every backward variant on the 16 x 16 x 4 form", "moves"),
     "r6m4": (["EMPC_BWD_R4B=1", "EMPC_BWD_SYMTILES=1", "EMPC_BWD_GLDS=1", "EMPC_BOX_LDS=1", "EMPC_ANY_BALLOT=1", "EMPC_BWD_MFMA4=1"],
              "r6 + mfma4", "moves"),
 }
