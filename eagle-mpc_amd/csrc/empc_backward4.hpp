@@ -202,11 +202,19 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
           const int i = 16 * mt + 4 * r + lq, j = 16 * nt + lj;
           int idx = SM::GLDS ? SM::RB : SM::OFF_ZERO;  // (GLDS: offsets relative to the current record buffer, zero word behind it)
           if (i < n && j < nm)
+#if EMPC_REC_TRI
+            idx = (j < n) ? DM::lxx(i, j) : DM::lxu(i, j - n);
+#else
             idx = DM::OFF_HX + i * nm + j;
+#endif
           else if (i < n && j == nm)
             idx = DM::OFF_LX + i;
           else if (i >= n && i < nm && j >= n && j < nm)
+#if EMPC_REC_TRI
+            idx = DM::luu(i - n, j - n);
+#else
             idx = DM::OFF_LUU + (i - n) * m + (j - n);
+#endif
           else if (i >= n && i < nm && j == nm)
             idx = DM::OFF_LU + (i - n);
           hidx[sl][mt][nt][r] = idx;
@@ -257,7 +265,11 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
       const double* r = tape + (size_t)T * REC;
       ex.each([&](int lane, int sl) {
         for (int i = lane; i < n * n; i += NL)
+#if EMPC_REC_TRI
+          V[(i / n) * VS + (i % n)] = r[DM::lxx(i / n, i % n)] + (((i / n) == (i % n)) ? xreg : 0.0);
+#else
           V[(i / n) * VS + (i % n)] = r[DM::OFF_LXX + (i / n) * nm + (i % n)] + (((i / n) == (i % n)) ? xreg : 0.0);
+#endif
         if (lane < n) {
           vx[lane] = r[DM::OFF_LX + lane];
           red[64 + lane] = r[DM::OFF_GAP + lane];  // gap of node T

@@ -54,16 +54,53 @@ struct Dims {
   static constexpr int OFF_FX = OFF_A;                   // leading dimension NM
   static constexpr int OFF_FU = OFF_A + NDX;             // leading dimension NM
   static constexpr int OFF_HX = OFF_A + NDX * NM;
+  // the layout every record has outside the device (C ABI empc_tape_layout / empc_solver_get_tape, emulator API) and, with
+  // EMPC_REC_TRI off, on the device as well: [Lxx Lxu] n x (n+m) row-major | Luu m x m
+  static constexpr int FULL_LXX = OFF_HX, FULL_LXU = OFF_HX + NDX, FULL_LUU = OFF_HX + NDX * NM, FULL_LX = FULL_LUU + NU * NU;
+  static constexpr int FULL_LU = FULL_LX + NDX, FULL_GAP = FULL_LU + NU, FULL_COST = FULL_GAP + NDX;
+  static constexpr int REC_FULL = (FULL_COST + 1 + 15) / 16 * 16;
+#if EMPC_REC_TRI
+  // upper triangles: row i of the Hessian block is Lxx(i, i .. n-1) | Lxu(i, 0 .. m-1); Luu row i is Luu(i, i .. m-1)
+  static constexpr int hxrow(int i) { return OFF_HX + i * NM - i * (i - 1) / 2; }
+  static constexpr int lxx(int i, int j) { return (i <= j) ? hxrow(i) + (j - i) : hxrow(j) + (i - j); }
+  static constexpr int lxu(int i, int k) { return hxrow(i) + (NDX - i) + k; }
+  static constexpr int OFF_LUU = OFF_HX + NDX * (NDX + 1) / 2 + NDX * NU;
+  static constexpr int luu(int i, int k) { return (i <= k) ? OFF_LUU + i * NU - i * (i - 1) / 2 + (k - i) : OFF_LUU + k * NU - k * (k - 1) / 2 + (i - k); }
+  static constexpr int OFF_LX = OFF_LUU + NU * (NU + 1) / 2;  // ndx
+  static constexpr bool stored_xx(int i, int j) { return i <= j; }  // the writer of column j stores rows i <= j only
+#else
   static constexpr int OFF_LXX = OFF_HX;                 // leading dimension NM
   static constexpr int OFF_LXU = OFF_HX + NDX;           // leading dimension NM
   static constexpr int OFF_LUU = OFF_HX + NDX * NM;      // leading dimension NU
+  static constexpr int lxx(int i, int j) { return OFF_LXX + i * NM + j; }
+  static constexpr int lxu(int i, int k) { return OFF_LXU + i * NM + k; }
+  static constexpr int luu(int i, int k) { return OFF_LUU + i * NU + k; }
   static constexpr int OFF_LX = OFF_LUU + NU * NU;       // ndx
+  static constexpr bool stored_xx(int, int) { return true; }
+#endif
   static constexpr int OFF_LU = OFF_LX + NDX;            // nu
   static constexpr int OFF_GAP = OFF_LU + NU;            // ndx   fs[t]
   static constexpr int OFF_COST = OFF_GAP + NDX;         // 1
   static constexpr int REC_RAW = OFF_COST + 1;
   static constexpr int REC = (REC_RAW + 15) / 16 * 16;   // padded to 128 B
 };
+
+// one record from the device layout to the full layout (what it is outside the device); the same copy when EMPC_REC_TRI is off
+template <class DM>
+inline void unpack_record(const double* dev, double* full) {
+  for (int i = 0; i < DM::REC_FULL; ++i) full[i] = 0.0;
+  for (int i = 0; i < DM::NDX * DM::NM; ++i) full[DM::OFF_A + i] = dev[DM::OFF_A + i];
+  for (int i = 0; i < DM::NDX; ++i) {
+    for (int j = 0; j < DM::NDX; ++j) full[DM::FULL_LXX + i * DM::NM + j] = dev[DM::lxx(i, j)];
+    for (int k = 0; k < DM::NU; ++k) full[DM::FULL_LXU + i * DM::NM + k] = dev[DM::lxu(i, k)];
+  }
+  for (int i = 0; i < DM::NU; ++i)
+    for (int k = 0; k < DM::NU; ++k) full[DM::FULL_LUU + i * DM::NU + k] = dev[DM::luu(i, k)];
+  for (int i = 0; i < DM::NDX; ++i) full[DM::FULL_LX + i] = dev[DM::OFF_LX + i];
+  for (int i = 0; i < DM::NU; ++i) full[DM::FULL_LU + i] = dev[DM::OFF_LU + i];
+  for (int i = 0; i < DM::NDX; ++i) full[DM::FULL_GAP + i] = dev[DM::OFF_GAP + i];
+  full[DM::FULL_COST] = dev[DM::OFF_COST];
+}
 
 // view of a baked model: the tree constants are the static members of B; the operational frames a problem selects (cost
 // and contact frames, EmpcModelDesc::frame_*) stay in the problem image

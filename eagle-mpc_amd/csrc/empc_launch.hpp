@@ -34,7 +34,9 @@ struct KernelTable {
   void (*pack_rows)(DevBuffers, double*, hipStream_t);
   void (*plant)(DevBuffers, double*, const double*, double, int, hipStream_t);
   int nx, ndx, nu, nv, nacc, rec;
-  int off[9], ld[5];
+  int off[9], ld[5];  // the FULL layout: what a record looks like outside the device (empc_tape_layout)
+  int rec_full, dev_off_cost;  // EMPC_REC_TRI: `rec` is the device stride, records leave the device through `unpack` in rec_full doubles
+  void (*unpack)(const double*, double*);
 };
 
 
@@ -714,7 +716,10 @@ static KernelTable make_table() {
   k.nv = DM::NV;
   k.nacc = DM::NACC;
   k.rec = DM::REC;
-  const int off[9] = {DM::OFF_FX, DM::OFF_FU, DM::OFF_LXX, DM::OFF_LXU, DM::OFF_LUU, DM::OFF_LX, DM::OFF_LU, DM::OFF_GAP, DM::OFF_COST};
+  k.rec_full = DM::REC_FULL;
+  k.dev_off_cost = DM::OFF_COST;
+  k.unpack = unpack_record<DM>;
+  const int off[9] = {DM::OFF_FX, DM::OFF_FU, DM::FULL_LXX, DM::FULL_LXU, DM::FULL_LUU, DM::FULL_LX, DM::FULL_LU, DM::FULL_GAP, DM::FULL_COST};
   std::memcpy(k.off, off, sizeof(off));
   const int ld[5] = {DM::NM, DM::NM, DM::NM, DM::NM, DM::NU};  // Fx, Fu, Lxx, Lxu, Luu leading dimensions
   std::memcpy(k.ld, ld, sizeof(ld));

@@ -1472,27 +1472,30 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
     if (lane < NDX) {
       out[DM::OFF_LX + lane] = lx_l[sl] * cscale;
 #pragma unroll
-      for (int i = 0; i < NDX; ++i) out[DM::OFF_LXX + i * DM::NM + lane] = hx_l[sl][i] * cscale;
+      for (int i = 0; i < NDX; ++i)
+        if (DM::stored_xx(i, lane)) out[DM::lxx(i, lane)] = hx_l[sl][i] * cscale;  // (EMPC_REC_TRI: rows i <= lane of the column)
     }
     const int k = lane - 2 * NV;
     if (k >= 0 && k < NU && lane < lpu) {
       out[DM::OFF_LU + k] = lx_l[sl] * cscale;
 #pragma unroll
-      for (int i = 0; i < NU; ++i) out[DM::OFF_LUU + i * NU + k] = hx_l[sl][i] * cscale;
+      for (int i = 0; i < NU; ++i)
+        if (DM::stored_xx(i, k)) out[DM::luu(i, k)] = hx_l[sl][i] * cscale;
 #pragma unroll
       for (int i = 0; i < NDX; ++i) {
         double v_ = 0.0;
         if constexpr (CT) v_ = hxu_l[sl][i] * cscale;
-        out[DM::OFF_LXU + i * DM::NM + k] = v_;
+        out[DM::lxu(i, k)] = v_;
       }
     }
     if constexpr (FOLD) {
       if (lane == LXL) {  // the folded control column: Lu entry, column of Luu (diagonal entry only), column of Lxu (zeros)
         out[DM::OFF_LU + KX] = lux_l[sl] * cscale;
 #pragma unroll
-        for (int i = 0; i < NU; ++i) out[DM::OFF_LUU + i * NU + KX] = ((i == KX) ? luux_l[sl] : 0.0) * cscale;
+        for (int i = 0; i < NU; ++i)
+          if (DM::stored_xx(i, KX)) out[DM::luu(i, KX)] = ((i == KX) ? luux_l[sl] : 0.0) * cscale;
 #pragma unroll
-        for (int i = 0; i < NDX; ++i) out[DM::OFF_LXU + i * DM::NM + KX] = 0.0;
+        for (int i = 0; i < NDX; ++i) out[DM::lxu(i, KX)] = 0.0;
       }
     }
     if (lane == 0) out[DM::OFF_COST] = N[SM::OFF_RED] * cscale;

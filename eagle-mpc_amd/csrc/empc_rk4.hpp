@@ -271,7 +271,11 @@ EMPC_HD void rk4_assemble_unit(Exec& ex, const DevBuffers& D, const Rk4Buffers& 
 #pragma unroll
           for (int a = 0; a < MTX; ++a) {
             const int row = 16 * a + li;
+#if EMPC_REC_TRI
+            aB[buf][sl][a] = RAW[DM::lxx(row < n ? row : n - 1, (4 * ks + lq) < n ? 4 * ks + lq : n - 1)];  // (columns >= n: any finite value)
+#else
             aB[buf][sl][a] = RAW[DM::OFF_LXX + (row < n ? row : n - 1) * NM + 4 * ks + lq];
+#endif
           }
 #pragma unroll
           for (int c = 0; c < NT; ++c) bY[buf][sl][c] = DY[(4 * ks + lq) * LD + 16 * c + li];
@@ -310,7 +314,7 @@ EMPC_HD void rk4_assemble_unit(Exec& ex, const DevBuffers& D, const Rk4Buffers& 
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int row = 16 * a + 4 * r + lq;
-            if (row < n) Z[row * LD + col] = w * (accB[sl][a][c][r] + ((col >= n) ? RAW[DM::OFF_LXU + row * NM + col - n] : 0.0));
+            if (row < n) Z[row * LD + col] = w * (accB[sl][a][c][r] + ((col >= n) ? RAW[EMPC_REC_TRI ? DM::lxu(row, col - n) : DM::FULL_LXU + row * NM + col - n] : 0.0));
           }
       }
       for (int e = lane; e < nv * nm; e += nl) {
@@ -324,7 +328,7 @@ EMPC_HD void rk4_assemble_unit(Exec& ex, const DevBuffers& D, const Rk4Buffers& 
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int i = 16 * a + 4 * r + lq, j = 16 * c + lj;
-            if (i < m && j < m) accP[sl][a][c][r] += w * RAW[DM::OFF_LUU + i * m + j];
+            if (i < m && j < m) accP[sl][a][c][r] += w * RAW[EMPC_REC_TRI ? DM::luu(i, j) : DM::FULL_LUU + i * m + j];
           }
       if (lane < nm) {
         double v_ = (lane >= n) ? RAW[DM::OFF_LU + lane - n] : 0.0;
@@ -356,7 +360,7 @@ EMPC_HD void rk4_assemble_unit(Exec& ex, const DevBuffers& D, const Rk4Buffers& 
 #pragma unroll
           for (int c = 0; c < MTU; ++c) {
             const int u = 16 * c + li;
-            aX[buf][sl][c] = RAW[DM::OFF_LXU + (kr < n ? kr : n - 1) * NM + (u < m ? u : m - 1)];
+            aX[buf][sl][c] = RAW[EMPC_REC_TRI ? DM::lxu(kr < n ? kr : n - 1, u < m ? u : m - 1) : DM::FULL_LXU + (kr < n ? kr : n - 1) * NM + (u < m ? u : m - 1)];
             bU[buf][sl][c] = w * DY[kr * LD + n + (u < m ? u : m - 1)];
           }
         });
@@ -429,9 +433,16 @@ EMPC_HD void rk4_assemble_unit(Exec& ex, const DevBuffers& D, const Rk4Buffers& 
           for (int r = 0; r < 4; ++r) {
             const int row = 16 * a + 4 * r + lq, col = 16 * c + lj;
             const double v_ = accL[sl][a][c][r];
+#if EMPC_REC_TRI
+            if (row < n && col < n && DM::stored_xx(row, col)) out[DM::lxx(row, col)] = v_ * cscale;
+            if (row < n && col >= n && col < nm) out[DM::lxu(row, col - n)] = v_ * cscale;
+            if (row >= n && row < nm && col >= n && col < nm && DM::stored_xx(row - n, col - n))
+              out[DM::luu(row - n, col - n)] = (v_ + PT[(row - n) * PLD + col - n]) * cscale;
+#else
             if (row < n && col < nm) out[DM::OFF_HX + row * NM + col] = v_ * cscale;  // [Lxx Lxu], row-interleaved
             if (row >= n && row < nm && col >= n && col < nm)
               out[DM::OFF_LUU + (row - n) * m + col - n] = (v_ + PT[(row - n) * PLD + col - n]) * cscale;
+#endif
           }
       if (lane == 0) out[DM::OFF_COST] = (KK[5 * n] + 2.0 * KK[5 * n + 1] + 2.0 * KK[5 * n + 2] + KK[5 * n + 3]) * cscale;
       // gaps: fs[t+1] = xnext (-) xs[t+1];  fs[0] = x0 (-) xs[0]

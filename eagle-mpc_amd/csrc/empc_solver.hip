@@ -440,12 +440,12 @@ int empc_solver_dims(const EmpcSolver* s, int* batch, int* T, int* nx, int* ndx,
   if (nx) *nx = s->kt.nx;
   if (ndx) *ndx = s->kt.ndx;
   if (nu) *nu = s->kt.nu;
-  if (rec_doubles) *rec_doubles = s->kt.rec;
+  if (rec_doubles) *rec_doubles = s->kt.rec_full;
   return EMPC_OK;
 }
 int empc_tape_layout(const EmpcSolver* s, EmpcTapeLayout* l) {
   if (!s || !l) return EMPC_ERR_INVALID;
-  l->rec = s->kt.rec;
+  l->rec = s->kt.rec_full;
   l->off_fx = s->kt.off[0];
   l->off_fu = s->kt.off[1];
   l->off_lxx = s->kt.off[2];
@@ -1061,9 +1061,19 @@ int empc_solver_get_trials(EmpcSolver* s, double* try_cost, double* try_dv, int*
   return EMPC_OK;
   EMPC_CATCH(RET_INT)
 }
+// the device tape as the ABI describes it: records in the full layout (with EMPC_REC_TRI off the device layout is that layout)
+static int tape_out(EmpcSolver* s, double* tape) {
+  const size_t nrec = (size_t)s->B * (s->T + 1);
+  if (s->kt.rec == s->kt.rec_full) return copy_out_fwd(s, s->D.tape, tape, sizeof(double) * nrec * s->kt.rec);
+  std::vector<double> h(nrec * s->kt.rec);
+  const int rc = copy_out_fwd(s, s->D.tape, h.data(), sizeof(double) * h.size());
+  if (rc != EMPC_OK) return rc;
+  for (size_t i = 0; i < nrec; ++i) s->kt.unpack(h.data() + i * s->kt.rec, tape + i * s->kt.rec_full);
+  return EMPC_OK;
+}
 int empc_solver_get_tape(EmpcSolver* s, double* tape) {
   if (!s) return EMPC_ERR_INVALID;
-  return copy_out_fwd(s, s->D.tape, tape, sizeof(double) * (size_t)s->B * (s->T + 1) * s->kt.rec);
+  return tape_out(s, tape);
 }
 int empc_solver_get_gains(EmpcSolver* s, double* K, double* k, double* Vx) {
   if (!s) return EMPC_ERR_INVALID;
@@ -1237,15 +1247,15 @@ int empc_linearize_batch(EmpcSolver* s, const double* xs, const double* us, doub
   s->stats.linearize_units = (long long)s->B * (s->T + 1);
   const size_t n = (size_t)s->B * (s->T + 1) * s->kt.rec;
   if (tape) {
-    HIP_CHECK(hipMemcpyAsync(tape, s->D.tape, sizeof(double) * n, hipMemcpyDeviceToHost, s->stream));
-    HIP_CHECK(hipStreamSynchronize(s->stream));
+    const int rc = tape_out(s, tape);
+    if (rc != EMPC_OK) return rc;
   }
   if (cost) {
     std::vector<double> h(n);
     HIP_CHECK(hipMemcpy(h.data(), s->D.tape, sizeof(double) * n, hipMemcpyDeviceToHost));
     for (int b = 0; b < s->B; ++b) {
       double c = 0;
-      for (int t = 0; t <= s->T; ++t) c += h[((size_t)b * (s->T + 1) + t) * s->kt.rec + s->kt.off[8]];
+      for (int t = 0; t <= s->T; ++t) c += h[((size_t)b * (s->T + 1) + t) * s->kt.rec + s->kt.dev_off_cost];
       cost[b] = c;
     }
   }

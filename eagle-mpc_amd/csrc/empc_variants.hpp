@@ -89,3 +89,12 @@
 #ifndef EMPC_BWD_VPTR
 #define EMPC_BWD_VPTR 0
 #endif
+// tape record: Lxx and Luu stored as their upper triangles (row i of the Hessian block holds Lxx(i, i..n-1) | Lxu(i, :)): 1 104 -> 912
+// doubles per (trajectory, knot) on the 9-DoF arm, i.e. -17 % of the bytes linearize writes and the backward pass reads.  NOT a
+// pure layout change: linearize computes Lxx(i, j) and Lxx(j, i) in different lanes with different summation orders (asymmetry up
+// to 1e-13 measured), so mirroring the stored triangle moves the backward pass's inputs in the last bit.  The C ABI and the
+// emulator API keep handing out records in the full layout (unpacked on the way out).  (The "128-byte row padding inside a
+// record" VERDICT r05 asks to drop does not exist: a record is one flat block, padded by 5 doubles at its end.)
+#ifndef EMPC_REC_TRI
+#define EMPC_REC_TRI 0
+#endif

@@ -11,8 +11,10 @@
 
 #include "../../eagle-mpc_amd/csrc/empc_prep.hpp"
 #include "../../eagle-mpc_amd/csrc/empc_linearize2.hpp"
+#if !EMPC_REC_TRI  // (the retired generations read the full record layout: cross-checks of the default build only)
 #include "superseded/empc_backward2.hpp"
 #include "superseded/empc_backward3.hpp"
+#endif
 #include "superseded/empc_rollout5.hpp"
 #include "../../eagle-mpc_amd/csrc/empc_backward4.hpp"
 #include "../../eagle-mpc_amd/csrc/empc_rollout6.hpp"
@@ -141,7 +143,7 @@ struct Emu {
 template <class DM>
 static void emu_alloc(Emu& e) {
   const int B = e.B, T = e.T, NA = e.NA;
-  e.rec = DM::REC;
+  e.rec = DM::REC_FULL;  // what the API hands out (EMPC_REC_TRI: the device stride DM::REC is smaller)
   e.nx = DM::NX;
   e.ndx = DM::NDX;
   e.nu = DM::NU;
@@ -317,11 +319,13 @@ static void emu_linearize_view(Emu& e, const DevBuffers& Dl) {
 static int g_bwd_version = 2;
 template <class DM>
 static void emu_backward(Emu& e) {
+#if !EMPC_REC_TRI
   std::vector<double> smem(Bwd2Smem<DM>::SIZE);
   std::vector<double> smem3(Bwd3Smem<DM>::SIZE);
+#endif
   std::vector<double> smem4(Bwd4Smem<DM>::SIZE);
   for (int b = 0; b < e.B; ++b) {
-    if (g_bwd_version == 4 || e.H.P.prm.solver_type != EMPC_SOLVER_SBFDDP) {
+    if (g_bwd_version == 4 || e.H.P.prm.solver_type != EMPC_SOLVER_SBFDDP || EMPC_REC_TRI) {
       CpuExec<64> ex{64};
       if (e.H.P.prm.solver_type != EMPC_SOLVER_SBFDDP)
         backward_traj4<DM, true>(ex, e.D, b, smem4.data());
@@ -329,6 +333,7 @@ static void emu_backward(Emu& e) {
         backward_traj4<DM, false>(ex, e.D, b, smem4.data());  // the shipped form: matrix cores, zero-padded tiles
       continue;
     }
+#if !EMPC_REC_TRI
     if (g_bwd_version == 3) {
       CpuExec<64> ex{64};
       backward_traj3<DM>(ex, e.D, b, smem3.data());  // the shipped matrix-core form
@@ -341,6 +346,7 @@ static void emu_backward(Emu& e) {
       CpuExec<256> ex{64};
       backward_traj2<DM, 64>(ex, e.D, b, smem.data());   // the shipped single-wavefront configuration
     }
+#endif
   }
 }
 static int g_roll_version = 6;
@@ -552,6 +558,11 @@ static void emu_node(Emu& e, int t, const double* x, const double* u, double smo
   *cost = c;
 }
 
+template <class DM>
+static void emu_tape_out(Emu& e, double* tape) {
+  const size_t nrec = (size_t)e.B * (e.T + 1);
+  for (size_t i = 0; i < nrec; ++i) unpack_record<DM>(e.tape.data() + i * DM::REC, tape + i * DM::REC_FULL);
+}
 extern "C" {
 // IAM.calc of one node through the device code path (node_nominal: Euler or RK4 as the problem says)
 void emu_node_nominal(void* h, int t, const double* x, const double* u, double smooth, double* xnext, double* acc, double* cost,
@@ -639,7 +650,7 @@ void emu_phase_linearize(void* h, double* tape, double* acc) {
   Emu* e = static_cast<Emu*>(h);
   DISPATCH(e, emu_calc, *e);
   DISPATCH(e, emu_linearize, *e);
-  if (tape) std::memcpy(tape, e->tape.data(), sizeof(double) * (e->tape.size() - 128));
+  if (tape) DISPATCH(e, emu_tape_out, *e, tape);
   if (acc) {
     const int nacc = e->nv + 6;
     for (size_t u = 0; u < (size_t)e->B * (e->T + 1); ++u) std::memcpy(acc + u * e->nv, &e->acc[u * nacc], sizeof(double) * e->nv);
@@ -706,7 +717,7 @@ void emu_get_trials(void* h, double* cost, double* dv, int* ok) {
 }
 void emu_get_tape(void* h, double* tape) {
   Emu* e = static_cast<Emu*>(h);
-  std::memcpy(tape, e->tape.data(), sizeof(double) * (e->tape.size() - 128));
+  DISPATCH(e, emu_tape_out, *e, tape);
 }
 void emu_get_gains(void* h, double* K, double* k, double* Vx) {
   Emu* e = static_cast<Emu*>(h);

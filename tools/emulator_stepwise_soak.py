@@ -36,7 +36,8 @@ def main():
         x0s = empc.perturbed_x0s(problem.x0, n, nq=d.model.nq, seed=seed)
         rep = sw.stepwise_parity(lambda k, p2: sw.EmuBackend(emu, d, p2 if p2 is not None else prm, k), d, prm, x0s, chunk=64,
                                  tape_every=7, tight_maxiter=200, do_same_minimum=(name != "hover"))
-        row = {"workload": name, "seed": seed, "rollouts": n, "backend": "CPU lane emulator of the kernel bodies (tests/csrc/lane_emulator.cpp)"}
+        row = {"workload": name, "seed": seed, "rollouts": n, "backend": "CPU lane emulator of the kernel bodies (tests/csrc/lane_emulator.cpp)",
+               "variant_macros": os.environ.get("EMU_MACROS", "")}  # (EMU_MACROS: the soak of a build-time variant, empc_variants.hpp)
         row.update({k: v for k, v in rep.items() if k != "free_run"})
         row["free_run"] = {k: v for k, v in rep["free_run"].items() if k != "first_divergences"}
         ok = rep["decisions_checked"] == rep["pairs"] and rep["free_run"]["unexplained"] == 0
