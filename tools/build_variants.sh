@@ -3,6 +3,8 @@
 # csrc/empc_variants.hpp; ~3 minutes each with 8 cores).  bash tools/build_variants.sh [tag ...]    JOBS=6 by default
 set -uo pipefail
 cd "$(dirname "${BASH_SOURCE[0]}")/../eagle-mpc_amd"
+# every backward variant on the 16 x 16 x 4 form (the 4 x 4 x 4 form excludes the overlap variant)
+BWD="-DEMPC_BWD_R4B=1 -DEMPC_BWD_SYMTILES=1 -DEMPC_BWD_GLDS=1 -DEMPC_BOX_LDS=1 -DEMPC_ANY_BALLOT=1 -DEMPC_BWD_OVERLAP=1 -DEMPC_BWD_FUSE=1 -DEMPC_BWD_VPTR=1"
 declare -A V=(
   [r4b]="-DEMPC_BWD_R4B=1"
   [sym]="-DEMPC_BWD_SYMTILES=1"
@@ -10,21 +12,20 @@ declare -A V=(
   [boxlds]="-DEMPC_BOX_LDS=1"
   [mfma4]="-DEMPC_BWD_MFMA4=1"
   [overlap]="-DEMPC_BWD_OVERLAP=1"
-  [r6]="-DEMPC_BWD_R4B=1 -DEMPC_BWD_SYMTILES=1 -DEMPC_BWD_GLDS=1 -DEMPC_BOX_LDS=1 -DEMPC_ANY_BALLOT=1"
-  [r6o]="-DEMPC_BWD_R4B=1 -DEMPC_BWD_SYMTILES=1 -DEMPC_BWD_GLDS=1 -DEMPC_BOX_LDS=1 -DEMPC_ANY_BALLOT=1 -DEMPC_BWD_OVERLAP=1"
-  [r6m4]="-DEMPC_BWD_R4B=1 -DEMPC_BWD_SYMTILES=1 -DEMPC_BWD_GLDS=1 -DEMPC_BOX_LDS=1 -DEMPC_ANY_BALLOT=1 -DEMPC_BWD_MFMA4=1"
   [fuse]="-DEMPC_BWD_FUSE=1"
-  [rcap]="-DEMPC_ROLL_CAP_LDS=1"
   [vptr]="-DEMPC_BWD_VPTR=1"
-  [r6ofv]="-DEMPC_BWD_R4B=1 -DEMPC_BWD_SYMTILES=1 -DEMPC_BWD_GLDS=1 -DEMPC_BOX_LDS=1 -DEMPC_ANY_BALLOT=1 -DEMPC_BWD_OVERLAP=1 -DEMPC_BWD_FUSE=1 -DEMPC_BWD_VPTR=1"
-  [r6of]="-DEMPC_BWD_R4B=1 -DEMPC_BWD_SYMTILES=1 -DEMPC_BWD_GLDS=1 -DEMPC_BOX_LDS=1 -DEMPC_ANY_BALLOT=1 -DEMPC_BWD_OVERLAP=1 -DEMPC_BWD_FUSE=1"
-  [all]="-DEMPC_BWD_R4B=1 -DEMPC_BWD_SYMTILES=1 -DEMPC_BWD_GLDS=1 -DEMPC_BOX_LDS=1 -DEMPC_ANY_BALLOT=1 -DEMPC_BWD_OVERLAP=1 -DEMPC_BWD_FUSE=1 -DEMPC_BWD_VPTR=1 -DEMPC_ROLL_CAP_LDS=1 -DEMPC_ROLL_GAP_EARLY"
-  [stamps]="-DEMPC_STAMPS"
-  [stamps_r6of]="-DEMPC_STAMPS -DEMPC_BWD_R4B=1 -DEMPC_BWD_SYMTILES=1 -DEMPC_BWD_GLDS=1 -DEMPC_BOX_LDS=1 -DEMPC_ANY_BALLOT=1 -DEMPC_BWD_OVERLAP=1 -DEMPC_BWD_FUSE=1"
+  [rcap]="-DEMPC_ROLL_CAP_LDS=1"
+  [tri]="-DEMPC_REC_TRI=1"
   [gap]="-DEMPC_ROLL_GAP_EARLY"
   [bits]="-DEMPC_FSQRT_BITS=1"
+  [bwd]="$BWD"
+  [bwdm4]="-DEMPC_BWD_R4B=1 -DEMPC_BWD_SYMTILES=1 -DEMPC_BWD_GLDS=1 -DEMPC_BOX_LDS=1 -DEMPC_ANY_BALLOT=1 -DEMPC_BWD_FUSE=1 -DEMPC_BWD_VPTR=1 -DEMPC_BWD_MFMA4=1"
+  [all]="$BWD -DEMPC_ROLL_CAP_LDS=1 -DEMPC_ROLL_GAP_EARLY"
+  [alltri]="$BWD -DEMPC_ROLL_CAP_LDS=1 -DEMPC_ROLL_GAP_EARLY -DEMPC_REC_TRI=1"
+  [stamps]="-DEMPC_STAMPS"
+  [stamps_bwd]="-DEMPC_STAMPS $BWD"
 )
-TAGS="${*:-r6 r6o r6of r6ofv all r6m4 r4b sym glds boxlds mfma4 overlap fuse vptr rcap}"
+TAGS="${*:-bwd bwdm4 all alltri r4b sym glds boxlds mfma4 overlap fuse vptr rcap tri gap bits stamps stamps_bwd}"
 for t in $TAGS; do
   [ -n "${V[$t]:-}" ] || { echo "unknown variant $t"; exit 2; }
   echo "== $t: ${V[$t]}"

@@ -23,6 +23,8 @@ import isa_loop_profile as ilp
 import kernel_resources as kr
 
 # tag -> (macros, what, arithmetic)
+BWD = ["EMPC_BWD_R4B=1", "EMPC_BWD_SYMTILES=1", "EMPC_BWD_GLDS=1", "EMPC_BOX_LDS=1", "EMPC_ANY_BALLOT=1", "EMPC_BWD_OVERLAP=1", "EMPC_BWD_FUSE=1",
+       "EMPC_BWD_VPTR=1"]
 VARIANTS = {
     "default": ([], "the shipped build (every switch 0)", "-"),
     "r4b": (["EMPC_BWD_R4B=1"], "round-4 late changes: triangle symmetrisation, 16-byte record moves", "same"),
@@ -33,16 +35,10 @@ VARIANTS = {
     "overlap": (["EMPC_BWD_OVERLAP=1"], "Qxx tiles issued between the pieces of the LLT", "same"),
     "fuse": (["EMPC_BWD_FUSE=1"], "k, Quu k and the LLT's verdict as wave broadcasts instead of LDS hand-overs", "same"),
     "vptr": (["EMPC_BWD_VPTR=1"], "output pointers per lane in vector registers (scalar-register relief)", "same"),
-    "r6": (["EMPC_BWD_R4B=1", "EMPC_BWD_SYMTILES=1", "EMPC_BWD_GLDS=1", "EMPC_BOX_LDS=1", "EMPC_ANY_BALLOT=1"],
-           "r4b + sym + glds + boxlds + ballot", "moves"),
-    "r6o": (["EMPC_BWD_R4B=1", "EMPC_BWD_SYMTILES=1", "EMPC_BWD_GLDS=1", "EMPC_BOX_LDS=1", "EMPC_ANY_BALLOT=1", "EMPC_BWD_OVERLAP=1"],
-            "r6 + overlap", "moves"),
-    "r6of": (["EMPC_BWD_R4B=1", "EMPC_BWD_SYMTILES=1", "EMPC_BWD_GLDS=1", "EMPC_BOX_LDS=1", "EMPC_ANY_BALLOT=1", "EMPC_BWD_OVERLAP=1", "EMPC_BWD_FUSE=1"],
-             "r6 + overlap + fuse", "moves"),
-    "r6ofv": (["EMPC_BWD_R4B=1", "EMPC_BWD_SYMTILES=1", "EMPC_BWD_GLDS=1", "EMPC_BOX_LDS=1", "EMPC_ANY_BALLOT=1", "EMPC_BWD_OVERLAP=1", "EMPC_BWD_FUSE=1",
-               "EMPC_BWD_VPTR=1"], "every backward variant on the 16 x 16 x 4 form", "moves"),
-    "r6m4": (["EMPC_BWD_R4B=1", "EMPC_BWD_SYMTILES=1", "EMPC_BWD_GLDS=1", "EMPC_BOX_LDS=1", "EMPC_ANY_BALLOT=1", "EMPC_BWD_MFMA4=1"],
-             "r6 + mfma4", "moves"),
+    "tri": (["EMPC_REC_TRI=1"], "Lxx / Luu as upper triangles in the record (1104 -> 912 doubles)", "moves"),
+    "bwd": (BWD, "every backward variant on the 16 x 16 x 4 form", "moves"),
+    "bwdm4": ([m for m in BWD if "OVERLAP" not in m] + ["EMPC_BWD_MFMA4=1"], "every backward variant on the 4 x 4 x 4 form (no overlap)", "moves"),
+    "alltri": (BWD + ["EMPC_ROLL_CAP_LDS=1", "EMPC_ROLL_GAP_EARLY=1", "EMPC_REC_TRI=1"], "everything", "moves"),
 }
 KERNELS = [("9-DoF", "Dims<4, 6, RuntimeModel>, false>", "4, 6, empc::RuntimeModel>, false"),
            ("9-DoF box", "Dims<4, 6, RuntimeModel>, true>", "4, 6, empc::RuntimeModel>, true"),
