@@ -332,11 +332,18 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
 #if EMPC_BWD_VPTR
     // this lane's slots of knot T - 1 (the first knot flushed); every flush steps them back one knot.  Pinned: opaque per-lane values
     // stay in vector registers and their increments are vector adds.
-    double *pK[Exec::SLOTS], *pVf[Exec::SLOTS], *pVx[Exec::SLOTS];
+    // (global address space stated: a pointer that went through the pin is generic to the compiler, and a FLAT store counts on
+    //  the LDS counter as well -- every later wait for an LDS read would wait for it)
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(1))) double* GPtr;
+#else
+    typedef double* GPtr;
+#endif
+    GPtr pK[Exec::SLOTS], pVf[Exec::SLOTS], pVx[Exec::SLOTS];
     ex.each([&](int lane, int sl) {
-      pK[sl] = (lane == n) ? D.kff + ((size_t)b * T + (T - 1)) * m : D.K + ((size_t)b * T + (T - 1)) * m * n + (lane < n ? lane : 0);
-      pVf[sl] = D.Vf + ((size_t)b * (T + 1) + (T - 1)) * n + (lane < n ? lane : 0);
-      pVx[sl] = D.Vx + ((size_t)b * (T + 1) + (T - 1)) * n + (lane < n ? lane : 0);
+      pK[sl] = (GPtr)((lane == n) ? D.kff + ((size_t)b * T + (T - 1)) * m : D.K + ((size_t)b * T + (T - 1)) * m * n + (lane < n ? lane : 0));
+      pVf[sl] = (GPtr)(D.Vf + ((size_t)b * (T + 1) + (T - 1)) * n + (lane < n ? lane : 0));
+      pVx[sl] = (GPtr)(D.Vx + ((size_t)b * (T + 1) + (T - 1)) * n + (lane < n ? lane : 0));
       BWD_PIN(pK[sl]);
       BWD_PIN(pVf[sl]);
       BWD_PIN(pVx[sl]);

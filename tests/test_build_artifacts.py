@@ -96,3 +96,55 @@ def test_nan_guards_survive_the_nan_free_build_of_the_baked_units():
             checked += 1
             with_guards += nb > 0
     assert checked >= 12 and with_guards >= 6, (checked, with_guards)
+
+
+def test_no_flat_memory_instructions_in_any_kernel():
+    """Every global access of the kernels is a global_* (or scalar) instruction.  A FLAT load / store -- what the compiler emits when
+    a pointer lost its address space, e.g. after passing through an inline-asm operand -- also counts on the LDS counter, so every
+    later wait for an LDS read waits for it: found in round 6 in a variant of the backward pass (EMPC_BWD_VPTR), where 64 flat
+    stores per knot pair would have sat in front of every `s_waitcnt lgkmcnt`.  Checked on all shipped objects and, when the variant
+    harness compiles (hipcc present), on the backward kernels with every variant switch on."""
+    import tempfile
+    LLVM = "/opt/rocm/lib/llvm/bin"
+    objs = sorted(glob.glob(os.path.join(OBJ, "empc_*.o")))
+    if not objs or not os.path.isfile(LLVM + "/llvm-objdump"):
+        pytest.skip("built objects or the LLVM tools are missing")
+
+    def flat_by_function(obj):
+        """{function symbol: number of flat_* instructions} of the gfx950 code object inside `obj` (empty: no device code)"""
+        with tempfile.TemporaryDirectory() as d:
+            fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "k.co")
+            if subprocess.run([LLVM + "/llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, obj, os.path.join(d, "copy.o")], capture_output=True).returncode != 0:
+                return {}
+            subprocess.run([LLVM + "/clang-offload-bundler", "--unbundle", "--type=o", "--input=" + fat, "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                            "--output=" + co], check=True)
+            txt = subprocess.run("%s/llvm-objdump -d %s | grep -E '^[0-9a-f]+ <|^\\s+flat_'" % (LLVM, co), shell=True, capture_output=True, text=True).stdout
+        out, cur = {}, None
+        for line in txt.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+            if m:
+                cur = m.group(1)
+            elif cur is not None:
+                out[cur] = out.get(cur, 0) + 1
+        return out
+
+    bad = {}
+    for o in objs:
+        for name, n in flat_by_function(o).items():
+            bad[os.path.basename(o) + ":" + name[:60]] = n
+    # Known exception, found by this very test and left alone (the default device code is locked to the hardware-verified one): in
+    # the RUNTIME-MODEL family of the 11-DoF class a lambda of linearize_unit2 is not inlined (a called function: generic pointers,
+    # 42 flat accesses).  The shipped 11-DoF robot runs the baked family (empc_inst_baked_arm5.o: clean); to be fixed with the next
+    # hardware run (force-inline + a new manifest).
+    known = {k: v for k, v in bad.items() if k.startswith("empc_inst_6_6")
+             and "linearize_unit2" in k and v == 42}
+    bad = {k: v for k, v in bad.items() if k not in known}
+    assert not bad, bad
+    if not os.path.isfile("/opt/rocm/bin/hipcc"):
+        return
+    import variant_verdicts as vv
+    with tempfile.TemporaryDirectory() as d:
+        for tag in ("bwd", "bwdm4"):
+            obj = os.path.join(d, tag + ".o")
+            vv.compile_harness(vv.VARIANTS[tag][0], obj)
+            assert not flat_by_function(obj), (tag, flat_by_function(obj))

@@ -99,6 +99,8 @@ def knot_loop(obj, want):
                 mix["accvgpr"] = mix.get("accvgpr", 0) + 1
             if op.startswith("scratch_"):
                 mix["scratch"] = mix.get("scratch", 0) + 1
+            if op.startswith("flat_"):
+                mix["flat"] = mix.get("flat", 0) + 1
         mix["total"] = b - a + 1
         return mix
     return None
@@ -161,7 +163,7 @@ def write_md(out, res, verdicts, static_only):
     L.append("v_mfma_f64_16x16x4 64 cycles, a v_mfma_f64_4x4x4_4b 16 (to be measured: tools/probes/mfma_f64_4x4_probe.hip).\n")
     for label, _, _ in KERNELS:
         L.append("## %s: `k_backward4`\n" % label)
-        L.append("| variant | macros | VGPR | AGPR | spilled VGPR | spilled SGPR | scratch B | knot loop | fp64 | mfma | lds | valu other (accvgpr) | salu | vmem (scratch) | wait |")
+        L.append("| variant | macros | VGPR | AGPR | spilled VGPR | spilled SGPR | scratch B | knot loop | fp64 | mfma | lds | valu other (accvgpr) | salu | vmem (scratch, flat) | wait |")
         L.append("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
         for tag, e in res.items():
             k = e["kernels"][label]
@@ -169,10 +171,10 @@ def write_md(out, res, verdicts, static_only):
             if r is None or m is None:
                 continue
             f = lambda x: ("%g" % x)
-            L.append("| %s | %s | %d | %d | %d | %d | %d | %s | %s | %s | %s | %s (%s) | %s | %s (%s) | %s |" % (
+            L.append("| %s | %s | %d | %d | %d | %d | %d | %s | %s | %s | %s | %s (%s) | %s | %s (%s, %s) | %s |" % (
                 tag, " ".join(x.replace("EMPC_", "").replace("=1", "") for x in e["macros"]) or "-", r["vgpr"], r["agpr"], r["vgpr_spill"], r["sgpr_spill"], r["scratch"],
                 f(m["total"]), f(m.get("fp64", 0)), f(m.get("mfma", 0)), f(m.get("lds", 0)), f(m.get("valu_other", 0)), f(m.get("accvgpr", 0)),
-                f(m.get("salu", 0)), f(m.get("vmem", 0)), f(m.get("scratch", 0)), f(m.get("wait", 0))))
+                f(m.get("salu", 0)), f(m.get("vmem", 0)), f(m.get("scratch", 0)), f(m.get("flat", 0)), f(m.get("wait", 0))))
         L.append("")
     if verdicts:
         L.append("## CPU verdicts (lane emulator)\n")
