@@ -228,21 +228,52 @@ __global__ void __launch_bounds__(BLK) EMPC_LIN_ATTR k_linearize_all(DevBuffers 
 #define EMPC_GLDS_HEAD "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_mov_b64 %2, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
 #define EMPC_GLDS_NEXT "v_lshl_add_u64 %1, %1, 0, %2\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
 #define EMPC_GLDS_TAIL "s_mov_b32 m0, %0"
+#define EMPC_GLDS_R0 ""
+#define EMPC_GLDS_R1 EMPC_GLDS_R0 EMPC_GLDS_NEXT
+#define EMPC_GLDS_R2 EMPC_GLDS_R1 EMPC_GLDS_NEXT
+#define EMPC_GLDS_R3 EMPC_GLDS_R2 EMPC_GLDS_NEXT
+#define EMPC_GLDS_R4 EMPC_GLDS_R3 EMPC_GLDS_NEXT
+#define EMPC_GLDS_R5 EMPC_GLDS_R4 EMPC_GLDS_NEXT
+#define EMPC_GLDS_R6 EMPC_GLDS_R5 EMPC_GLDS_NEXT
+#define EMPC_GLDS_R7 EMPC_GLDS_R6 EMPC_GLDS_NEXT
+#define EMPC_GLDS_R8 EMPC_GLDS_R7 EMPC_GLDS_NEXT
+#define EMPC_GLDS_R9 EMPC_GLDS_R8 EMPC_GLDS_NEXT
+#define EMPC_GLDS_R10 EMPC_GLDS_R9 EMPC_GLDS_NEXT
+#define EMPC_GLDS_R11 EMPC_GLDS_R10 EMPC_GLDS_NEXT
+#define EMPC_GLDS_R12 EMPC_GLDS_R11 EMPC_GLDS_NEXT
 template <int ROWS>
 __device__ __forceinline__ void glds_rows(double* dst, const double* src_lane) {
-  static_assert(ROWS == 4 || ROWS == 7 || ROWS == 9, "record sizes of the robot classes this variant is built for");
+  static_assert(ROWS >= 1 && ROWS <= 13, "pieces of 1 KiB per record (9 for the 9-DoF arm, 8 with EMPC_REC_TRI)");
   const double* g = src_lane;
   const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)dst);
   unsigned keep;
   unsigned long long inc;
-#define N3 EMPC_GLDS_NEXT EMPC_GLDS_NEXT EMPC_GLDS_NEXT
-  if constexpr (ROWS == 4)
-    asm volatile(EMPC_GLDS_HEAD N3 EMPC_GLDS_TAIL : "=&s"(keep), "+v"(g), "=&s"(inc) : "s"(l) : "memory", "scc");
+  if constexpr (ROWS == 1)
+    asm volatile(EMPC_GLDS_HEAD EMPC_GLDS_R0 EMPC_GLDS_TAIL : "=&s"(keep), "+v"(g), "=&s"(inc) : "s"(l) : "memory", "scc");
+  else if constexpr (ROWS == 2)
+    asm volatile(EMPC_GLDS_HEAD EMPC_GLDS_R1 EMPC_GLDS_TAIL : "=&s"(keep), "+v"(g), "=&s"(inc) : "s"(l) : "memory", "scc");
+  else if constexpr (ROWS == 3)
+    asm volatile(EMPC_GLDS_HEAD EMPC_GLDS_R2 EMPC_GLDS_TAIL : "=&s"(keep), "+v"(g), "=&s"(inc) : "s"(l) : "memory", "scc");
+  else if constexpr (ROWS == 4)
+    asm volatile(EMPC_GLDS_HEAD EMPC_GLDS_R3 EMPC_GLDS_TAIL : "=&s"(keep), "+v"(g), "=&s"(inc) : "s"(l) : "memory", "scc");
+  else if constexpr (ROWS == 5)
+    asm volatile(EMPC_GLDS_HEAD EMPC_GLDS_R4 EMPC_GLDS_TAIL : "=&s"(keep), "+v"(g), "=&s"(inc) : "s"(l) : "memory", "scc");
+  else if constexpr (ROWS == 6)
+    asm volatile(EMPC_GLDS_HEAD EMPC_GLDS_R5 EMPC_GLDS_TAIL : "=&s"(keep), "+v"(g), "=&s"(inc) : "s"(l) : "memory", "scc");
   else if constexpr (ROWS == 7)
-    asm volatile(EMPC_GLDS_HEAD N3 N3 EMPC_GLDS_TAIL : "=&s"(keep), "+v"(g), "=&s"(inc) : "s"(l) : "memory", "scc");
-  else
-    asm volatile(EMPC_GLDS_HEAD N3 N3 EMPC_GLDS_NEXT EMPC_GLDS_NEXT EMPC_GLDS_TAIL : "=&s"(keep), "+v"(g), "=&s"(inc) : "s"(l) : "memory", "scc");
-#undef N3
+    asm volatile(EMPC_GLDS_HEAD EMPC_GLDS_R6 EMPC_GLDS_TAIL : "=&s"(keep), "+v"(g), "=&s"(inc) : "s"(l) : "memory", "scc");
+  else if constexpr (ROWS == 8)
+    asm volatile(EMPC_GLDS_HEAD EMPC_GLDS_R7 EMPC_GLDS_TAIL : "=&s"(keep), "+v"(g), "=&s"(inc) : "s"(l) : "memory", "scc");
+  else if constexpr (ROWS == 9)
+    asm volatile(EMPC_GLDS_HEAD EMPC_GLDS_R8 EMPC_GLDS_TAIL : "=&s"(keep), "+v"(g), "=&s"(inc) : "s"(l) : "memory", "scc");
+  else if constexpr (ROWS == 10)
+    asm volatile(EMPC_GLDS_HEAD EMPC_GLDS_R9 EMPC_GLDS_TAIL : "=&s"(keep), "+v"(g), "=&s"(inc) : "s"(l) : "memory", "scc");
+  else if constexpr (ROWS == 11)
+    asm volatile(EMPC_GLDS_HEAD EMPC_GLDS_R10 EMPC_GLDS_TAIL : "=&s"(keep), "+v"(g), "=&s"(inc) : "s"(l) : "memory", "scc");
+  else if constexpr (ROWS == 12)
+    asm volatile(EMPC_GLDS_HEAD EMPC_GLDS_R11 EMPC_GLDS_TAIL : "=&s"(keep), "+v"(g), "=&s"(inc) : "s"(l) : "memory", "scc");
+  else if constexpr (ROWS == 13)
+    asm volatile(EMPC_GLDS_HEAD EMPC_GLDS_R12 EMPC_GLDS_TAIL : "=&s"(keep), "+v"(g), "=&s"(inc) : "s"(l) : "memory", "scc");
 }
 
 struct BlockExec {
