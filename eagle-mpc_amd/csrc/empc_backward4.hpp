@@ -447,27 +447,43 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
 #pragma unroll
             for (int r = 0; r < 4; ++r) accW[sl][mt][nt][r] = 0.0;
       });
-#if EMPC_BWD_OVERLAP && !EMPC_BWD_MFMA4
+#if EMPC_BWD_OVERLAP
       // EMPC_BWD_OVERLAP.  NTX column tiles lie wholly left of column n ("x tiles": Qxx | Qux); the others ("u tiles") hold Qxu | Quu |
-      // Qx, Qu.  Phase 1: W and Q restricted to the u tiles -> LDS.  Phase 2: the x tiles, one instruction after each of the 3 m
-      // pieces of computeGains (m Cholesky columns, m rows forward, m rows backward); what is left of either list runs at the end.
+      // Qx, Qu.  Phase 1: W and Q restricted to the u tiles -> LDS.  Phase 2: the x tiles, PER_PIECE instructions after each of the
+      // 3 m pieces of computeGains (m Cholesky columns, m rows forward, m rows backward); what is left of either list runs at the end.
+      // A operands per k step: one per 16-row tile (16 x 16 x 4 form) or one per 4-row group (EMPC_BWD_MFMA4: the group's rows in
+      // every block, instructions of 16 instead of 64 cycles -- two per piece).
       constexpr int NTX = n / 16;
+#if EMPC_BWD_MFMA4
+      constexpr int AW = SM::RGN, AQ = SM::RGQ, PER_PIECE = 2;
+#else
+      constexpr int AW = MTN, AQ = MTQ, PER_PIECE = 1;
+#endif
       if constexpr (!BOX && NTX > 0) {
-        auto loadW = [&](double (&aop)[2][Exec::SLOTS][MTN], double (&bop)[2][Exec::SLOTS][NTQ], int ks, int buf, int nt0, int nt1) {
+        auto a_row = [](int a_, int li) { return EMPC_BWD_MFMA4 ? 4 * a_ + li % 4 : 16 * a_ + li; };  // row of A operand a_ held by lane column li
+        auto skipped = [](int a_, int nt) { return EMPC_BWD_MFMA4 ? SM::group_skipped(a_, nt) : SM::tile_skipped(a_, nt); };
+        auto product = [&](auto& aop, int a_, auto& bop, int nt, auto& acc) {
+#if EMPC_BWD_MFMA4
+          ex.mfma4(aop, a_, bop, nt, acc, a_ / 4, nt, a_ % 4);
+#else
+          ex.mfma(aop, a_, bop, nt, acc, a_, nt);
+#endif
+        };
+        auto loadW = [&](double (&aop)[2][Exec::SLOTS][AW], double (&bop)[2][Exec::SLOTS][NTQ], int ks, int buf, int nt0, int nt1) {
           ex.each([&](int lane, int sl) {
             const int li = lane % 16, lq = lane / 16;
 #pragma unroll
-            for (int mt = 0; mt < MTN; ++mt) aop[buf][sl][mt] = V[(16 * mt + li) * VS + 4 * ks + lq];
+            for (int a_ = 0; a_ < AW; ++a_) aop[buf][sl][a_] = V[a_row(a_, li) * VS + 4 * ks + lq];
 #pragma unroll
             for (int nt = 0; nt < NTQ; ++nt)
               if (nt >= nt0 && nt < nt1) bop[buf][sl][nt] = rec[DM::OFF_A + (4 * ks + lq) * nm + 16 * nt + li];
           });
         };
-        auto loadQ = [&](double (&aop)[2][Exec::SLOTS][MTQ], double (&bop)[2][Exec::SLOTS][NTQ], int ks, int buf, int nt0, int nt1) {
+        auto loadQ = [&](double (&aop)[2][Exec::SLOTS][AQ], double (&bop)[2][Exec::SLOTS][NTQ], int ks, int buf, int nt0, int nt1) {
           ex.each([&](int lane, int sl) {
             const int li = lane % 16, lq = lane / 16;
 #pragma unroll
-            for (int mt = 0; mt < MTQ; ++mt) aop[buf][sl][mt] = rec[DM::OFF_A + (4 * ks + lq) * nm + 16 * mt + li];
+            for (int a_ = 0; a_ < AQ; ++a_) aop[buf][sl][a_] = rec[DM::OFF_A + (4 * ks + lq) * nm + a_row(a_, li)];
             const double vxk = vx[4 * ks + lq];
 #pragma unroll
             for (int nt = 0; nt < NTQ; ++nt)
@@ -476,28 +492,28 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
         };
         // ---- phase 1: u tiles ----------------------------------------------------------------------------------------
         {
-          double aopW[2][Exec::SLOTS][MTN], bopW[2][Exec::SLOTS][NTQ];
+          double aopW[2][Exec::SLOTS][AW], bopW[2][Exec::SLOTS][NTQ];
           loadW(aopW, bopW, 0, 0, NTX, NTQ);
 #pragma unroll
           for (int ks = 0; ks < KSN; ++ks) {
             if (ks + 1 < KSN) loadW(aopW, bopW, ks + 1, (ks + 1) & 1, NTX, NTQ);
 #pragma unroll
-            for (int mt = 0; mt < MTN; ++mt)
+            for (int a_ = 0; a_ < AW; ++a_)
 #pragma unroll
-              for (int nt = NTX; nt < NTQ; ++nt) ex.mfma(aopW[ks & 1], mt, bopW[ks & 1], nt, accW, mt, nt);
+              for (int nt = NTX; nt < NTQ; ++nt) product(aopW[ks & 1], a_, bopW[ks & 1], nt, accW);
           }
         }
         {
-          double aopQ[2][Exec::SLOTS][MTQ], bopQ[2][Exec::SLOTS][NTQ];
+          double aopQ[2][Exec::SLOTS][AQ], bopQ[2][Exec::SLOTS][NTQ];
           loadQ(aopQ, bopQ, 0, 0, NTX, NTQ);
 #pragma unroll
           for (int ks = 0; ks < KSN; ++ks) {
             if (ks + 1 < KSN) loadQ(aopQ, bopQ, ks + 1, (ks + 1) & 1, NTX, NTQ);
 #pragma unroll
-            for (int mt = 0; mt < MTQ; ++mt)
+            for (int a_ = 0; a_ < AQ; ++a_)
 #pragma unroll
               for (int nt = NTX; nt < NTQ; ++nt)
-                if (!SM::tile_skipped(mt, nt)) ex.mfma(aopQ[ks & 1], mt, bopQ[ks & 1], nt, accQ, mt, nt);
+                if (!skipped(a_, nt)) product(aopQ[ks & 1], a_, bopQ[ks & 1], nt, accQ);
           }
         }
         ex.each([&](int lane, int sl) {
@@ -581,34 +597,35 @@ EMPC_HD void backward_traj4(Exec& ex, const DevBuffers& D, int b, double* smem) 
           });
         };
         int pc = 0;  // next piece (a compile-time constant at every use once the loops below are unrolled)
+        int issued = 0;
         {
-          double aopW[2][Exec::SLOTS][MTN], bopW[2][Exec::SLOTS][NTQ];
+          double aopW[2][Exec::SLOTS][AW], bopW[2][Exec::SLOTS][NTQ];
           loadW(aopW, bopW, 0, 0, 0, NTX);
 #pragma unroll
           for (int ks = 0; ks < KSN; ++ks) {
             if (ks + 1 < KSN) loadW(aopW, bopW, ks + 1, (ks + 1) & 1, 0, NTX);
 #pragma unroll
-            for (int mt = 0; mt < MTN; ++mt)
+            for (int a_ = 0; a_ < AW; ++a_)
 #pragma unroll
               for (int nt = 0; nt < NTX; ++nt) {
-                ex.mfma(aopW[ks & 1], mt, bopW[ks & 1], nt, accW, mt, nt);
-                if (pc < 3 * m) piece(pc++);
+                product(aopW[ks & 1], a_, bopW[ks & 1], nt, accW);
+                if (++issued % PER_PIECE == 0 && pc < 3 * m) piece(pc++);
               }
           }
         }
         {
-          double aopQ[2][Exec::SLOTS][MTQ], bopQ[2][Exec::SLOTS][NTQ];
+          double aopQ[2][Exec::SLOTS][AQ], bopQ[2][Exec::SLOTS][NTQ];
           loadQ(aopQ, bopQ, 0, 0, 0, NTX);
 #pragma unroll
           for (int ks = 0; ks < KSN; ++ks) {
             if (ks + 1 < KSN) loadQ(aopQ, bopQ, ks + 1, (ks + 1) & 1, 0, NTX);
 #pragma unroll
-            for (int mt = 0; mt < MTQ; ++mt)
+            for (int a_ = 0; a_ < AQ; ++a_)
 #pragma unroll
               for (int nt = 0; nt < NTX; ++nt)
-                if (!SM::tile_skipped(mt, nt)) {
-                  ex.mfma(aopQ[ks & 1], mt, bopQ[ks & 1], nt, accQ, mt, nt);
-                  if (pc < 3 * m) piece(pc++);
+                if (!skipped(a_, nt)) {
+                  product(aopQ[ks & 1], a_, bopQ[ks & 1], nt, accQ);
+                  if (++issued % PER_PIECE == 0 && pc < 3 * m) piece(pc++);
                 }
           }
         }

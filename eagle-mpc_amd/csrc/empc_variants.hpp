@@ -65,7 +65,7 @@
 // all that computeGains reads), then, BETWEEN the column steps of the Cholesky factorisation and the rows of the two substitutions,
 // one matrix-core instruction at a time, the tiles that only feed Qxx (needed by the Vxx update afterwards).  The matrix pipe
 // (64 cycles per instruction) then runs under the ~400 vector instructions of the LLT instead of in front of them.  Same
-// operations on the same operands: bit-identical.  Squash-box instantiations of the 16 x 16 x 4 form only (not BOX, not MFMA4).
+// operations on the same operands: bit-identical.  Squash-box instantiations (not BOX); with EMPC_BWD_MFMA4 two instructions per piece.
 #ifndef EMPC_BWD_OVERLAP
 #define EMPC_BWD_OVERLAP 0
 #endif

@@ -3,7 +3,7 @@
 # csrc/empc_variants.hpp; ~3 minutes each with 8 cores).  bash tools/build_variants.sh [tag ...]    JOBS=6 by default
 set -uo pipefail
 cd "$(dirname "${BASH_SOURCE[0]}")/../eagle-mpc_amd"
-# every backward variant on the 16 x 16 x 4 form (the 4 x 4 x 4 form excludes the overlap variant)
+# every backward variant on the 16 x 16 x 4 form; bwdm4: the same on the 4 x 4 x 4 form
 BWD="-DEMPC_BWD_R4B=1 -DEMPC_BWD_SYMTILES=1 -DEMPC_BWD_GLDS=1 -DEMPC_BOX_LDS=1 -DEMPC_ANY_BALLOT=1 -DEMPC_BWD_OVERLAP=1 -DEMPC_BWD_FUSE=1 -DEMPC_BWD_VPTR=1"
 declare -A V=(
   [r4b]="-DEMPC_BWD_R4B=1"
@@ -19,7 +19,7 @@ declare -A V=(
   [gap]="-DEMPC_ROLL_GAP_EARLY"
   [bits]="-DEMPC_FSQRT_BITS=1"
   [bwd]="$BWD"
-  [bwdm4]="-DEMPC_BWD_R4B=1 -DEMPC_BWD_SYMTILES=1 -DEMPC_BWD_GLDS=1 -DEMPC_BOX_LDS=1 -DEMPC_ANY_BALLOT=1 -DEMPC_BWD_FUSE=1 -DEMPC_BWD_VPTR=1 -DEMPC_BWD_MFMA4=1"
+  [bwdm4]="$BWD -DEMPC_BWD_MFMA4=1"
   [all]="$BWD -DEMPC_ROLL_CAP_LDS=1 -DEMPC_ROLL_GAP_EARLY"
   [alltri]="$BWD -DEMPC_ROLL_CAP_LDS=1 -DEMPC_ROLL_GAP_EARLY -DEMPC_REC_TRI=1"
   [stamps]="-DEMPC_STAMPS"

@@ -37,7 +37,7 @@ VARIANTS = {
     "vptr": (["EMPC_BWD_VPTR=1"], "output pointers per lane in vector registers (scalar-register relief)", "same"),
     "tri": (["EMPC_REC_TRI=1"], "Lxx / Luu as upper triangles in the record (1104 -> 912 doubles)", "moves"),
     "bwd": (BWD, "every backward variant on the 16 x 16 x 4 form", "moves"),
-    "bwdm4": ([m for m in BWD if "OVERLAP" not in m] + ["EMPC_BWD_MFMA4=1"], "every backward variant on the 4 x 4 x 4 form (no overlap)", "moves"),
+    "bwdm4": (BWD + ["EMPC_BWD_MFMA4=1"], "every backward variant on the 4 x 4 x 4 form", "moves"),
     "alltri": (BWD + ["EMPC_ROLL_CAP_LDS=1", "EMPC_ROLL_GAP_EARLY=1", "EMPC_REC_TRI=1"], "everything", "moves"),
 }
 KERNELS = [("9-DoF", "Dims<4, 6, RuntimeModel>, false>", "4, 6, empc::RuntimeModel>, false"),
