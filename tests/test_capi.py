@@ -45,3 +45,21 @@ def test_product_does_not_touch_oracle():
                     if re.search(r'#include\s*[<"][^>"]*oracle|import\s+oracle|from\s+oracle|liboracle|oracle_binding|CDLL\([^)]*oracle', txt):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_variant_libraries_export_the_same_abi():
+    """Every prebuilt variant library (eagle-mpc_amd/libempc_<tag>.so, tools/build_variants.sh; loaded through EMPC_LIB_PATH by
+    `tools/gpu_r5.sh variants`) exports every symbol of include/empc.h: a library left over from before an ABI addition fails here,
+    not on a GPU slot (found in round 6: three round-5 libraries lacked empc_solver_device_info)."""
+    import glob
+    libs = sorted(glob.glob(os.path.join(ROOT, "eagle-mpc_amd", "libempc_*.so")))
+    if not libs:
+        pytest.skip("no variant library built (bash tools/build_variants.sh)")
+    names = declared_symbols()
+    stale = {}
+    for lib in libs:
+        L = C.CDLL(lib)
+        missing = [n for n in names if not hasattr(L, n)]
+        if missing:
+            stale[os.path.basename(lib)] = missing
+    assert not stale, stale
