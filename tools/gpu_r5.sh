@@ -151,7 +151,7 @@ PY
     for lib in $ROOT/eagle-mpc_amd/libempc_*.so; do
       v=$(basename $lib .so); v=${v#libempc_}
       case "$v" in stamps*) continue;; esac
-      if [ -n "${VARIANTS:-}" ] && ! echo " $VARIANTS " | grep -q " $v "; then continue; fi
+      if [ -n "${VARIANTS:-}" ] && ! echo " ${VARIANTS//,/ } " | grep -q " $v "; then continue; fi  # (VARIANTS=bwd,all: a comma list survives the gpurun command line)
       echo "=== variant $v ($(python3 tools/device_code_id.py $lib))"
       EMPC_LIB_PATH=$lib timeout 1500 python -m pytest $QT -q -m gpu -x 2>&1 | tail -6 | tee "gpurun_out/${TAG}_pytest_${v}.log"
       for cfg in ${CONFIGS:-eagle_catch displacement push_slide}; do

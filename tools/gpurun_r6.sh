@@ -16,7 +16,9 @@ declare -A TMO=([check]=2400 [profiles]=3000 [experimental]=1200 [probes]=400 [v
 for ph in $PHASES; do
   tag="r06_${ph}"
   echo "=== phase $ph (tag $tag, limit ${TMO[$ph]} s)"
-  bash tools/gpurun_r5.sh "$ph" "$tag" "${TMO[$ph]}"; rc=$?
+  # the variants phase: the four combinations first (one hour); the single switches (attribution) only when asked: VARIANTS=... in the environment
+  extra=""; [ "$ph" = variants ] && extra="VARIANTS=${VARIANTS:-bwd,bwdm4,all,alltri}"
+  bash tools/gpurun_r5.sh "$ph" "$tag" "${TMO[$ph]}" $extra; rc=$?
   if grep -q "status=refused" "gpurun_out/${tag}_call.log" 2>/dev/null; then
     echo "pool closed (gpurun_out/${tag}_call.log): stopping"; exit 2
   fi
