@@ -57,7 +57,7 @@ def variants():
     import tempfile
     from conftest import arm5_contact_variant, contact_variant, mixed_contact_variant, small_class_contact_variant
     n, seed = int(sys.argv[2]), int(sys.argv[3])
-    out = os.path.join(ROOT, "profiles", "r05_stepwise_emulator_soak.jsonl")
+    out = sys.argv[4] if len(sys.argv) > 4 else os.path.join(ROOT, "profiles", "r05_stepwise_emulator_soak.jsonl")
     emu = sw.load_emulator()
     tmp = pathlib.Path(tempfile.mkdtemp())
     tr = empc.Trajectory()
@@ -78,7 +78,8 @@ def variants():
         prm.solver_type = st
         x0s = empc.perturbed_x0s(problem.x0, n, nq=d.model.nq, amplitude=0.02, seed=seed)
         rep = sw.stepwise_parity(lambda k, p2: sw.EmuBackend(emu, d, p2 if p2 is not None else prm, k), d, prm, x0s, chunk=64, tape_every=13, **kw)
-        row = {"workload": tag, "seed": seed, "rollouts": n, "backend": "CPU lane emulator of the kernel bodies (tests/csrc/lane_emulator.cpp)"}
+        row = {"workload": tag, "seed": seed, "rollouts": n, "backend": "CPU lane emulator of the kernel bodies (tests/csrc/lane_emulator.cpp)",
+               "variant_macros": os.environ.get("EMU_MACROS", "")}
         row.update({k: v for k, v in rep.items() if k != "free_run"})
         row["free_run"] = {k: v for k, v in rep["free_run"].items() if k != "first_divergences"}
         ok = rep["decisions_checked"] == rep["pairs"] and rep["free_run"]["unexplained"] == 0
