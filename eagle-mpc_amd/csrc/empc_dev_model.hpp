@@ -191,6 +191,13 @@ constexpr int NCAP = 2;
 // contact rows of a kernel instantiation (template parameter CT / NC): 0 free dynamics, 3 ContactModel3D, 6 ContactModel6D,
 // CT_MIXED a problem whose stages use both (the bodies of 3 and 6 behind a uniform branch on the node's contact type)
 constexpr int CT_MIXED = 9;
+// CT_PAIR3 a problem with a stage whose ContactModelMultiple holds TWO ContactModel3D contacts (src/stage.cpp:38-48 adds every
+// name of the stage's list; crocoddyl stacks their rows in the order of its name-sorted map = the order of set.contacts[]): six
+// stacked rows, contact 0 in rows 0-2, contact 1 in rows 3-5, one KKT system.  Stages of the same problem with ONE ContactModel3D
+// run the 3-row body behind a uniform branch on the node's contact count.  Opt-in (EMPC_EXPERIMENTAL_CONTACT), never run on a GPU.
+constexpr int CT_PAIR3 = 33;
+// constraint rows a kernel instantiation reserves room for
+constexpr int ct_rows(int CT) { return (CT == CT_MIXED || CT == CT_PAIR3) ? 6 : CT; }
 template <class S>
 struct FrameCap {
   S R[9], p[3];  // world placement
@@ -869,6 +876,137 @@ EMPC_HD void contact_forward(const MT& m, const ContactT& ct, const FrameCap<dou
     for (int i = 0; i < NV; ++i) a[i] += MiJt[r][i] * lam[r];
 }
 
+// Two ContactModel3D contacts of one stage (CT_PAIR3): [M Jc^T; Jc 0][a; -lam] = [tau - h; -a0] with Jc = [JcA; JcB] (rows of
+// contact 0 first), a0 likewise; lam[0..2] = LOCAL force of contact 0, lam[3..5] of contact 1.  Same steps as contact_forward<DM, 3>
+// per contact -- drift = classical acceleration of the contact point + Baumgarte terms, LOCAL linear Jacobian from the kinematics --
+// with the walk along the chain (joint axes and origins in the world frame) shared by the two frames.
+template <class DM, class ContactT, class MT>
+EMPC_HD void contact_forward_pair3(const MT& m, const ContactT& ctA, const ContactT& ctB, const FrameCap<double>& ckA,
+                                   const FrameCap<double>& ckB, const double* R0, const double* q, const double* cs,
+                                   const double* sn, const double* L, double* a, double* lam) {
+  constexpr int NV = DM::NV;
+  constexpr int nc = 6;
+  double ng[3] = {-m.gravity[0], -m.gravity[1], -m.gravity[2]}, a0[nc];
+  {
+    double gf[3], wxv[3];
+    matTvec3<double>(ckA.R, ng, gf);
+    cross3<double>(ckA.v + 3, ckA.v, wxv);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) a0[r] = (ckA.a[r] - gf[r]) + wxv[r];
+    if (ctA.gains[0] != 0.0)
+#pragma unroll
+      for (int r = 0; r < 3; ++r) a0[r] += ctA.gains[0] * (ckA.p[r] - ctA.ref_p[r]);
+    if (ctA.gains[1] != 0.0)
+#pragma unroll
+      for (int r = 0; r < 3; ++r) a0[r] += ctA.gains[1] * ckA.v[r];
+  }
+  {
+    double gf[3], wxv[3];
+    matTvec3<double>(ckB.R, ng, gf);
+    cross3<double>(ckB.v + 3, ckB.v, wxv);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) a0[3 + r] = (ckB.a[r] - gf[r]) + wxv[r];
+    if (ctB.gains[0] != 0.0)
+#pragma unroll
+      for (int r = 0; r < 3; ++r) a0[3 + r] += ctB.gains[0] * (ckB.p[r] - ctB.ref_p[r]);
+    if (ctB.gains[1] != 0.0)
+#pragma unroll
+      for (int r = 0; r < 3; ++r) a0[3 + r] += ctB.gains[1] * ckB.v[r];
+  }
+  double Jc[nc][NV], MiJt[nc][NV];
+  {
+    const int bfA = m.frame_body[ctA.frame], bfB = m.frame_body[ctB.frame];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      double w[3] = {R0[j], R0[3 + j], R0[6 + j]}, linA[3], linB[3];
+      matTvec3<double>(ckA.R, w, linA);
+      matTvec3<double>(ckB.R, w, linB);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        Jc[r][j] = linA[r];
+        Jc[3 + r][j] = linB[r];
+      }
+    }
+    double Rw[9], pw[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Rw[i] = R0[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) pw[i] = q[i];
+#pragma unroll
+    for (int j = 3; j < NV; ++j) {
+      double z[3];
+      bool onA = true, onB = true;
+      if (j < 6) {
+        z[0] = R0[j - 3];
+        z[1] = R0[3 + j - 3];
+        z[2] = R0[6 + j - 3];
+      } else {
+        const int b = j - 6 + 1;
+        double Rj[9], XR[9], Rr[3], Rn[9];
+        axis_rot<double>(m.axis[b], cs[b - 1], sn[b - 1], Rj);
+        matmul3<double>(m.jplace_R[b], Rj, XR);
+        matvec3<double>(Rw, m.jplace_p[b], Rr);
+        matmul3<double>(Rw, XR, Rn);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Rw[i] = Rn[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) pw[i] += Rr[i];
+        double ax[3] = {m.axis[b][0], m.axis[b][1], m.axis[b][2]};
+        matvec3<double>(Rw, ax, z);
+        onA = (b <= bfA);
+        onB = (b <= bfB);
+      }
+      double dA[3] = {ckA.p[0] - pw[0], ckA.p[1] - pw[1], ckA.p[2] - pw[2]}, dB[3] = {ckB.p[0] - pw[0], ckB.p[1] - pw[1], ckB.p[2] - pw[2]};
+      double zxd[3], lin[3];
+      cross3<double>(z, dA, zxd);
+      matTvec3<double>(ckA.R, zxd, lin);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) Jc[r][j] = onA ? lin[r] : 0.0;
+      cross3<double>(z, dB, zxd);
+      matTvec3<double>(ckB.R, zxd, lin);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) Jc[3 + r][j] = onB ? lin[r] : 0.0;
+    }
+  }
+  double G[nc * (nc + 1) / 2];  // packed nc x nc
+#pragma unroll
+  for (int r = 0; r < nc; ++r) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) MiJt[r][i] = Jc[r][i];
+    chol_solve_packed<NV>(L, MiJt[r]);
+  }
+#pragma unroll
+  for (int r = 0; r < nc; ++r)
+#pragma unroll
+    for (int c = 0; c <= r; ++c) {
+      double g = 0;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) g += Jc[r][i] * MiJt[c][i];
+      G[r * (r + 1) / 2 + c] = g;
+    }
+  chol_packed<nc>(G);
+#pragma unroll
+  for (int r = 0; r < nc; ++r) {
+    double g = a0[r];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) g += Jc[r][i] * a[i];
+    lam[r] = -g;
+  }
+  chol_solve_packed<nc>(G, lam);
+#pragma unroll
+  for (int r = 0; r < nc; ++r)
+#pragma unroll
+    for (int i = 0; i < NV; ++i) a[i] += MiJt[r][i] * lam[r];
+}
+// row offset of the contact whose force a ContactFrictionCone cost on frame `cframe` reads (crocoddyl's residual data looks the
+// contact up by frame id): 3 when the stage has two contacts and the second one sits on that frame, 0 otherwise (a stage with
+// one contact keeps that contact whatever the cost's frame says -- behaviour of rounds 1-5, and of the oracle)
+template <int CT, class SetT>
+EMPC_HD int cone_force_offset(const SetT& set, int cframe) {
+  if constexpr (CT == CT_PAIR3) return (set.ncontacts > 1 && set.contacts[1].frame == cframe) ? 3 : 0;
+  return 0;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Nominal evaluation of one node by ONE lane (used by the per-lane rollout and the calc kernels), in two layers:
 //   dam_nominal   DifferentialActionModel{Free,Contact}FwdDynamics::calc(x, s): acceleration, contact force, cost sum
@@ -1003,6 +1141,26 @@ EMPC_HD void dam_nominal(const EMPC_K DevProblem& P, const SetT& set, double smo
       }
     }
   }
+  int ccap2 = 0;  // CT_PAIR3: capture slot of the stage's second contact frame
+  if constexpr (CT == CT_PAIR3) {
+    if (use_contact && set.ncontacts > 1) {
+      const int cframe2 = set.contacts[1].frame;
+      bool seen = false;
+#pragma unroll
+      for (int k = 0; k < NCAP; ++k)
+        if (k < ncap && capf[k] == cframe2) {
+          seen = true;
+          ccap2 = k;
+        }
+      if (!seen) {
+#pragma unroll
+        for (int k = 0; k < NCAP; ++k)
+          if (k == ncap) capf[k] = cframe2;
+        ccap2 = ncap;
+        ncap = (ncap < NCAP) ? ncap + 1 : ncap;
+      }
+    }
+  }
   FrameCap<double> caps[NCAP];
   EMPC_STAMP(1);  // squash, tau, quaternion, joint sin/cos, frame scan
   // bias forces h = RNEA(q, v, 0)
@@ -1071,7 +1229,19 @@ EMPC_HD void dam_nominal(const EMPC_K DevProblem& P, const SetT& set, double smo
 #pragma unroll
     for (int kk = 1; kk < NCAP; ++kk)
       if (kk == ccap) ck = caps[kk];
-    contact_forward<DM, CT>(m, set.contacts[0], ck, R0, q, cs, sn, L, a, lam);
+    if constexpr (CT == CT_PAIR3) {
+      if (set.ncontacts > 1) {
+        FrameCap<double> ck2 = caps[0];
+#pragma unroll
+        for (int kk = 1; kk < NCAP; ++kk)
+          if (kk == ccap2) ck2 = caps[kk];
+        contact_forward_pair3<DM>(m, set.contacts[0], set.contacts[1], ck, ck2, R0, q, cs, sn, L, a, lam);
+      } else {
+        contact_forward<DM, 3>(m, set.contacts[0], ck, R0, q, cs, sn, L, a, lam);
+      }
+    } else {
+      contact_forward<DM, CT>(m, set.contacts[0], ck, R0, q, cs, sn, L, a, lam);
+    }
   }
 #pragma unroll
   for (int i = 0; i < NV; ++i) acc[i] = a[i];
@@ -1096,9 +1266,17 @@ EMPC_HD void dam_nominal(const EMPC_K DevProblem& P, const SetT& set, double smo
     const auto& c = set.costs[ci];
     if (!c.active || c.type != EMPC_COST_CONTACT_FRICTION_CONE) continue;
     double r[6] = {0, 0, 0, 0, 0, 0};  // rows of A R_n^T precomputed by prepare_problem in ref[4..18]
+    double lc[3] = {lam[0], lam[1], lam[2]};  // force of the contact the cost reads (selects, not a run-time index)
+    if constexpr (CT == CT_PAIR3) {
+      if (cone_force_offset<CT>(set, c.frame) != 0) {
+        lc[0] = lam[3];
+        lc[1] = lam[4];
+        lc[2] = lam[5];
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 5; ++i)
-      r[i] = use_contact ? (c.ref[4 + 3 * i] * lam[0] + c.ref[5 + 3 * i] * lam[1] + c.ref[6 + 3 * i] * lam[2]) : 0.0;
+      r[i] = use_contact ? (c.ref[4 + 3 * i] * lc[0] + c.ref[5 + 3 * i] * lc[1] + c.ref[6 + 3 * i] * lc[2]) : 0.0;
     ell += c.weight * activation_value<6>(c, r, 5);
   }
   ell += ell_frames;

@@ -56,6 +56,8 @@ KernelTable empc_table_6_6();
 KernelTable empc_table_6_6_contact();
 KernelTable empc_table_6_6_contact6();
 KernelTable empc_table_6_6_contact_mixed();  // (opt-in: EMPC_EXPERIMENTAL_CONTACT)
+KernelTable empc_table_4_6_contact_pair();   // two ContactModel3D per stage (CT_PAIR3; opt-in: EMPC_EXPERIMENTAL_CONTACT)
+KernelTable empc_table_6_6_contact_pair();
 // instantiations over the baked constants of a shipped robot (csrc/baked/, tools/bake_models.py): picked by find_table when
 // the problem's model and platform equal the baked tables bit for bit
 KernelTable empc_table_baked_arm3();
@@ -132,6 +134,11 @@ __device__ __forceinline__ int knot_contact_rows(const DevBuffers& D, int t) {
   const EMPC_K EmpcCostSet& set = EMPC_KPTR(EmpcCostSet, D.sets)[EMPC_KPTR(int, D.knot_set)[t]];
   return (set.ncontacts > 0 && set.contacts[0].type == EMPC_CONTACT_6D) ? 6 : 3;
 }
+// CT_PAIR3 problems: does knot t hold two contacts (the six-row body) or one ContactModel3D / none (the three-row body)
+__device__ __forceinline__ bool knot_contact_pair(const DevBuffers& D, int t) {
+  const EMPC_K EmpcCostSet& set = EMPC_KPTR(EmpcCostSet, D.sets)[EMPC_KPTR(int, D.knot_set)[t]];
+  return set.ncontacts > 1;
+}
 template <class DM, int CT, int LPU, int BLK, bool FR>
 // Two wavefronts per SIMD: at the compiler's own choice (326 registers, one wavefront per SIMD) the kernel sits at
 // ~1 resident wave per SIMD with 37 % of its time in waits; capping the budget at 256 registers costs ~250 spilled
@@ -184,6 +191,12 @@ __device__ __forceinline__ void lin_block(const DevBuffers& D, const int block, 
         linearize_unit2<DM, 6, FR, LaneExec, RW>(ex, D, b, t, LPU, smem_lin + (size_t)u * USZ, &R);
       else
         linearize_unit2<DM, 3, FR, LaneExec, RW>(ex, D, b, t, LPU, smem_lin + (size_t)u * USZ, &R);
+    } else if constexpr (CT == CT_PAIR3) {
+      // (the same argument: one knot per block, so the number of its contacts is uniform over the workgroup)
+      if (knot_contact_pair(D, t))
+        linearize_unit2<DM, CT_PAIR3, FR, LaneExec, RW>(ex, D, b, t, LPU, smem_lin + (size_t)u * USZ, &R);
+      else
+        linearize_unit2<DM, 3, FR, LaneExec, RW>(ex, D, b, t, LPU, smem_lin + (size_t)u * USZ, &R);
     } else
       linearize_unit2<DM, CT, FR, LaneExec, RW>(ex, D, b, t, LPU, smem_lin + (size_t)u * USZ, &R);
   } else {
@@ -191,6 +204,11 @@ __device__ __forceinline__ void lin_block(const DevBuffers& D, const int block, 
     if constexpr (CT == CT_MIXED) {
       if (knot_contact_rows(D, t) == 6)
         linearize_unit2<DM, 6, FR>(ex, D, b, t, LPU, smem_lin + (size_t)u * USZ);
+      else
+        linearize_unit2<DM, 3, FR>(ex, D, b, t, LPU, smem_lin + (size_t)u * USZ);
+    } else if constexpr (CT == CT_PAIR3) {
+      if (knot_contact_pair(D, t))
+        linearize_unit2<DM, CT_PAIR3, FR>(ex, D, b, t, LPU, smem_lin + (size_t)u * USZ);
       else
         linearize_unit2<DM, 3, FR>(ex, D, b, t, LPU, smem_lin + (size_t)u * USZ);
     } else
@@ -697,7 +715,7 @@ static void launch_rollout(DevBuffers D, hipStream_t s) {
   if (version == 1 || D.NA > MAX_ALPHAS) {  // > 16 step lengths: the per-lane form
     hipLaunchKernelGGL((k_rollout<DM, CT>), dim3((n + 63) / 64), dim3(64), 0, s, D);
   } else {
-    const size_t smem = sizeof(double) * Roll6Smem<DM>::SIZE;
+    const size_t smem = sizeof(double) * Roll6Smem<DM>::size_for(CT);
     static const bool once = [&] {  // more than 64 KB of dynamic LDS needs the opt-in
       (void)hipFuncSetAttribute((const void*)k_rollout6<DM, CT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
       (void)hipFuncSetAttribute((const void*)k_rollout6<DM, CT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);

@@ -56,8 +56,12 @@ struct Lin2Smem {
   static constexpr int OFF_JC = OFF_CONE + 26;
   static constexpr int off_mij(int nc) { return OFF_JC + nc * NV; }
   static constexpr int off_g(int nc) { return OFF_JC + 2 * nc * NV; }
-  static constexpr int size_for(int nc) { return nc == 0 ? SIZE_NC : (nc == CT_MIXED ? size_for(6) : (off_g(nc) + nc * (nc + 1) / 2 + 1) / 2 * 2); }
-  static constexpr int SIZE = (OFF_JC + 12 * NV + 21 + 1) / 2 * 2;  // the largest unit (six rows)
+  static constexpr int size_for(int nc) {
+    return nc == 0 ? SIZE_NC : (nc == CT_MIXED ? size_for(6) : (nc == CT_PAIR3 ? size_for(6) + 6 : (off_g(nc) + nc * (nc + 1) / 2 + 1) / 2 * 2));
+  }
+  // CT_PAIR3 (two ContactModel3D of one stage): the spatial force of the second contact on ITS body, behind the six-row unit
+  static constexpr int OFF_FEXT2 = (OFF_JC + 12 * NV + 21 + 1) / 2 * 2;
+  static constexpr int SIZE = OFF_FEXT2 + 6;  // the largest unit (six rows + the second contact's force)
   static constexpr int SIZE_NC = (OFF_LAM + 1) / 2 * 2;  // problems without contacts never touch the contact block
 };
 
@@ -81,7 +85,7 @@ constexpr int lin_lanes_per_unit() {
 
 // forward kinematics + nominal Newton-Euler quantities of one unit, executed by ONE lane
 template <class DM, class MT>
-EMPC_HD void lin2_nominal_chain(const MT& m, double* N, int cbody = -1) {
+EMPC_HD void lin2_nominal_chain(const MT& m, double* N, int cbody = -1, int cbody2 = -1) {
   typedef Lin2Smem<DM> SM;
   constexpr int NB = DM::NB, NQ = DM::NQ, NX = DM::NX;
   const double* x = N + SM::OFF_X;
@@ -216,6 +220,14 @@ EMPC_HD void lin2_nominal_chain(const MT& m, double* N, int cbody = -1) {
 #pragma unroll
       for (int i = 0; i < 6; ++i) Bb[SM::B_FS + i] -= N[SM::OFF_FEXT + i];
     }
+  // (CT_PAIR3: the second contact of the stage, on body `cbody2` -- possibly the same body)
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+    if (b == cbody2) {
+      double* Bb = N + SM::OFF_BODY + b * SM::BODY;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) Bb[SM::B_FS + i] -= N[SM::OFF_FEXT2 + i];
+    }
   // subtree forces
 #pragma unroll
   for (int b = NB - 1; b >= 1; --b) {
@@ -260,7 +272,8 @@ EMPC_HD void lin2_dforce(const MT& m, int b, const double* Bb, const double* dv,
 // of the body carrying captured frame c.
 template <class DM, class MT>
 EMPC_HD void lin2_tangent(const MT& m, const double* N, int lane, double* dtau, int ncap,
-                          const int* capf, double (*capdv)[6], int cbody = -1, double* capda = nullptr) {
+                          const int* capf, double (*capdv)[6], int cbody = -1, double* capda = nullptr, int cbody2 = -1,
+                          double* capda2 = nullptr) {
   typedef Lin2Smem<DM> SM;
   constexpr int NB = DM::NB, NV = DM::NV, NQ = DM::NQ, NX = DM::NX;
   const double* x = N + SM::OFF_X;
@@ -291,6 +304,10 @@ EMPC_HD void lin2_tangent(const MT& m, const double* N, int lane, double* dtau, 
   if (cbody == 0 && capda) {
 #pragma unroll
     for (int i = 0; i < 6; ++i) capda[i] = da[i];
+  }
+  if (cbody2 == 0 && capda2) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) capda2[i] = da[i];
   }
   lin2_dforce<DM>(m, 0, N + SM::OFF_BODY, dv, da, df[0]);
 #pragma unroll
@@ -354,6 +371,10 @@ EMPC_HD void lin2_tangent(const MT& m, const double* N, int lane, double* dtau, 
     if (cbody == b && capda) {
 #pragma unroll
       for (int i = 0; i < 6; ++i) capda[i] = da[i];
+    }
+    if (cbody2 == b && capda2) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) capda2[i] = da[i];
     }
     lin2_dforce<DM>(m, b, Bb, dv, da, df[b]);
   }
@@ -514,7 +535,7 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
   }
 
   // contact of this node: CT = 3 (ContactModel3D) or 6 (ContactModel6D) constraint rows, fixed per kernel instantiation
-  constexpr int NCR = CT ? CT : 3;
+  constexpr int NCR = CT ? ct_rows(CT) : 3;
   constexpr int OFF_MIJ = SM::off_mij(NCR), OFF_G = SM::off_g(NCR);
   const bool use_contact = FR && CT && P.has_contact && set.ncontacts > 0;
   int cframe = -1, cbody = -1, ccap = 0;
@@ -536,6 +557,29 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
       ncap = (ncap < NCAP) ? ncap + 1 : ncap;
     }
   }
+  // CT_PAIR3: the stage's second ContactModel3D (rows 3-5); this body runs only on nodes that have two (the launcher sends the
+  // others to the 3-row body)
+  int cframe2 = -1, cbody2 = -1, ccap2 = 0;
+  if constexpr (CT == CT_PAIR3) {
+    if (use_contact) {
+      cframe2 = set.contacts[1].frame;
+      cbody2 = m.frame_body[cframe2];
+      bool seen = false;
+#pragma unroll
+      for (int k = 0; k < NCAP; ++k)
+        if (k < ncap && capf[k] == cframe2) {
+          seen = true;
+          ccap2 = k;
+        }
+      if (!seen) {
+#pragma unroll
+        for (int k = 0; k < NCAP; ++k)
+          if (k == ncap) capf[k] = cframe2;
+        ccap2 = ncap;
+        ncap = (ncap < NCAP) ? ncap + 1 : ncap;
+      }
+    }
+  }
 
 #if defined(EMPC_STAMPS) && defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
   unsigned long long lst[16];
@@ -544,7 +588,10 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
 #endif
   // the three single-lane sections of a unit, as functions of the unit's LDS block (see LinRole)
   auto chain_section = [&](double* Nu) {
-    lin2_nominal_chain<DM>(m, Nu, use_contact ? cbody : -1);
+    if constexpr (CT == CT_PAIR3)
+      lin2_nominal_chain<DM>(m, Nu, use_contact ? cbody : -1, use_contact ? cbody2 : -1);
+    else
+      lin2_nominal_chain<DM>(m, Nu, use_contact ? cbody : -1);
     // nominal frame data
 #pragma unroll
     for (int c = 0; c < NCAP; ++c) {
@@ -753,6 +800,16 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
           N[SM::OFF_FEXT + i] = fb[i];
           N[SM::OFF_FEXT + 3 + i] = rxf[i];
         }
+        if constexpr (CT == CT_PAIR3) {
+          double fl2[3] = {N[SM::OFF_LAM + 3], N[SM::OFF_LAM + 4], N[SM::OFF_LAM + 5]}, fb2[3], rxf2[3];
+          matvec3<double>(m.frame_R[cframe2], fl2, fb2);
+          cross3<double>(m.frame_p[cframe2], fb2, rxf2);
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            N[SM::OFF_FEXT2 + i] = fb2[i];
+            N[SM::OFF_FEXT2 + 3 + i] = rxf2[i];
+          }
+        }
       }
     } else if (lane == lpu - 1) {
       double q[4] = {N[SM::OFF_X + 3], N[SM::OFF_X + 4], N[SM::OFF_X + 5], N[SM::OFF_X + 6]};
@@ -788,11 +845,15 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
   double dcon_l[Exec::SLOTS][NCR], dlam_l[Exec::SLOTS][NCR];
   ex.each([&](int lane, int sl) {
     double capdv[NCAP][6], capda[6] = {0, 0, 0, 0, 0, 0};
+    double capda2[CT == CT_PAIR3 ? 6 : 1] = {0};
 #pragma unroll
     for (int c = 0; c < NCAP; ++c)
 #pragma unroll
       for (int i = 0; i < 6; ++i) capdv[c][i] = 0.0;
-    lin2_tangent<DM>(m, N, lane, dtau_l[sl], ncap, capf, capdv, use_contact ? cbody : -1, capda);
+    if constexpr (CT == CT_PAIR3)
+      lin2_tangent<DM>(m, N, lane, dtau_l[sl], ncap, capf, capdv, use_contact ? cbody : -1, capda, use_contact ? cbody2 : -1, capda2);
+    else
+      lin2_tangent<DM>(m, N, lane, dtau_l[sl], ncap, capf, capdv, use_contact ? cbody : -1, capda);
     if (lane >= 2 * NV && lane < 3 * NV) {
 #pragma unroll
       for (int i = 0; i < NV; ++i) N[SM::OFF_M + i * NV + (lane - 2 * NV)] = dtau_l[sl][i];
@@ -826,75 +887,127 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
 #pragma unroll
       for (int r = 0; r < NCR; ++r) dcon_l[sl][r] = dlam_l[sl][r] = 0.0;
       if (use_contact) {
-        // derivative of the contact drift at fixed generalized acceleration.  3D: d(classical acceleration of the contact
-        // frame origin, LOCAL) = d a_f.lin + dphi x (Rf^T (-g)) + d w_f x v_f.lin + w_f x d v_f.lin;
-        // 6D: d(spatial acceleration, LOCAL) = [d a_f.lin + dphi x (Rf^T (-g)); d a_f.ang].  Baumgarte terms
-        // (ContactModel3D/6D::calcDiff): 3D g0 oRf fJf.lin, 6D g0 Jlog6(Mref^-1 oMf) fJf, both g1 d(v_f)
-        const EmpcContact& ctc = set.contacts[0];
-        const double* F = N + SM::OFF_FR + ccap * 18;
-        double daf[3], wxr[3], tmp[3], gf[3], c1[3], c2[3], c3[3];
-        cross3<double>(capda + 3, m.frame_p[cframe], wxr);
+        if constexpr (CT == CT_PAIR3) {
+          // two ContactModel3D: the 3D form below once per contact, rows 3 k .. 3 k + 2 (contact k on frame cf, capture slot cc,
+          // tangent acceleration of its body cda)
+          auto drift3 = [&](const EmpcContact& ctk, const int cf, const int cc, const double* cda, double* out3) {
+            const double* F = N + SM::OFF_FR + cc * 18;
+            double daf[3], wxr[3], tmp[3], gf[3], c1[3], c2[3], c3[3];
+            cross3<double>(cda + 3, m.frame_p[cf], wxr);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) tmp[i] = capda[i] + wxr[i];
-        matTvec3<double>(m.frame_R[cframe], tmp, daf);
-        double ng[3] = {-m.gravity[0], -m.gravity[1], -m.gravity[2]};
-        matTvec3<double>(F, ng, gf);
-        double jcc[6], dvcc[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          jcc[i] = jc_l[sl][0][i];
-          dvcc[i] = dvc_l[sl][0][i];
-        }
-#pragma unroll
-        for (int kk = 1; kk < NCAP; ++kk)
-          if (kk == ccap) {
+            for (int i = 0; i < 3; ++i) tmp[i] = cda[i] + wxr[i];
+            matTvec3<double>(m.frame_R[cf], tmp, daf);
+            double ng[3] = {-m.gravity[0], -m.gravity[1], -m.gravity[2]};
+            matTvec3<double>(F, ng, gf);
+            double jcc[6], dvcc[6];
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
-              jcc[i] = jc_l[sl][kk][i];
-              dvcc[i] = dvc_l[sl][kk][i];
+              jcc[i] = jc_l[sl][0][i];
+              dvcc[i] = dvc_l[sl][0][i];
             }
-          }
-        cross3<double>(jcc + 3, gf, c1);
-        if constexpr (CT == 6) {
-          double dang[3];
-          matTvec3<double>(m.frame_R[cframe], capda + 3, dang);
+#pragma unroll
+            for (int kk = 1; kk < NCAP; ++kk)
+              if (kk == cc) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                  jcc[i] = jc_l[sl][kk][i];
+                  dvcc[i] = dvc_l[sl][kk][i];
+                }
+              }
+            cross3<double>(jcc + 3, gf, c1);
+            cross3<double>(dvcc + 3, F + 12, c2);
+            cross3<double>(F + 15, dvcc, c3);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) out3[i] = daf[i] + c1[i] + c2[i] + c3[i];
+            if (ctk.gains[0] != 0.0) {
+              double wl[3];
+              matvec3<double>(F, jcc, wl);  // oRf * (LOCAL linear Jacobian column)
+#pragma unroll
+              for (int i = 0; i < 3; ++i) out3[i] += ctk.gains[0] * wl[i];
+            }
+            if (ctk.gains[1] != 0.0)
+#pragma unroll
+              for (int i = 0; i < 3; ++i) out3[i] += ctk.gains[1] * dvcc[i];
+          };
+          double d0[3], d1[3];
+          drift3(set.contacts[0], cframe, ccap, capda, d0);
+          drift3(set.contacts[1], cframe2, ccap2, capda2, d1);
 #pragma unroll
           for (int i = 0; i < 3; ++i) {
-            dcon_l[sl][i] = daf[i] + c1[i];
-            dcon_l[sl][3 + i] = dang[i];
-          }
-          if (ctc.gains[0] != 0.0) {
-            double rR[9], dp[3], rp[3], qq[4], xi[6], J6[36];
-            matTmul3<double>(ctc.ref_R, F, rR);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) dp[i] = F[9 + i] - ctc.ref_p[i];
-            matTvec3<double>(ctc.ref_R, dp, rp);
-            R_to_quat(rR, qq);
-            log6_quat(qq, rp, xi);
-            Jlog6(xi, rp, J6);
-#pragma unroll
-            for (int r = 0; r < 6; ++r) {
-              double a_ = 0;
-#pragma unroll
-              for (int l = 0; l < 6; ++l) a_ += J6[r * 6 + l] * jcc[l];
-              dcon_l[sl][r] += ctc.gains[0] * a_;
-            }
+            dcon_l[sl][i] = d0[i];
+            dcon_l[sl][3 + i] = d1[i];
           }
         } else {
-          cross3<double>(dvcc + 3, F + 12, c2);
-          cross3<double>(F + 15, dvcc, c3);
-#pragma unroll
-          for (int i = 0; i < 3; ++i) dcon_l[sl][i] = daf[i] + c1[i] + c2[i] + c3[i];
-          if (ctc.gains[0] != 0.0) {
-            double wl[3];
-            matvec3<double>(F, jcc, wl);  // oRf * (LOCAL linear Jacobian column)
-#pragma unroll
-            for (int i = 0; i < 3; ++i) dcon_l[sl][i] += ctc.gains[0] * wl[i];
+          // derivative of the contact drift at fixed generalized acceleration.  3D: d(classical acceleration of the contact
+          // frame origin, LOCAL) = d a_f.lin + dphi x (Rf^T (-g)) + d w_f x v_f.lin + w_f x d v_f.lin;
+          // 6D: d(spatial acceleration, LOCAL) = [d a_f.lin + dphi x (Rf^T (-g)); d a_f.ang].  Baumgarte terms
+          // (ContactModel3D/6D::calcDiff): 3D g0 oRf fJf.lin, 6D g0 Jlog6(Mref^-1 oMf) fJf, both g1 d(v_f)
+          const EmpcContact& ctc = set.contacts[0];
+          const double* F = N + SM::OFF_FR + ccap * 18;
+          double daf[3], wxr[3], tmp[3], gf[3], c1[3], c2[3], c3[3];
+          cross3<double>(capda + 3, m.frame_p[cframe], wxr);
+  #pragma unroll
+          for (int i = 0; i < 3; ++i) tmp[i] = capda[i] + wxr[i];
+          matTvec3<double>(m.frame_R[cframe], tmp, daf);
+          double ng[3] = {-m.gravity[0], -m.gravity[1], -m.gravity[2]};
+          matTvec3<double>(F, ng, gf);
+          double jcc[6], dvcc[6];
+  #pragma unroll
+          for (int i = 0; i < 6; ++i) {
+            jcc[i] = jc_l[sl][0][i];
+            dvcc[i] = dvc_l[sl][0][i];
           }
+  #pragma unroll
+          for (int kk = 1; kk < NCAP; ++kk)
+            if (kk == ccap) {
+  #pragma unroll
+              for (int i = 0; i < 6; ++i) {
+                jcc[i] = jc_l[sl][kk][i];
+                dvcc[i] = dvc_l[sl][kk][i];
+              }
+            }
+          cross3<double>(jcc + 3, gf, c1);
+          if constexpr (CT == 6) {
+            double dang[3];
+            matTvec3<double>(m.frame_R[cframe], capda + 3, dang);
+  #pragma unroll
+            for (int i = 0; i < 3; ++i) {
+              dcon_l[sl][i] = daf[i] + c1[i];
+              dcon_l[sl][3 + i] = dang[i];
+            }
+            if (ctc.gains[0] != 0.0) {
+              double rR[9], dp[3], rp[3], qq[4], xi[6], J6[36];
+              matTmul3<double>(ctc.ref_R, F, rR);
+  #pragma unroll
+              for (int i = 0; i < 3; ++i) dp[i] = F[9 + i] - ctc.ref_p[i];
+              matTvec3<double>(ctc.ref_R, dp, rp);
+              R_to_quat(rR, qq);
+              log6_quat(qq, rp, xi);
+              Jlog6(xi, rp, J6);
+  #pragma unroll
+              for (int r = 0; r < 6; ++r) {
+                double a_ = 0;
+  #pragma unroll
+                for (int l = 0; l < 6; ++l) a_ += J6[r * 6 + l] * jcc[l];
+                dcon_l[sl][r] += ctc.gains[0] * a_;
+              }
+            }
+          } else {
+            cross3<double>(dvcc + 3, F + 12, c2);
+            cross3<double>(F + 15, dvcc, c3);
+  #pragma unroll
+            for (int i = 0; i < 3; ++i) dcon_l[sl][i] = daf[i] + c1[i] + c2[i] + c3[i];
+            if (ctc.gains[0] != 0.0) {
+              double wl[3];
+              matvec3<double>(F, jcc, wl);  // oRf * (LOCAL linear Jacobian column)
+  #pragma unroll
+              for (int i = 0; i < 3; ++i) dcon_l[sl][i] += ctc.gains[0] * wl[i];
+            }
+          }
+          if (ctc.gains[1] != 0.0)
+  #pragma unroll
+            for (int r = 0; r < NCR; ++r) dcon_l[sl][r] += ctc.gains[1] * dvcc[r];
         }
-        if (ctc.gains[1] != 0.0)
-#pragma unroll
-          for (int r = 0; r < NCR; ++r) dcon_l[sl][r] += ctc.gains[1] * dvcc[r];
         if (lane >= 2 * NV && lane < 3 * NV) {
           // direction da_j: d(con)/d(a_j) is column j of the contact Jacobian
 #pragma unroll
@@ -997,7 +1110,7 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
           double a_ = N[OFF_MIJ + i * NCR] * z[0] + N[OFF_MIJ + i * NCR + 1] * z[1] + N[OFF_MIJ + i * NCR + 2] * z[2];
-          if constexpr (CT == 6)
+          if constexpr (NCR == 6)
             a_ += N[OFF_MIJ + i * NCR + 3] * z[3] + N[OFF_MIJ + i * NCR + 4] * z[4] + N[OFF_MIJ + i * NCR + 5] * z[5];
           da[i] += a_;
         }
@@ -1400,9 +1513,10 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
 #pragma unroll
           for (int j = 0; j < 3; ++j) AR[i][j] = c.ref[4 + 3 * i + j];
         double cv = 0;
+        const int fo = cone_force_offset<CT>(set, c.frame);  // CT_PAIR3: the contact on the cost's frame; 0 otherwise
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
-          const double r = AR[i][0] * N[SM::OFF_LAM] + AR[i][1] * N[SM::OFF_LAM + 1] + AR[i][2] * N[SM::OFF_LAM + 2];
+          const double r = AR[i][0] * N[SM::OFF_LAM + fo] + AR[i][1] * N[SM::OFF_LAM + fo + 1] + AR[i][2] * N[SM::OFF_LAM + fo + 2];
           double av, Ar, Arr;
           activation1(c.activation, r, c.act_w[i], c.lb[i], c.ub[i], av, Ar, Arr);
           cv += av;
@@ -1421,10 +1535,18 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
         if (!xlane && !ulane) return;
         const int colidx = xlane ? lane : NDX + k;
         double g = 0;
+        double dl3[3] = {dlam_l[sl][0], dlam_l[sl][1], dlam_l[sl][2]};
+        if constexpr (CT == CT_PAIR3) {
+          if (cone_force_offset<CT>(set, c.frame) != 0) {
+            dl3[0] = dlam_l[sl][3];
+            dl3[1] = dlam_l[sl][4];
+            dl3[2] = dlam_l[sl][5];
+          }
+        }
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
-          const double col = N[SM::OFF_CONE + i * 3] * dlam_l[sl][0] + N[SM::OFF_CONE + i * 3 + 1] * dlam_l[sl][1] +
-                             N[SM::OFF_CONE + i * 3 + 2] * dlam_l[sl][2];
+          const double col = N[SM::OFF_CONE + i * 3] * dl3[0] + N[SM::OFF_CONE + i * 3 + 1] * dl3[1] +
+                             N[SM::OFF_CONE + i * 3 + 2] * dl3[2];
           g += col * N[SM::OFF_CONE + 15 + i];
           wc_l[sl][i] = N[SM::OFF_CONE + 20 + i] * col;
           N[SM::OFF_RSH + i * (NDX + NU) + colidx] = col;

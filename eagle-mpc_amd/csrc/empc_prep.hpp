@@ -117,6 +117,7 @@ inline void prepare_problem(const EmpcProblemDesc& d, const EmpcSolverParams& pr
         for (int j = 0; j < 3; ++j) c.ref[4 + 3 * r + j] = AR[r][j];
     }
   // frame-capture capacity per cost set
+  bool pair_seen = false;
   for (auto& s : H.sets) {
     int frames[EMPC_MAX_COSTS], nf = 0;
     for (int i = 0; i < s.ncosts; ++i) {
@@ -131,20 +132,44 @@ inline void prepare_problem(const EmpcProblemDesc& d, const EmpcSolverParams& pr
       EmpcCostSet& ms = s;
       ms.costs[0].reserved = (ms.costs[0].reserved & ~1) | ((nf > 0 || s.ncontacts >= 1) ? 1 : 0);
     }
-    if (s.ncontacts >= 1) {  // the contact frame is captured too
+    for (int k = 0; k < s.ncontacts && k < EMPC_MAX_CONTACTS; ++k) {  // the contact frames are captured too
+      if (s.contacts[k].frame < 0 || s.contacts[k].frame >= m.nframes)
+        throw std::invalid_argument("contact references a frame outside the model's frame table");
       bool seen = false;
-      for (int k = 0; k < nf; ++k) seen = seen || frames[k] == s.contacts[0].frame;
-      if (!seen) ++nf;
+      for (int q = 0; q < nf; ++q) seen = seen || frames[q] == s.contacts[k].frame;
+      if (!seen) frames[nf++] = s.contacts[k].frame;
     }
     if (nf > NCAP) throw std::runtime_error("a cost set references more distinct frames than the kernels capture");
-    if (s.ncontacts > 1) throw std::runtime_error("more than one contact per stage is not supported by the kernels");
-    if (s.ncontacts == 1) {
+    if (s.ncontacts > 2) throw std::runtime_error("more than two contacts per stage are not supported by the kernels");
+    if (s.ncontacts == 2) {
+      // ContactModelMultiple with two entries (src/stage.cpp:38-48): the kernels have the six-row form for two ContactModel3D
+      // (CT_PAIR3).  3 + 6 or 6 + 6 rows would leave the 9- and 11-dof robots of this path 0 to 2 degrees of freedom (on
+      // the 9-dof arm Jc M^-1 Jc^T of a 6D + 3D pair is singular: the oracle's Cholesky fails as crocoddyl's would).
+      if (s.contacts[0].type != EMPC_CONTACT_3D || s.contacts[1].type != EMPC_CONTACT_3D)
+        throw std::runtime_error("two contacts per stage are supported for two ContactModel3D only (six constraint rows)");
+      pair_seen = true;
+    }
+    if (s.ncontacts >= 1) {
       // the number of constraint rows is a compile-time constant of the kernels (3: ContactModel3D, 6: ContactModel6D)
       const int rows = s.contacts[0].type == EMPC_CONTACT_3D ? 3 : (s.contacts[0].type == EMPC_CONTACT_6D ? 6 : -1);
       if (rows < 0) throw std::runtime_error("unknown contact type in a cost set");
       // stages of both types in one problem: the mixed instantiation (CT_MIXED), which branches on the node's contact type
       H.contact_rows = (H.contact_rows != 0 && H.contact_rows != rows) ? CT_MIXED : rows;
     }
+    // a ContactFrictionCone cost of a stage with two contacts reads the force of the contact on ITS frame (crocoddyl looks the
+    // contact up by frame id and fails without one)
+    if (s.ncontacts == 2)
+      for (int i = 0; i < s.ncosts; ++i) {
+        const EmpcCost& c = s.costs[i];
+        if (!c.active || c.type != EMPC_COST_CONTACT_FRICTION_CONE) continue;
+        if (c.frame != s.contacts[0].frame && c.frame != s.contacts[1].frame)
+          throw std::runtime_error("a ContactFrictionCone cost of a stage with two contacts names a frame that carries neither");
+      }
+  }
+  if (pair_seen) {
+    // every other contact stage of the problem must be a single ContactModel3D (the three-row body behind a uniform branch)
+    if (H.contact_rows != 3) throw std::runtime_error("a problem with a two-contact stage may only hold ContactModel3D contacts");
+    H.contact_rows = CT_PAIR3;
   }
   // work lists per cost set (SetInfo); the capture order is the one node_nominal derives by scanning the table
   H.set_info.assign(H.sets.size(), SetInfo());
@@ -191,6 +216,17 @@ inline void prepare_problem(const EmpcProblemDesc& d, const EmpcSolverParams& pr
       if (!seen) {
         I.ccap = I.ncap;
         if (I.ncap < NCAP) I.capf[I.ncap++] = cframe;
+      }
+      if (s.ncontacts > 1) {  // CT_PAIR3: slot of the second contact frame in bits 8.. of ccap (read by the pair kernels only)
+        const int cframe2 = s.contacts[1].frame;
+        int slot2 = -1;
+        for (int q = 0; q < I.ncap; ++q)
+          if (I.capf[q] == cframe2) slot2 = q;
+        if (slot2 < 0) {
+          slot2 = I.ncap;
+          if (I.ncap < NCAP) I.capf[I.ncap++] = cframe2;
+        }
+        I.ccap |= slot2 << 8;
       }
     }
   }

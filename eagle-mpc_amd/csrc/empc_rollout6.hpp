@@ -62,6 +62,9 @@ struct Roll6Smem {
   static constexpr int OFF_TB = OFF_DUMP + 2 * NL;            // trajectory index of each packed slot (ints)
   static constexpr int OFF_NOM = OFF_TB + R6_GMAX;            // [2][NOMSZ], 16-byte aligned
   static constexpr int SIZE = (OFF_NOM + 2 * NOMSZ + 1) / 2 * 2;
+  // CT_PAIR3 (two ContactModel3D of one stage): the capture of the second contact frame (B -> C) behind everything else
+  static constexpr int OFF_CAPB = SIZE;
+  static constexpr int size_for(int CT) { return CT == CT_PAIR3 ? SIZE + 24 * NL : SIZE; }
   static_assert(OFF_NOM % 2 == 0 && OFF_DUMP % 2 == 0 && KS % 2 == 0 && (NU * NDX) % 2 == 0, "gain rows are staged in 16-byte pieces");
 };
 
@@ -342,8 +345,9 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
     for (int k = 0; k < si.n_cone; ++k) {
       const auto& c = set.costs[si.cone_ci[k]];
       double lam[3], r[6] = {0, 0, 0, 0, 0, 0};
+      const int fo = cone_force_offset<CT>(set, c.frame);  // CT_PAIR3: the contact on the cost's frame; 0 otherwise
 #pragma unroll
-      for (int i = 0; i < 3; ++i) lam[i] = ACC[(NV + i) * NL + lane];
+      for (int i = 0; i < 3; ++i) lam[i] = ACC[(NV + fo + i) * NL + lane];
 #pragma unroll
       for (int i = 0; i < 5; ++i)
         r[i] = use_contact ? (c.ref[4 + 3 * i] * lam[0] + c.ref[5 + 3 * i] * lam[1] + c.ref[6 + 3 * i] * lam[2]) : 0.0;
@@ -528,7 +532,8 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
       int capf[NCAP];
 #pragma unroll
       for (int k = 0; k < NCAP; ++k) capf[k] = si.capf[k];
-      const int ncap = si.ncap, ccap = si.ccap;
+      // (CT_PAIR3 problems: si.ccap = slot of contact 0's frame | slot of contact 1's frame << 8, see prepare_problem)
+      const int ncap = si.ncap, ccap = (CT == CT_PAIR3) ? (si.ccap & 0xff) : si.ccap;
 #if EMPC_ROLL_CAP_LDS
       double zero[NV], h[NV];
 #pragma unroll
@@ -575,6 +580,24 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
           for (int i = 0; i < 6; ++i) CAP[(12 + i) * NL + lane] = ck.v[i];
 #pragma unroll
           for (int i = 0; i < 6; ++i) CAP[(18 + i) * NL + lane] = ck.a[i];
+          if constexpr (CT == CT_PAIR3) {
+            if (set.ncontacts > 1) {
+              const int ccap2 = si.ccap >> 8;
+              double* CAPB = N + SM::OFF_CAPB;
+              FrameCap<double> ck2 = caps[0];
+#pragma unroll
+              for (int kk = 1; kk < NCAP; ++kk)
+                if (kk == ccap2) ck2 = caps[kk];
+#pragma unroll
+              for (int i = 0; i < 9; ++i) CAPB[i * NL + lane] = ck2.R[i];
+#pragma unroll
+              for (int i = 0; i < 3; ++i) CAPB[(9 + i) * NL + lane] = ck2.p[i];
+#pragma unroll
+              for (int i = 0; i < 6; ++i) CAPB[(12 + i) * NL + lane] = ck2.v[i];
+#pragma unroll
+              for (int i = 0; i < 6; ++i) CAPB[(18 + i) * NL + lane] = ck2.a[i];
+            }
+          }
         }
       }
 #endif
@@ -734,7 +757,8 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
           FrameCap<double> ck;
 #if EMPC_ROLL_CAP_LDS
           // the slot role B's register form copied from: caps[0] unless a later slot is the contact frame's (si.ccap)
-          const double* CAPc = CAP + (size_t)((si.ccap >= 1 && si.ccap < NCAP) ? si.ccap : 0) * 24 * NL;
+          const int ccapc = (CT == CT_PAIR3) ? (si.ccap & 0xff) : si.ccap;
+          const double* CAPc = CAP + (size_t)((ccapc >= 1 && ccapc < NCAP) ? ccapc : 0) * 24 * NL;
 #else
           const double* CAPc = CAP;
 #endif
@@ -750,7 +774,30 @@ EMPC_HD void rollout_group6(Exec& ex, const DevBuffers& D, int group, double* N)
           quat_to_R(x + 3, R0);
 #pragma unroll
           for (int b = 1; b < NB; ++b) fsincos(x[7 + b - 1], &sn[b - 1], &cs[b - 1]);
-          contact_forward<DM, CT>(m, set.contacts[0], ck, R0, x, cs, sn, Lc[sl], a, lam);
+          if constexpr (CT == CT_PAIR3) {
+            if (set.ncontacts > 1) {
+              FrameCap<double> ck2;
+#if EMPC_ROLL_CAP_LDS
+              const int ccap2 = si.ccap >> 8;
+              const double* CAPd = CAP + (size_t)((ccap2 >= 1 && ccap2 < NCAP) ? ccap2 : 0) * 24 * NL;
+#else
+              const double* CAPd = N + SM::OFF_CAPB;
+#endif
+#pragma unroll
+              for (int i = 0; i < 9; ++i) ck2.R[i] = CAPd[i * NL + lane];
+#pragma unroll
+              for (int i = 0; i < 3; ++i) ck2.p[i] = CAPd[(9 + i) * NL + lane];
+#pragma unroll
+              for (int i = 0; i < 6; ++i) ck2.v[i] = CAPd[(12 + i) * NL + lane];
+#pragma unroll
+              for (int i = 0; i < 6; ++i) ck2.a[i] = CAPd[(18 + i) * NL + lane];
+              contact_forward_pair3<DM>(m, set.contacts[0], set.contacts[1], ck, ck2, R0, x, cs, sn, Lc[sl], a, lam);
+            } else {
+              contact_forward<DM, 3>(m, set.contacts[0], ck, R0, x, cs, sn, Lc[sl], a, lam);
+            }
+          } else {
+            contact_forward<DM, CT>(m, set.contacts[0], ck, R0, x, cs, sn, Lc[sl], a, lam);
+          }
         }
       }
       R6_SUB(2);

@@ -116,6 +116,19 @@ static bool find_table(const DevProblem& P, int nb, int nrot, bool contact, int 
   else if (nb == 1 && nrot == 6 && contact) k = empc_table_1_6_contact();
   else if (nb == 3 && nrot == 6 && contact) k = empc_table_3_6_contact();
   else if (nb == 4 && nrot == 6 && !contact) k = empc_table_4_6();
+  // a stage with TWO ContactModel3D contacts (ContactModelMultiple, src/stage.cpp:38-48): the six-row instantiation of the
+  // (4,6) and (6,6) classes.  Opt-in like the classes above: these kernels have only run on the CPU lane emulator.
+  else if (contact && contact_rows == empc::CT_PAIR3 && !((nb == 4 || nb == 6) && nrot == 6)) {
+    find_table_reason = "two contacts per stage: kernels exist for the (4,6) and (6,6) robot classes only";
+    return false;
+  }
+  else if (contact && contact_rows == empc::CT_PAIR3 && !experimental_contact()) {
+    find_table_reason = "two contacts per stage (two ContactModel3D, six constraint rows): kernels not yet verified on hardware; "
+                        "set EMPC_EXPERIMENTAL_CONTACT=1 to run them";
+    return false;
+  }
+  else if (nb == 4 && nrot == 6 && contact && contact_rows == empc::CT_PAIR3) k = empc_table_4_6_contact_pair();
+  else if (nb == 6 && nrot == 6 && contact && contact_rows == empc::CT_PAIR3) k = empc_table_6_6_contact_pair();
   else if (nb == 4 && nrot == 6 && contact && contact_rows == empc::CT_MIXED) k = empc_table_4_6_contact_mixed();
   else if (nb == 4 && nrot == 6 && contact && contact_rows != 6) k = empc_table_4_6_contact();
   else if (nb == 4 && nrot == 6 && contact && contact_rows == 6) k = empc_table_4_6_contact6();

@@ -22,6 +22,7 @@ constexpr int NX = EMPC_MAX_NX;
 constexpr int NDX = EMPC_MAX_NDX;
 constexpr int NU = EMPC_MAX_NU;
 constexpr int NR = EMPC_MAX_NR;
+constexpr int NCM = 6 * EMPC_MAX_CONTACTS;  // constraint rows of a stage's ContactModelMultiple (each contact 3 or 6)
 
 struct Problem {
   EmpcProblemDesc d;
@@ -115,7 +116,7 @@ struct NodeData {
   double cost;
   double xout[NV];        // acceleration
   double u_squash[NU];    // sigma(s): what SolverSbFDDP::fillSquashedOutputs copies (src/sbfddp.cpp:479-486)
-  double lambda[6];       // contact force (LOCAL), when a contact is active
+  double lambda[NCM];     // contact forces (LOCAL), stacked in the stage's contact order, when contacts are active
   double Fx[NDX * NDX], Fu[NDX * NU];
   double Lx[NDX], Lu[NU], Lxx[NDX * NDX], Lxu[NDX * NU], Luu[NU * NU];
 };
@@ -193,18 +194,27 @@ inline void dam_eval(const Problem& P, int t, const double* x, const double* u_i
   double M[NV * NV], L[NV * NV];
   crba(m, kin, M);
   std::memcpy(L, M, sizeof(double) * nv * nv);
-  // contacts of this node (ContactModelMultiple of the stage); nc rows in total
+  // contacts of this node (ContactModelMultiple of the stage, src/stage.cpp:38-48: every name of the stage's list is
+  // added; crocoddyl stacks their rows in the order of its name-sorted map, which is the order of set.contacts[]); nc rows
+  // in total, contact k owns rows coff[k] .. coff[k] + cnr[k] - 1
   int nc = 0;
-  double Jc[6 * NV], a0[6];
+  double Jc[NCM * NV], a0[NCM];
   const bool use_contact = P.d.has_contact && set.ncontacts > 0;
+  const int ncon = use_contact ? set.ncontacts : 0;
+  int coff[EMPC_MAX_CONTACTS] = {0}, cnr[EMPC_MAX_CONTACTS] = {0};
   Kin<double> kin0;  // true accelerations with qdd = 0
-  FrameKin<double> cfk;
-  if (use_contact) {
+  FrameKin<double> cfks[EMPC_MAX_CONTACTS];
+  if (use_contact) forward_kin<double>(m, R0, q, cs, sn, v, zero, false, kin0);
+  for (int k = 0; k < ncon; ++k) {
     // ContactModel3D/6D (A.7): LOCAL frame Jacobian rows and drift a0
-    const EmpcContact& ct = set.contacts[0];
-    forward_kin<double>(m, R0, q, cs, sn, v, zero, false, kin0);
+    const EmpcContact& ct = set.contacts[k];
+    FrameKin<double>& cfk = cfks[k];
     frame_kin<double>(m, kin0, ct.frame, cfk);
-    nc = (ct.type == EMPC_CONTACT_3D) ? 3 : 6;
+    const int nk = (ct.type == EMPC_CONTACT_3D) ? 3 : 6;
+    const int o = nc;
+    coff[k] = o;
+    cnr[k] = nk;
+    nc += nk;
     // frame Jacobian (LOCAL) via unit velocities: column j = local frame velocity for v = e_j
     for (int j = 0; j < nv; ++j) {
       double ej[NV] = {0};
@@ -213,38 +223,38 @@ inline void dam_eval(const Problem& P, int t, const double* x, const double* u_i
       FrameKin<double> fj;
       forward_kin<double>(m, R0, q, cs, sn, ej, zero, false, kj);
       frame_kin<double>(m, kj, ct.frame, fj);
-      for (int r = 0; r < nc; ++r) Jc[r * nv + j] = fj.v[r];
+      for (int r = 0; r < nk; ++r) Jc[(o + r) * nv + j] = fj.v[r];
     }
     // drift: 3D = classical acceleration of the frame origin, 6D = spatial acceleration (+ Baumgarte terms)
-    if (nc == 3) {
+    if (nk == 3) {
       double wxv[3];
       cross3<double>(cfk.v + 3, cfk.v, wxv);
-      for (int r = 0; r < 3; ++r) a0[r] = cfk.a[r] + wxv[r];
+      for (int r = 0; r < 3; ++r) a0[o + r] = cfk.a[r] + wxv[r];
     } else {
-      for (int r = 0; r < 6; ++r) a0[r] = cfk.a[r];
+      for (int r = 0; r < 6; ++r) a0[o + r] = cfk.a[r];
     }
     if (ct.gains[0] != 0.0) {
-      if (nc == 3) {
+      if (nk == 3) {
         // crocoddyl 1.8 ContactModel3D::calc: a0 += gains[0] * (oMf.translation() - xref)   (world-frame error)
-        for (int r = 0; r < 3; ++r) a0[r] += ct.gains[0] * (cfk.p[r] - ct.ref_p[r]);
+        for (int r = 0; r < 3; ++r) a0[o + r] += ct.gains[0] * (cfk.p[r] - ct.ref_p[r]);
       } else {
         double rR[9], dp[3], rp[3], xi[6];
         matTmul3<double>(ct.ref_R, cfk.R, rR);
         for (int r = 0; r < 3; ++r) dp[r] = cfk.p[r] - ct.ref_p[r];
         matTvec3<double>(ct.ref_R, dp, rp);
         log6(rR, rp, xi);
-        for (int r = 0; r < 6; ++r) a0[r] += ct.gains[0] * xi[r];
+        for (int r = 0; r < 6; ++r) a0[o + r] += ct.gains[0] * xi[r];
       }
     }
     if (ct.gains[1] != 0.0)
-      for (int r = 0; r < nc; ++r) a0[r] += ct.gains[1] * cfk.v[r];
+      for (int r = 0; r < nk; ++r) a0[o + r] += ct.gains[1] * cfk.v[r];
   }
 
   double a[NV];
   bool ok = cholesky(L, nv);
   (void)ok;
-  double lam[6] = {0};
-  double MinvJt[NV * 6], Lc[36];  // M^-1 Jc^T and chol(Jc M^-1 Jc^T)
+  double lam[NCM] = {0};
+  double MinvJt[NV * NCM], Lc[NCM * NCM];  // M^-1 Jc^T and chol(Jc M^-1 Jc^T)
   if (!use_contact) {
     for (int i = 0; i < nv; ++i) a[i] = tau[i] - h[i];
     cholesky_solve(L, nv, a);
@@ -257,12 +267,12 @@ inline void dam_eval(const Problem& P, int t, const double* x, const double* u_i
       double col[NV];
       for (int i = 0; i < nv; ++i) col[i] = Jc[r * nv + i];
       cholesky_solve(L, nv, col);
-      for (int i = 0; i < nv; ++i) MinvJt[i * 6 + r] = col[i];
+      for (int i = 0; i < nv; ++i) MinvJt[i * NCM + r] = col[i];
     }
     for (int r = 0; r < nc; ++r)
       for (int c = 0; c < nc; ++c) {
         double acc = 0;
-        for (int i = 0; i < nv; ++i) acc += Jc[r * nv + i] * MinvJt[i * 6 + c];
+        for (int i = 0; i < nv; ++i) acc += Jc[r * nv + i] * MinvJt[i * NCM + c];
         Lc[r * nc + c] = acc;
       }
     cholesky(Lc, nc);
@@ -274,17 +284,17 @@ inline void dam_eval(const Problem& P, int t, const double* x, const double* u_i
     cholesky_solve(Lc, nc, lam);
     for (int i = 0; i < nv; ++i) {
       double acc = afree[i];
-      for (int r = 0; r < nc; ++r) acc += MinvJt[i * 6 + r] * lam[r];
+      for (int r = 0; r < nc; ++r) acc += MinvJt[i * NCM + r] * lam[r];
       a[i] = acc;
     }
   }
   for (int i = 0; i < nv; ++i) D.xout[i] = a[i];
-  for (int i = 0; i < 6; ++i) D.lambda[i] = lam[i];
+  for (int i = 0; i < NCM; ++i) D.lambda[i] = lam[i];
 
   // --- derivatives of the dynamics
   //   dtau_dx: derivative of RNEA(q,v,a) - Jc^T lam at fixed (a, lam); da0_dx: derivative of the contact drift + Jc a
   double dtau_dx[NV * NDX];
-  double dcon_dx[6 * NDX];
+  double dcon_dx[NCM * NDX];
   static thread_local Kin<Dual> kd_s, kd0_s;
   static thread_local Dual fext_s[NB][6];
   static thread_local DualState ds;
@@ -295,71 +305,78 @@ inline void dam_eval(const Problem& P, int t, const double* x, const double* u_i
     for (int i = 0; i < nv; ++i) ad[i] = Dual(a[i]);
     Dual(*fext)[6] = nullptr;
     if (use_contact) {
-      // external force on the contact body = X_f^* lam (lam in the LOCAL frame, body coordinates)
-      const EmpcContact& ct = set.contacts[0];
-      const int b = m.frame_body[ct.frame];
+      // external force on each contact body = X_f^* lam_k (lam_k in the LOCAL frame, body coordinates); contacts on one body add up
       fext = fext_s;
       for (int bb = 0; bb < NB; ++bb)
         for (int i = 0; i < 6; ++i) fext[bb][i] = Dual(0.0);
-      double fl[3] = {lam[0], lam[1], lam[2]}, fn[3] = {0, 0, 0};
-      if (nc == 6) {
-        fn[0] = lam[3];
-        fn[1] = lam[4];
-        fn[2] = lam[5];
-      }
-      double fb[3], nb_[3], nb2[3], rxf[3];
-      matvec3<double>(m.frame_R[ct.frame], fl, fb);
-      matvec3<double>(m.frame_R[ct.frame], fn, nb_);
-      cross3<double>(m.frame_p[ct.frame], fb, rxf);
-      for (int i = 0; i < 3; ++i) nb2[i] = nb_[i] + rxf[i];
-      for (int i = 0; i < 3; ++i) {
-        fext[b][i] = Dual(fb[i]);
-        fext[b][3 + i] = Dual(nb2[i]);
+      for (int k = 0; k < ncon; ++k) {
+        const EmpcContact& ct = set.contacts[k];
+        const int b = m.frame_body[ct.frame];
+        const double* lk = lam + coff[k];
+        double fl[3] = {lk[0], lk[1], lk[2]}, fn[3] = {0, 0, 0};
+        if (cnr[k] == 6) {
+          fn[0] = lk[3];
+          fn[1] = lk[4];
+          fn[2] = lk[5];
+        }
+        double fb[3], nb_[3], nb2[3], rxf[3];
+        matvec3<double>(m.frame_R[ct.frame], fl, fb);
+        matvec3<double>(m.frame_R[ct.frame], fn, nb_);
+        cross3<double>(m.frame_p[ct.frame], fb, rxf);
+        for (int i = 0; i < 3; ++i) nb2[i] = nb_[i] + rxf[i];
+        for (int i = 0; i < 3; ++i) {
+          fext[b][i] = fext[b][i] + Dual(fb[i]);
+          fext[b][3 + i] = fext[b][3 + i] + Dual(nb2[i]);
+        }
       }
     }
     rnea<Dual>(m, ds.R0, ds.p0, ds.cs, ds.sn, ds.v, ad, fext, taud, *kd);
     for (int r = 0; r < nv; ++r)
       for (int c = 0; c < ndx; ++c) dtau_dx[r * ndx + c] = taud[r].d[c];
     if (use_contact) {
-      const EmpcContact& ct = set.contacts[0];
       Kin<Dual>* kd0 = &kd0_s;
       forward_kin<Dual>(m, ds.R0, ds.p0, ds.cs, ds.sn, ds.v, ad, false, *kd0);
-      FrameKin<Dual> fk;
-      frame_kin<Dual>(m, *kd0, ct.frame, fk);
-      Dual con[6];
-      if (nc == 3) {
-        Dual wxv[3];
-        cross3<Dual>(fk.v + 3, fk.v, wxv);
-        for (int r = 0; r < 3; ++r) con[r] = fk.a[r] + wxv[r];
-      } else {
-        for (int r = 0; r < 6; ++r) con[r] = fk.a[r];
-      }
-      if (ct.gains[1] != 0.0)
-        for (int r = 0; r < nc; ++r) con[r] += ct.gains[1] * fk.v[r];
-      if (ct.gains[0] != 0.0 && nc == 3)  // derivative: gains[0] * oRf * fJf.topRows<3>() (ContactModel3D::calcDiff)
-        for (int r = 0; r < 3; ++r) con[r] += ct.gains[0] * (fk.p[r] - ct.ref_p[r]);
-      for (int r = 0; r < nc; ++r)
-        for (int c = 0; c < ndx; ++c) dcon_dx[r * ndx + c] = con[r].d[c];
-      if (ct.gains[0] != 0.0 && nc == 6) {
-        // ContactModel6D::calcDiff: da0_dq += gains[0] * Jlog6(rMf) * fJf, rMf = Mref^-1 oMf, fJf the LOCAL frame Jacobian
-        double rR[9], dp[3], rp[3], xi[6], J6[36];
-        matTmul3<double>(ct.ref_R, cfk.R, rR);
-        for (int r = 0; r < 3; ++r) dp[r] = cfk.p[r] - ct.ref_p[r];
-        matTvec3<double>(ct.ref_R, dp, rp);
-        log6(rR, rp, xi);
-        Jlog6(xi, J6);
-        for (int r = 0; r < 6; ++r)
-          for (int c = 0; c < nv; ++c) {
-            double acc = 0;
-            for (int l = 0; l < 6; ++l) acc += J6[r * 6 + l] * Jc[l * nv + c];
-            dcon_dx[r * ndx + c] += ct.gains[0] * acc;
-          }
+      for (int k = 0; k < ncon; ++k) {
+        const EmpcContact& ct = set.contacts[k];
+        const FrameKin<double>& cfk = cfks[k];
+        const int nk = cnr[k], o = coff[k];
+        FrameKin<Dual> fk;
+        frame_kin<Dual>(m, *kd0, ct.frame, fk);
+        Dual con[6];
+        if (nk == 3) {
+          Dual wxv[3];
+          cross3<Dual>(fk.v + 3, fk.v, wxv);
+          for (int r = 0; r < 3; ++r) con[r] = fk.a[r] + wxv[r];
+        } else {
+          for (int r = 0; r < 6; ++r) con[r] = fk.a[r];
+        }
+        if (ct.gains[1] != 0.0)
+          for (int r = 0; r < nk; ++r) con[r] += ct.gains[1] * fk.v[r];
+        if (ct.gains[0] != 0.0 && nk == 3)  // derivative: gains[0] * oRf * fJf.topRows<3>() (ContactModel3D::calcDiff)
+          for (int r = 0; r < 3; ++r) con[r] += ct.gains[0] * (fk.p[r] - ct.ref_p[r]);
+        for (int r = 0; r < nk; ++r)
+          for (int c = 0; c < ndx; ++c) dcon_dx[(o + r) * ndx + c] = con[r].d[c];
+        if (ct.gains[0] != 0.0 && nk == 6) {
+          // ContactModel6D::calcDiff: da0_dq += gains[0] * Jlog6(rMf) * fJf, rMf = Mref^-1 oMf, fJf the LOCAL frame Jacobian
+          double rR[9], dp[3], rp[3], xi[6], J6[36];
+          matTmul3<double>(ct.ref_R, cfk.R, rR);
+          for (int r = 0; r < 3; ++r) dp[r] = cfk.p[r] - ct.ref_p[r];
+          matTvec3<double>(ct.ref_R, dp, rp);
+          log6(rR, rp, xi);
+          Jlog6(xi, J6);
+          for (int r = 0; r < 6; ++r)
+            for (int c = 0; c < nv; ++c) {
+              double acc = 0;
+              for (int l = 0; l < 6; ++l) acc += J6[r * 6 + l] * Jc[(o + l) * nv + c];
+              dcon_dx[(o + r) * ndx + c] += ct.gains[0] * acc;
+            }
+        }
       }
     }
   }
 
   // da/dx (nv x ndx), da/du (nv x nu) -> caller; dlam/dx, dlam/du
-  double dl_dx[6 * NDX], dl_du[6 * NU];
+  double dl_dx[NCM * NDX], dl_du[NCM * NU];
   if (diff) {
     // actuation derivative dtau/ds = B diag(sigma')
     double dtau_du[NV * NU];
@@ -382,7 +399,7 @@ inline void dam_eval(const Problem& P, int t, const double* x, const double* u_i
           for (int i = 0; i < nv; ++i) dA[i * n + c] = col[i];
         } else {
           // KKT: [M Jc^T; Jc 0][da; -dlam] = [rhs_tau; -rhs_con]
-          double y[6];
+          double y[NCM];
           for (int r = 0; r < nc; ++r) {
             double acc = rhs_con ? rhs_con[r * n + c] : 0.0;
             for (int i = 0; i < nv; ++i) acc += Jc[r * nv + i] * col[i];
@@ -392,7 +409,7 @@ inline void dam_eval(const Problem& P, int t, const double* x, const double* u_i
           for (int r = 0; r < nc; ++r) dLam[r * n + c] = y[r];
           for (int i = 0; i < nv; ++i) {
             double acc = col[i];
-            for (int r = 0; r < nc; ++r) acc += MinvJt[i * 6 + r] * y[r];
+            for (int r = 0; r < nc; ++r) acc += MinvJt[i * NCM + r] * y[r];
             dA[i * n + c] = acc;
           }
         }
@@ -547,22 +564,27 @@ inline void dam_eval(const Problem& P, int t, const double* x, const double* u_i
             AR[i][j] = acc;
           }
         const bool has = use_contact;
+        // the force of the contact on the cost's frame (crocoddyl's residual data looks the contact up by frame id);
+        // a stage with one contact keeps that contact whatever the cost's frame says (behaviour of rounds 1-5)
+        int fo = 0;
+        for (int k = 0; k < ncon; ++k)
+          if (ncon > 1 && set.contacts[k].frame == c.frame) fo = coff[k];
         for (int i = 0; i < 5; ++i) {
           double acc = 0;
           if (has)
-            for (int l = 0; l < 3; ++l) acc += AR[i][l] * lam[l];
+            for (int l = 0; l < 3; ++l) acc += AR[i][l] * lam[fo + l];
           r[i] = acc;
         }
         if (diff && has) {
           for (int i = 0; i < 5; ++i) {
             for (int j = 0; j < ndx; ++j) {
               double acc = 0;
-              for (int l = 0; l < 3; ++l) acc += AR[i][l] * dl_dx[l * ndx + j];
+              for (int l = 0; l < 3; ++l) acc += AR[i][l] * dl_dx[(fo + l) * ndx + j];
               Rx[i * ndx + j] = acc;
             }
             for (int j = 0; j < nu; ++j) {
               double acc = 0;
-              for (int l = 0; l < 3; ++l) acc += AR[i][l] * dl_du[l * nu + j];
+              for (int l = 0; l < 3; ++l) acc += AR[i][l] * dl_du[(fo + l) * nu + j];
               Ru[i * nu + j] = acc;
             }
           }
@@ -736,7 +758,7 @@ inline void node_calc_rk4(const Problem& P, int t, const double* x, const double
   const double cscale = (terminal && !P.prm.terminal_dt_scaling) ? 1.0 / 6.0 : dt / 6.0;
   D.cost = (ell[0] + 2.0 * ell[1] + 2.0 * ell[2] + ell[3]) * cscale;
   for (int j = 0; j < nv; ++j) D.xout[j] = S[0].xout[j];
-  for (int j = 0; j < 6; ++j) D.lambda[j] = S[0].lambda[j];
+  for (int j = 0; j < NCM; ++j) D.lambda[j] = S[0].lambda[j];
   for (int j = 0; j < nu; ++j) D.u_squash[j] = S[0].u_squash[j];
   if (!diff) return;
   // dk_i/dx (n x n), dk_i/du (n x nu), dy_i/dx, dy_i/du

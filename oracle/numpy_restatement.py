@@ -413,30 +413,41 @@ def dam(P, cset, x, s, smooth, terminal):
     u = squash(P, s, smooth) if P.d.use_squash else s
     tau = np.concatenate([P.tau_f @ u[:P.nrot], u[P.nrot:]])
     use_contact = bool(P.d.has_contact) and len(cset["contacts"]) > 0
-    lam = np.zeros(6, dtype=complex)
+    lam = np.zeros(12, dtype=complex)
+    coff = []
     R, p, X, vel, acc0 = kinematics(md, q, v, np.zeros(P.nv), gravity=False)
     if not use_contact:
         a = aba(md, q, v, tau)
     else:
-        ct = cset["contacts"][0]
-        nc = 3 if ct["type"] == 0 else 6
-        Rf, pf, vf, af, Xf = frame_kin(md, ct["frame"], R, p, vel, acc0)
-        J = np.zeros((nc, P.nv), dtype=complex)
+        # ContactModelMultiple (src/stage.cpp:38-48): the rows of every contact of the stage stacked in the stage's order
+        Js, a0s = [], []
+        unit_vel = []
         for j in range(P.nv):
             e = np.zeros(P.nv)
             e[j] = 1.0
-            _, _, _, velj, _ = kinematics(md, q, e, np.zeros(P.nv), gravity=False)
-            J[:, j] = (Xf @ velj[md.frame_body[ct["frame"]]])[:nc]
-        a0 = af[:nc].copy()
-        if nc == 3:
-            a0 = a0 + np.cross(vf[3:], vf[:3])
-        if ct["gains"][0] != 0.0:
+            unit_vel.append(kinematics(md, q, e, np.zeros(P.nv), gravity=False)[3])
+        for ct in cset["contacts"]:
+            nc = 3 if ct["type"] == 0 else 6
+            coff.append(sum(len(x_) for x_ in a0s))
+            Rf, pf, vf, af, Xf = frame_kin(md, ct["frame"], R, p, vel, acc0)
+            J = np.zeros((nc, P.nv), dtype=complex)
+            for j in range(P.nv):
+                J[:, j] = (Xf @ unit_vel[j][md.frame_body[ct["frame"]]])[:nc]
+            a0 = af[:nc].copy()
             if nc == 3:
-                a0 = a0 + ct["gains"][0] * (pf - ct["ref_p"])
-            else:
-                a0 = a0 + ct["gains"][0] * log6(ct["ref_R"].T @ Rf, ct["ref_R"].T @ (pf - ct["ref_p"]))
-        if ct["gains"][1] != 0.0:
-            a0 = a0 + ct["gains"][1] * vf[:nc]
+                a0 = a0 + np.cross(vf[3:], vf[:3])
+            if ct["gains"][0] != 0.0:
+                if nc == 3:
+                    a0 = a0 + ct["gains"][0] * (pf - ct["ref_p"])
+                else:
+                    a0 = a0 + ct["gains"][0] * log6(ct["ref_R"].T @ Rf, ct["ref_R"].T @ (pf - ct["ref_p"]))
+            if ct["gains"][1] != 0.0:
+                a0 = a0 + ct["gains"][1] * vf[:nc]
+            Js.append(J)
+            a0s.append(a0)
+        J = np.vstack(Js)
+        a0 = np.concatenate(a0s)
+        nc = len(a0)
         M = mass_matrix(md, q)
         h = rnea(md, q, v, np.zeros(P.nv))
         KKT = np.zeros((P.nv + nc, P.nv + nc), dtype=complex)
@@ -470,7 +481,12 @@ def dam(P, cset, x, s, smooth, terminal):
             else:
                 r = vf - c["ref"][:6]
         else:
-            r = cone_matrix(c) @ lam[:3] if use_contact else np.zeros(5, dtype=complex)
+            fo = 0  # the force of the contact on the cost's frame (one contact: that contact, whatever the frame)
+            if use_contact and len(cset["contacts"]) > 1:
+                for k, ct in enumerate(cset["contacts"]):
+                    if ct["frame"] == c["frame"]:
+                        fo = coff[k]
+            r = cone_matrix(c) @ lam[fo:fo + 3] if use_contact else np.zeros(5, dtype=complex)
         val, _, _ = activation(c, r)
         ell = ell + c["weight"] * val
         items.append((c, _c(r)))

@@ -61,6 +61,32 @@ def contact_variant(empc, tmp_path, contact="ContactModel3D", gains=(0.0, 0.0), 
     return tr, tr.createProblem(dt, squash, integrator)
 
 
+def two_contact_variant(empc, tmp_path, second="ContactModel3D", gains=(0.0, 0.0), gains2=(0.0, 0.0), dt=32,
+                        integrator="IntegratedActionModelEuler", link2="flying_arm_3__link_2", squash=True, cone_on_second=False):
+    """eagle_catch with a SECOND contact in its grasp stage (src/stage.cpp:38-48 adds every name of the stage's `contacts` list
+    to one ContactModelMultiple; no shipped YAML lists more than one).  The new contact is called "elbow": crocoddyl's
+    name-sorted map puts it BEFORE "end_effector", so its rows come first in the stacked Jacobian.  Returns (trajectory, problem)."""
+    src = open(empc.yaml_path(CONFIGS["eagle_catch"][0])).read()
+    old = '          type: "ContactModel3D"\n          link_name: "flying_arm_3__gripper"\n          position: [0, 0, 0]\n          gains: [0, 0]\n'
+    assert src.count(old) == 1
+    new = '          type: "ContactModel3D"\n          link_name: "flying_arm_3__gripper"\n          position: [0, 0, 0]\n'
+    new += '          gains: [%r, %r]\n' % (float(gains[0]), float(gains[1]))
+    new += '        - name: "elbow"\n          type: "%s"\n          link_name: "%s"\n          position: [0.1, -0.05, 0.2]\n' % (second, link2)
+    if second == "ContactModel6D":
+        new += '          orientation: [0, 0, 0, 1]\n'
+    new += '          gains: [%r, %r]\n' % (float(gains2[0]), float(gains2[1]))
+    src = src.replace(old, new)
+    if cone_on_second:  # the friction cone reads the force of the contact on ITS frame (crocoddyl looks the contact up by frame id)
+        old_c = '          mu: 0.7\n          link_name: "flying_arm_3__gripper"\n'
+        assert src.count(old_c) == 1
+        src = src.replace(old_c, '          mu: 0.7\n          link_name: "%s"\n' % link2)
+    f = tmp_path / ("eagle_catch_two_%s_%g_%g_%g_%g_%d.yaml" % (second, gains[0], gains[1], gains2[0], gains2[1], int(cone_on_second)))
+    f.write_text(src)
+    tr = empc.Trajectory()
+    tr.autoSetup(str(f))
+    return tr, tr.createProblem(dt, squash, integrator)
+
+
 def unweighted_barrier_variant(empc, tmp_path, dt=80):
     """displacement with every `limits_state` cost switched from ActivationModelWeightedQuadraticBarrier to the unweighted
     ActivationModelQuadraticBarrier (src/factory/activation.cpp:53-68: bounds only, `weights` ignored) and bounds on every
@@ -135,6 +161,22 @@ def arm5_contact_variant(empc, tmp_path, contact="ContactModel3D", gains=(0.0, 0
         g0=float(gains[0]), g1=float(gains[1]))
     f = tmp_path / ("arm5_%s_%g_%g.yaml" % (contact, gains[0], gains[1]))
     f.write_text(src)
+    tr = empc.Trajectory()
+    tr.autoSetup(str(f))
+    return tr, tr.createProblem(dt, True, "IntegratedActionModelEuler")
+
+
+def arm5_two_contact_variant(empc, tmp_path, gains=(0.0, 0.0), gains2=(0.0, 0.0), dt=26, link2="flying_arm_5__link_3"):
+    """arm5_contact_variant with a SECOND ContactModel3D ("elbow", on `link2`) in the appended stage: two contacts per stage
+    (src/stage.cpp:38-48) on the (6, 6) robot class -- 64-lane linearize units (empc_inst_6_6_contact_pair.hip; opt-in)."""
+    src = open(empc.yaml_path(CONFIGS["push_slide"][0])).read()
+    src = src.replace("duration: 2000 #ms", "duration: 1040 #ms")
+    assert src.count("duration: 1040 #ms") == 1
+    stage = ARM5_CONTACT_STAGE % dict(contact="ContactModel3D", orientation="", g0=float(gains[0]), g1=float(gains[1]))
+    stage = stage.rstrip("\n") + ('\n        - name: "elbow"\n          type: "ContactModel3D"\n          link_name: "%s"\n'
+                                  '          position: [0.3, 0.0, 0.9]\n          gains: [%r, %r]\n' % (link2, float(gains2[0]), float(gains2[1])))
+    f = tmp_path / ("arm5_two_%g_%g_%g_%g.yaml" % (gains[0], gains[1], gains2[0], gains2[1]))
+    f.write_text(src.rstrip("\n") + "\n" + stage)
     tr = empc.Trajectory()
     tr.autoSetup(str(f))
     return tr, tr.createProblem(dt, True, "IntegratedActionModelEuler")

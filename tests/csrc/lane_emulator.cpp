@@ -203,9 +203,13 @@ static void emu_alloc(Emu& e) {
 }
 
 // constraint rows of the contact of knot t: the problem's, or the knot's own in a problem with stages of both types
+// robot classes with a two-contact (CT_PAIR3) instantiation, as in the product (empc_solver.hip find_table)
+template <class DM>
+constexpr bool emu_pair_class() { return (DM::NB == 4 || DM::NB == 6) && DM::NROT == 6; }
 static int emu_knot_rows(const Emu& e, int t) {
-  if (e.H.contact_rows != CT_MIXED) return e.H.contact_rows;
   const EmpcCostSet& set = e.H.sets[e.H.knot_set[t]];
+  if (e.H.contact_rows == CT_PAIR3) return set.ncontacts > 1 ? CT_PAIR3 : 3;  // (as lin_block: the six-row body on two-contact knots)
+  if (e.H.contact_rows != CT_MIXED) return e.H.contact_rows;
   return (set.ncontacts > 0 && set.contacts[0].type == EMPC_CONTACT_6D) ? 6 : 3;
 }
 template <class DM>
@@ -215,7 +219,9 @@ static void emu_calc(Emu& e) {
     for (int t = 0; t <= e.T; ++t) {
       if constexpr (true) {  // (every robot class has contact instantiations since round 4)
         if (ct) {
-          if (e.H.contact_rows == CT_MIXED) {
+          if (e.H.contact_rows == CT_PAIR3) {
+            if constexpr (emu_pair_class<DM>()) calc_thread<DM, CT_PAIR3>(e.D, b, t);
+          } else if (e.H.contact_rows == CT_MIXED) {
             calc_thread<DM, CT_MIXED>(e.D, b, t);
           } else if (e.H.contact_rows == 6) {
             calc_thread<DM, 6>(e.D, b, t);
@@ -244,7 +250,9 @@ static void emu_linearize_rk4(Emu& e) {
     for (int b = 0; b < e.B; ++b) {
       if constexpr (true) {  // (every robot class has contact instantiations since round 4)
         if (ct) {
-          if (e.H.contact_rows == CT_MIXED) {
+          if (e.H.contact_rows == CT_PAIR3) {
+            if constexpr (emu_pair_class<DM>()) rk4_stage_thread<DM, CT_PAIR3>(e.D, R, b, t);
+          } else if (e.H.contact_rows == CT_MIXED) {
             rk4_stage_thread<DM, CT_MIXED>(e.D, R, b, t);
           } else if (e.H.contact_rows == 6) {
             rk4_stage_thread<DM, 6>(e.D, R, b, t);
@@ -297,12 +305,16 @@ static void emu_linearize_view(Emu& e, const DevBuffers& Dl) {
         if (e.H.P.has_contact) {
           CpuExec<64> ex{LPUC};
           constexpr int LPU = LPUC;
-          if (emu_knot_rows(e, t) == 6) {
+          if (emu_knot_rows(e, t) == CT_PAIR3) {
+            if constexpr (emu_pair_class<DM>()) linearize_unit2<DM, CT_PAIR3, false>(ex, Dl, b, t, LPU, smem.data());
+          } else if (emu_knot_rows(e, t) == 6) {
             linearize_unit2<DM, 6, false>(ex, Dl, b, t, LPU, smem.data());
           } else {
             linearize_unit2<DM, 3, false>(ex, Dl, b, t, LPU, smem.data());
           }
-          if (emu_knot_rows(e, t) == 6) {
+          if (emu_knot_rows(e, t) == CT_PAIR3) {
+            if constexpr (emu_pair_class<DM>()) linearize_unit2<DM, CT_PAIR3, true>(ex, Dl, b, t, LPU, smem.data());
+          } else if (emu_knot_rows(e, t) == 6) {
             linearize_unit2<DM, 6, true>(ex, Dl, b, t, LPU, smem.data());
           } else {
             linearize_unit2<DM, 3, true>(ex, Dl, b, t, LPU, smem.data());
@@ -356,11 +368,13 @@ static void emu_rollout(Emu& e) {
   if ((g_roll_version == 6 || (g_roll_version == 5 && e.H.P.prm.solver_type != EMPC_SOLVER_SBFDDP)) && e.NA <= MAX_ALPHAS) {
     // the shipped form: packed trajectories, role wavefronts (Euler nodes, and RK4 nodes as four stages per knot)
     const int G = roll6_group_size(e.NA);
-    std::vector<double> smem6(Roll6Smem<DM>::SIZE);
+    std::vector<double> smem6(Roll6Smem<DM>::size_for(CT_PAIR3));
     for (int grp = 0; grp * G < e.B; ++grp) {
       if constexpr (true) {  // (every robot class has contact instantiations since round 4)
         if (ct) {
-          if (e.H.contact_rows == CT_MIXED) {
+          if (e.H.contact_rows == CT_PAIR3) {
+            if constexpr (emu_pair_class<DM>()) emu_rollout_group6<DM, CT_PAIR3>(e.D, grp, smem6.data());
+          } else if (e.H.contact_rows == CT_MIXED) {
             emu_rollout_group6<DM, CT_MIXED>(e.D, grp, smem6.data());
           } else if (e.H.contact_rows == 6) {
             emu_rollout_group6<DM, 6>(e.D, grp, smem6.data());
@@ -376,7 +390,7 @@ static void emu_rollout(Emu& e) {
   }
   for (int b = 0; b < e.B; ++b)
     for (int ai = 0; ai < e.NA; ++ai) {
-      if (g_roll_version >= 5 && e.H.P.integrator == EMPC_INTEGRATOR_EULER) {
+      if (g_roll_version >= 5 && e.H.P.integrator == EMPC_INTEGRATOR_EULER && e.H.contact_rows != CT_PAIR3) {  // (the retired wave form has no two-contact body)
         if (ai > 0) continue;  // one call per trajectory: the 64 lanes cover every step length
         std::vector<double> smem5(Roll5Smem<DM>::SIZE);
         CpuExec<64> ex{64};
@@ -397,7 +411,9 @@ static void emu_rollout(Emu& e) {
       }
       if constexpr (true) {  // (every robot class has contact instantiations since round 4)
         if (ct) {
-          if (e.H.contact_rows == CT_MIXED) {
+          if (e.H.contact_rows == CT_PAIR3) {
+            if constexpr (emu_pair_class<DM>()) rollout_thread<DM, CT_PAIR3>(e.D, b, ai);
+          } else if (e.H.contact_rows == CT_MIXED) {
             rollout_thread<DM, CT_MIXED>(e.D, b, ai);
           } else if (e.H.contact_rows == 6) {
             rollout_thread<DM, 6>(e.D, b, ai);
@@ -543,7 +559,9 @@ static void emu_node(Emu& e, int t, const double* x, const double* u, double smo
   double c = 0;
   if constexpr (true) {  // (every robot class has contact instantiations since round 4)
     if (e.H.P.has_contact) {
-      if (e.H.contact_rows == CT_MIXED) {
+      if (e.H.contact_rows == CT_PAIR3) {
+        if constexpr (emu_pair_class<DM>()) node_nominal<DM, CT_PAIR3>(e.H.P, set, smooth, x, u, u == nullptr, xnext, acc, c, usq, lam);
+      } else if (e.H.contact_rows == CT_MIXED) {
         node_nominal<DM, CT_MIXED>(e.H.P, set, smooth, x, u, u == nullptr, xnext, acc, c, usq, lam);
       } else if (e.H.contact_rows == 6) {
         node_nominal<DM, 6>(e.H.P, set, smooth, x, u, u == nullptr, xnext, acc, c, usq, lam);

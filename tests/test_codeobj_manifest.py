@@ -22,7 +22,9 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 # objects whose kernels have not run on hardware: reachable only with the named environment switch (empc_solver.hip find_table)
 OPT_IN = {"empc_inst_1_4_contact.o": "EMPC_EXPERIMENTAL_CONTACT", "empc_inst_1_6_contact.o": "EMPC_EXPERIMENTAL_CONTACT",
-          "empc_inst_3_6_contact.o": "EMPC_EXPERIMENTAL_CONTACT", "empc_inst_6_6_contact_mixed.o": "EMPC_EXPERIMENTAL_CONTACT"}
+          "empc_inst_3_6_contact.o": "EMPC_EXPERIMENTAL_CONTACT", "empc_inst_6_6_contact_mixed.o": "EMPC_EXPERIMENTAL_CONTACT",
+          # two ContactModel3D per stage (CT_PAIR3, round 6)
+          "empc_inst_4_6_contact_pair.o": "EMPC_EXPERIMENTAL_CONTACT", "empc_inst_6_6_contact_pair.o": "EMPC_EXPERIMENTAL_CONTACT"}
 
 
 def test_shipped_device_code_is_the_hardware_verified_one():

@@ -185,7 +185,7 @@ def test_unweighted_quadratic_barrier_kernel_bodies(empc, emu, tmp_path):
     kernel_bodies(emu, problem, "displacement", 2, 4, 6)
 
 
-def kernel_bodies(emu, problem, name, lin, bwd, roll):
+def kernel_bodies(emu, problem, name, lin, bwd, roll, tape_tol=1e-11, gain_tol=1e-6, vx_tol=1e-8):
     d = problem.desc
     prm = ob.default_params()
     emu.emu_set_linearize_version(lin)
@@ -222,7 +222,7 @@ def kernel_bodies(emu, problem, name, lin, bwd, roll):
         for key in got:
             if t == T and key in ("Fx", "Fu", "Lxu", "Luu", "Lu"):
                 continue
-            assert rel(np.asarray(got[key]).ravel(), np.asarray(ref[key]).ravel()) < 1e-11, (t, key)
+            assert rel(np.asarray(got[key]).ravel(), np.asarray(ref[key]).ravel()) < tape_tol, (t, key)
     ok, Ko, ko, Vxo, _, dgo = o.phase_backward(1e-9)
     K = np.zeros((T, m, n))
     k = np.zeros((T, m))
@@ -233,7 +233,7 @@ def kernel_bodies(emu, problem, name, lin, bwd, roll):
     ce = np.zeros(1)
     emu.emu_phase_backward(e, ob.P(K), ob.P(k), ob.P(Vx), ob.P(dg), oke.ctypes.data_as(_ip), fe.ctypes.data_as(_ip), ob.P(ce))
     assert ok and oke[0] == 1 and fe[0] == int(feas)
-    assert rel(K, Ko) < 1e-6 and rel(k, ko) < 1e-6 and rel(Vx, Vxo) < 1e-8 and np.allclose(dg, dgo, rtol=1e-7)
+    assert rel(K, Ko) < gain_tol and rel(k, ko) < gain_tol and rel(Vx, Vxo) < vx_tol and np.allclose(dg, dgo, rtol=1e-7 * max(1.0, gain_tol / 1e-6))
     assert abs(ce[0] - cost_o) < 1e-10 * (1 + abs(cost_o))
     for ai in (2, 4):
         oko, xo, uo, co, d01 = o.phase_forward(2.0 ** -ai)
@@ -337,6 +337,12 @@ def test_rk4_kernel_bodies_vs_oracle(empc, emu, name, dt):
     tr = empc.Trajectory()
     tr.autoSetup(empc.yaml_path(CONFIGS[name][0]))
     problem = tr.createProblem(dt, True, "IntegratedActionModelRK4")
+    kernel_bodies_rk4(emu, problem, name)
+
+
+def kernel_bodies_rk4(emu, problem, name="eagle_catch", tape_tol=1e-10, seed=3):
+    """phases of an RK4 problem against the oracle; a whole solve as well unless `name` is eagle_catch (contact problems: too slow
+    lane by lane)"""
     d = problem.desc
     prm = ob.default_params()
     emu.emu_set_linearize_version(2)
@@ -347,7 +353,7 @@ def test_rk4_kernel_bodies_vs_oracle(empc, emu, name, dt):
     o = ob.OracleSolver(d)
     T, nx, ndx, nu, nv = d.T, d.nx, d.ndx, d.nu, d.model.nv
     rec = emu.emu_rec(e)
-    xs, us = candidate(d, 3, scale=0.1)
+    xs, us = candidate(d, seed, scale=0.1)
     o.set_smooth(0.1)
     cost_o, fs, feas = o.phase_calcdiff(xs, us)
     emu.emu_set_warmstart(e, ob.P(xs), ob.P(us))
@@ -373,7 +379,7 @@ def test_rk4_kernel_bodies_vs_oracle(empc, emu, name, dt):
         for key in got:
             if t == T and key in ("Fx", "Fu", "Lxu", "Luu", "Lu"):
                 continue
-            assert rel(np.asarray(got[key]).ravel(), np.asarray(ref[key]).ravel()) < 1e-10, (t, key)
+            assert rel(np.asarray(got[key]).ravel(), np.asarray(ref[key]).ravel()) < tape_tol, (t, key)
     ok, Ko, ko, Vxo, _, dgo = o.phase_backward(1e-9)
     K = np.zeros((T, m, n))
     k = np.zeros((T, m))

@@ -1,0 +1,200 @@
+"""Several contacts per stage: src/stage.cpp:38-48 adds EVERY name of a stage's `contacts` list to one
+ContactModelMultiple, whose rows crocoddyl stacks in the order of its name-sorted map into one KKT system.  No shipped YAML lists
+more than one; the factory accepts any number.  Here: eagle_catch with a second ContactModel3D ("elbow", on link 2) in its grasp
+stage -- six stacked rows --
+  * the C++ oracle against the NumPy second restatement (dense stacked KKT, complex-step derivatives) at 1e-10, Euler and RK4 nodes,
+    Baumgarte gains, the friction cone reading the force of the contact on ITS frame;
+  * the kernel bodies of the CT_PAIR3 instantiation (csrc/empc_dev_model.hpp contact_forward_pair3, the pair paths of
+    empc_linearize2.hpp / empc_rollout6.hpp / empc_prep.hpp) on the CPU lane emulator against the oracle: tape 1e-9, gains 1e-6,
+    trial rollouts 1e-7, the per-lane nominal evaluation 1e-9 -- the tolerances of the single-contact classes.
+The GPU edition is tests/test_zz_gpu_two_contacts.py (opt-in: these kernels have never run on hardware)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from conftest import arm5_two_contact_variant, two_contact_variant
+from test_emulator_parity import emu, kernel_bodies, rel  # noqa: F401  (emu: the fixture that builds / binds the emulator)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+KEYS = ("xnext", "cost", "acc", "lam", "u_squash", "Fx", "Fu", "Lx", "Lu", "Lxx", "Lxu", "Luu")
+
+# Tape tolerance: the parity contract's 1e-9 (tests/test_gpu_parity.py).  The single-contact emulator tests hold 1e-11; the six-row
+# KKT system of a random candidate is worse conditioned (measured: 1.4e-11 on Fx of the first grasp knot).
+TAPE_TOL = 1e-9
+
+# (gains of "end_effector", gains of "elbow", friction cone on the second contact's frame)
+OPTIONS = [((0.0, 0.0), (0.0, 0.0), False), ((3.0, 1.5), (2.0, 0.7), True)]
+
+
+def gain_yardstick(problem):
+    """Tolerances of the backward pass for kernel_bodies: the usual 1e-6 / 1e-8, widened to three times what the oracle's OWN
+    FMA-contracted build (liboracle_fma.so: the same source, another correct compiler) differs from the oracle by on the same
+    candidate.  With the friction cone on the elbow contact the barrier is inactive on this candidate, Luu is 1e2 beside a Vxx of
+    1e11, and Quu^-1 turns the tape's last bits into 2.4e-5 of K between the two oracle builds (measured; the emulator: 2.6e-5)."""
+    from test_emulator_parity import candidate
+    d = problem.desc
+    res = []
+    for variant in (None, "fma"):
+        o = ob.OracleSolver(d, variant=variant)
+        xs, us = candidate(d, 3)
+        o.set_smooth(0.1)
+        o.phase_calcdiff(xs, us)
+        ok, K, k, Vx, _, _ = o.phase_backward(1e-9)
+        assert ok
+        res.append((K, k, Vx))
+    yk = max(rel(res[0][0], res[1][0]), rel(res[0][1], res[1][1]))
+    yv = rel(res[0][2], res[1][2])
+    return dict(gain_tol=max(1e-6, 3 * yk), vx_tol=max(1e-8, 3 * yv))
+
+
+def random_node(problem, d, rng):
+    x = np.array(problem.x0)
+    x[:3] += rng.normal(size=3) * 0.2
+    q = x[3:7] + rng.normal(size=4) * 0.3
+    x[3:7] = q / np.linalg.norm(q)
+    x[7:] += rng.normal(size=d.nx - 7) * 0.4
+    u = rng.uniform(1, 8, size=d.nu)
+    u[d.n_rotors:] = rng.normal(size=d.nu - d.n_rotors) * 0.3
+    return x, u
+
+
+@pytest.mark.parametrize("integrator", ["IntegratedActionModelEuler", "IntegratedActionModelRK4"])
+@pytest.mark.parametrize("gains,gains2,cone2", OPTIONS)
+def test_oracle_two_contacts_vs_second_restatement(empc, tmp_path, integrator, gains, gains2, cone2):
+    import numpy_restatement as nr
+    _, problem = two_contact_variant(empc, tmp_path, "ContactModel3D", gains, gains2, integrator=integrator, cone_on_second=cone2)
+    d = problem.desc
+    prm = ob.default_params()
+    smooth = 0.07
+    P = nr.Problem(d, prm)
+    sets = nr.cost_sets_of(d, prm, smooth)
+    o = ob.OracleSolver(d, prm)
+    o.set_smooth(smooth)
+    knots = [t for t in range(d.T + 1) if len(sets[d.knot_set[t]]["contacts"]) == 2]
+    assert len(knots) >= 3
+    # the stacking order is the name-sorted map's: "elbow" (link 2) before "end_effector" (gripper)
+    f0, f1 = (c["frame"] for c in sets[d.knot_set[knots[0]]]["contacts"])
+    assert f0 != f1
+    rng = np.random.default_rng(5)
+    for t in knots[:2]:
+        x, u = random_node(problem, d, rng)
+        mine = nr.node(P, sets[d.knot_set[t]], x, u, smooth)
+        ref = o.node_calc(t, x, u)
+        assert np.abs(ref["lam"][:6]).min() > 1e-6, "both contacts must carry a force"
+        for key in KEYS:
+            got = ref[key][:6] if key == "lam" else ref[key]
+            want = mine[key][:6] if key == "lam" else mine[key]
+            assert rel(np.ravel(got), np.ravel(np.asarray(want, dtype=float))) < 1e-10, (t, key)
+
+
+def test_oracle_refuses_nothing_it_cannot_solve(empc, tmp_path):
+    """6D + 3D on the 9-dof arm: Jc M^-1 Jc^T is singular (nine rows on a tree with nine degrees of freedom, one body pinned twice);
+    the second restatement's dense solve says so -- the reason the kernels take two ContactModel3D only."""
+    import numpy_restatement as nr
+    _, problem = two_contact_variant(empc, tmp_path, "ContactModel6D")
+    d = problem.desc
+    prm = ob.default_params()
+    P = nr.Problem(d, prm)
+    sets = nr.cost_sets_of(d, prm, 0.07)
+    t = [t for t in range(d.T + 1) if len(sets[d.knot_set[t]]["contacts"]) == 2][0]
+    x, u = random_node(problem, d, np.random.default_rng(1))
+    with pytest.raises(np.linalg.LinAlgError):
+        nr.node(P, sets[d.knot_set[t]], x, u, 0.07)
+
+
+@pytest.mark.parametrize("gains,gains2,cone2", OPTIONS)
+def test_two_contact_kernel_bodies_vs_oracle(empc, emu, tmp_path, gains, gains2, cone2):
+    """linearize (six-row body on the grasp knots, three-row / lean bodies elsewhere), backward, role-split rollout of the CT_PAIR3
+    instantiation against the oracle"""
+    _, problem = two_contact_variant(empc, tmp_path, "ContactModel3D", gains, gains2, cone_on_second=cone2)
+    kernel_bodies(emu, problem, "eagle_catch", 2, 4, 6, tape_tol=TAPE_TOL, **gain_yardstick(problem))
+
+
+def test_two_contact_per_lane_forms_vs_oracle(empc, emu, tmp_path):
+    """the per-lane rollout (k_rollout, > 16 step lengths) and the nominal node evaluation (calc kernel, RK4 stage kernel) of
+    the same instantiation"""
+    _, problem = two_contact_variant(empc, tmp_path, "ContactModel3D", (3.0, 1.5), (2.0, 0.7), cone_on_second=True)
+    kernel_bodies(emu, problem, "eagle_catch", 2, 4, 1, tape_tol=TAPE_TOL, **gain_yardstick(problem))
+    d = problem.desc
+    prm = ob.default_params()
+    e = C.c_void_p(emu.emu_create(C.byref(d), C.byref(prm), 1))
+    o = ob.OracleSolver(d, prm)
+    o.set_smooth(0.07)
+    rng = np.random.default_rng(9)
+    pair_knots = [44, 45]  # grasp stage (asserted to hold two contacts by test_oracle_two_contacts_vs_second_restatement)
+    for t in pair_knots[:2] + [10]:
+        x, u = random_node(problem, d, rng)
+        r = o.node_calc(t, x, u, diff=False)
+        xn, acc, cost, usq, lam = np.zeros(d.nx), np.zeros(d.model.nv), np.zeros(1), np.zeros(d.nu), np.zeros(6)
+        emu.emu_node_nominal(e, t, ob.P(x), ob.P(u), 0.07, ob.P(xn), ob.P(acc), ob.P(cost), ob.P(usq), ob.P(lam))
+        assert np.abs(xn - r["xnext"]).max() < 1e-9 and np.abs(acc - r["acc"]).max() < 1e-9 * (1 + np.abs(r["acc"]).max())
+        assert abs(cost[0] - r["cost"]) < 1e-9 * (1 + abs(r["cost"]))
+        assert np.abs(lam - r["lam"][:6]).max() < 1e-9 * (1 + np.abs(r["lam"]).max())
+    emu.emu_destroy(e)
+
+
+def test_two_contact_rk4_kernel_bodies_vs_oracle(empc, emu, tmp_path):
+    """IntegratedActionModelRK4 nodes over the two-contact differential model: stage kernel, raw records of the stage batch
+    through the six-row linearize body, chain rule, four-stage rollout"""
+    from test_emulator_parity import kernel_bodies_rk4
+    _, problem = two_contact_variant(empc, tmp_path, "ContactModel3D", integrator="IntegratedActionModelRK4")
+    # candidate seed 4: on seed 3 (the other tests') the first grasp knot sits next to a singular Jc M^-1 Jc^T -- Fx entries of 9e7
+    # in the oracle, and the same absolute noise (1e-4) on Fu entries of order 1: conditioning of the candidate, not of a kernel
+    kernel_bodies_rk4(emu, problem, seed=4)
+
+
+def test_two_contact_stepwise_parity_on_the_emulator(empc, tmp_path):
+    """The step-wise argument (tests/stepwise.py) on a two-contact problem that converges (second contact on link 1, no gains: 63
+    iterations from the nominal state): every iteration of the oracle's paths reproduced by the CT_PAIR3 kernel bodies from the
+    oracle's iterate (tape 1e-9, gains 1e-6, trial costs 1e-9, every decision exactly), every iteration of the device's own paths
+    reproduced by the oracle, the same minimiser from a common restart."""
+    import stepwise as sw
+    from test_gpu_teacher_forced import check
+    emu_sw = sw.load_emulator()
+    _, problem = two_contact_variant(empc, tmp_path, "ContactModel3D", link2="flying_arm_3__link_1")
+    d = problem.desc
+    prm = ob.default_params()
+    x0s = empc.perturbed_x0s(problem.x0, 2, nq=d.model.nq, amplitude=0.002)
+    rep = sw.stepwise_parity(lambda n, p2: sw.EmuBackend(emu_sw, d, p2 if p2 is not None else prm, n), d, prm, x0s, chunk=64,
+                             tape_every=13, tight=1e-6, tight_maxiter=300)
+    check(rep, max_waived=0.10, min_asserted=100, max_exploded=0)  # (measured: 129 pairs, waived 0.054, 122 asserted)
+    assert rep["same_minimum"]["converged_on_oracle"] >= 1 and rep["same_minimum"]["xs_err_max"] < 1e-6  # (measured 2.0e-8)
+    print("two contacts: pairs", rep["pairs"], "waived", rep["waived_fraction"], "asserted", rep["decisions_asserted"], rep["same_minimum"], rep["max_rel"])
+
+
+def test_two_contact_kernel_bodies_on_the_11_dof_class(empc, emu, tmp_path):
+    """the (6, 6) robot class (hextilt_flying_arm_5): 64-lane linearize units, six-row body on the knots of the appended stage"""
+    _, problem = arm5_two_contact_variant(empc, tmp_path, (2.0, 1.0), (0.0, 3.0))
+    d = problem.desc
+    o = ob.OracleSolver(d)
+    o.set_smooth(0.07)
+    x, u = random_node(problem, d, np.random.default_rng(2))
+    r = o.node_calc(d.T - 3, x, u, diff=False)
+    assert np.abs(r["lam"][:6]).min() > 1e-6, "both contacts must carry a force"
+    kernel_bodies(emu, problem, "eagle_catch", 2, 4, 6, tape_tol=TAPE_TOL, **gain_yardstick(problem))
+
+
+def test_factory_answer_for_two_contact_problems(empc, tmp_path, monkeypatch):
+    """empc_solver_supported: a two-ContactModel3D stage is refused with the reason until the opt-in is set (the six-row kernels
+    have never run on hardware) and accepted with it, on both arm classes; a 6D + 3D pair is refused whatever the switch says,
+    with the reason (six rows are what the kernels and the robots have room for)."""
+    _, p3 = two_contact_variant(empc, tmp_path, "ContactModel3D")
+    _, p5 = arm5_two_contact_variant(empc, tmp_path)
+    _, p6 = two_contact_variant(empc, tmp_path, "ContactModel6D")
+    monkeypatch.delenv("EMPC_EXPERIMENTAL_CONTACT", raising=False)
+    for p in (p3, p5):
+        assert not empc.solver_supported(p) and "EMPC_EXPERIMENTAL_CONTACT" in empc.last_error() and "two contacts" in empc.last_error()
+    monkeypatch.setenv("EMPC_EXPERIMENTAL_CONTACT", "1")
+    for p in (p3, p5):
+        assert empc.solver_supported(p), empc.last_error()
+    assert not empc.solver_supported(p6) and "two ContactModel3D only" in empc.last_error()
+    # the single-contact problem of the same file still takes the shipped three-row instantiation, switch or no switch
+    from conftest import contact_variant
+    _, p1 = contact_variant(empc, tmp_path)
+    monkeypatch.delenv("EMPC_EXPERIMENTAL_CONTACT", raising=False)
+    assert empc.solver_supported(p1), empc.last_error()

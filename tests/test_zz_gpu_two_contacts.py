@@ -1,0 +1,70 @@
+"""Two contacts per stage on the GPU: a ContactModelMultiple with two ContactModel3D entries (src/stage.cpp:38-48 adds every name
+of a stage's `contacts` list; no shipped YAML lists more than one).  Kernel instantiations empc_inst_{4_6,6_6}_contact_pair.hip
+(CT_PAIR3: six stacked rows, one KKT system; the pair paths of empc_dev_model.hpp / empc_linearize2.hpp / empc_rollout6.hpp).
+CPU edition on the lane emulator: tests/test_two_contacts_emulator.py (green)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import stepwise as sw
+from conftest import arm5_two_contact_variant, two_contact_variant
+from test_gpu_parity import phase_parity
+from test_gpu_teacher_forced import check, factory
+
+# Never run on hardware (written in round 6 with the GPU pool closed): skipped unless asked for, in a pytest process of its own
+# (tools/gpu_r5.sh experimental) -- a fault in a new instantiation must not take the whole `pytest -m gpu` process down.  After the
+# first green run on an MI355X the opt-in of the kernels (EMPC_EXPERIMENTAL_CONTACT) and this guard go away together.
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(os.environ.get("EMPC_RUN_EXPERIMENTAL_GPU_TESTS", "") in ("", "0"),
+                                 reason="kernels never run on hardware: set EMPC_RUN_EXPERIMENTAL_GPU_TESTS=1 (tools/gpu_r5.sh experimental)")]
+
+
+@pytest.fixture(autouse=True)
+def _opt_in(monkeypatch):
+    monkeypatch.setenv("EMPC_EXPERIMENTAL_CONTACT", "1")
+
+
+@pytest.mark.parametrize("gains,gains2,cone2", [((0.0, 0.0), (0.0, 0.0), False), ((3.0, 1.5), (2.0, 0.7), True)])
+def test_two_contact_phase_parity(empc, tmp_path, gains, gains2, cone2):
+    """linearize (six-row body on the grasp knots) / backward / role-split rollout against the oracle's calcDiff / backwardPass /
+    forwardPass on the 9-dof arm"""
+    _, problem = two_contact_variant(empc, tmp_path, "ContactModel3D", gains, gains2, cone_on_second=cone2)
+    assert empc.solver_supported(problem), empc.last_error()
+    phase_parity(empc, problem, "two_contacts/%d" % int(cone2))
+
+
+def test_two_contact_phase_parity_rk4_and_arm5(empc, tmp_path):
+    _, problem = two_contact_variant(empc, tmp_path, "ContactModel3D", integrator="IntegratedActionModelRK4")
+    phase_parity(empc, problem, "two_contacts/rk4")
+    _, problem = arm5_two_contact_variant(empc, tmp_path, (2.0, 1.0), (0.0, 3.0))
+    assert empc.solver_supported(problem), empc.last_error()
+    phase_parity(empc, problem, "two_contacts/arm5")
+
+
+def test_two_contact_stepwise(empc, tmp_path):
+    """every iteration of the oracle's paths reproduced by the device and the other way round; bounds from the same driver on the
+    lane emulator (129 pairs of 2 rollouts: waived 0.054) + 0.05, to be replaced by measured + 0.05 after the first hardware run"""
+    _, problem = two_contact_variant(empc, tmp_path, "ContactModel3D", link2="flying_arm_3__link_1")
+    d = problem.desc
+    prm = ob.default_params()
+    x0s = empc.perturbed_x0s(problem.x0, 8, nq=d.model.nq, amplitude=0.002)
+    x0s[0] = problem.x0
+    rep = sw.stepwise_parity(factory(empc, problem, prm), d, prm, x0s, tape_every=13, tight=1e-6)
+    check(rep, max_waived=0.11, min_asserted=300, max_exploded=8)
+    assert rep["same_minimum"]["xs_err_max"] < 1e-4
+
+
+def test_two_contact_solves_are_batch_independent(empc, tmp_path):
+    """a batch of four equals four batches of one, bit for bit, and the runtime-model family runs it (no baked pair tables)"""
+    _, problem = two_contact_variant(empc, tmp_path, "ContactModel3D", link2="flying_arm_3__link_1")
+    d = problem.desc
+    x0s = empc.perturbed_x0s(problem.x0, 4, nq=d.model.nq, amplitude=0.002)
+    s = empc.SolverSbFDDP(problem, batch=4)
+    s.solve([], [], 30, x0s=x0s)
+    assert np.isfinite(s.xs_batch).all() and s.kernel_family == "runtime model"
+    one = empc.SolverSbFDDP(problem, batch=1)
+    for b in range(4):
+        one.solve([], [], 30, x0s=x0s[b:b + 1])
+        assert np.array_equal(one.xs_batch[0], s.xs_batch[b]) and one.iter_batch[0] == s.iter_batch[b]

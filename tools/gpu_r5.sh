@@ -163,6 +163,8 @@ PY
     # GPU tests of kernels that have never run on hardware (opt-in problem classes), in a pytest process of their own: a fault
     # here must not take the suite with it
     EMPC_RUN_EXPERIMENTAL_GPU_TESTS=1 timeout 1200 python -m pytest tests/test_zz_gpu_contact_small_classes.py -q -m gpu --durations=5 2>&1 | tail -30 | tee "gpurun_out/${TAG}_pytest_experimental.log"
+    # (round 6: two contacts per stage, CT_PAIR3 -- again its own process)
+    EMPC_RUN_EXPERIMENTAL_GPU_TESTS=1 timeout 1200 python -m pytest tests/test_zz_gpu_two_contacts.py -q -m gpu --durations=5 2>&1 | tail -30 | tee "gpurun_out/${TAG}_pytest_two_contacts.log"
     ;;
   probes)
     # one-wavefront probes of instructions the product does not use yet (built on the CPU side, shipped with the snapshot)

@@ -17,7 +17,8 @@ case "$PH" in
       [ -f "$O/bench_$c.json" ] && cp "$O/bench_$c.json" "profiles/r06_bench_$c.json"
       [ -f "$O/bench_under_rocprof_$c.json" ] && cp "$O/bench_under_rocprof_$c.json" "profiles/r06_bench_under_rocprof_$c.json"
     done ;;
-  experimental) [ -s "gpurun_out/${TAG}_pytest_experimental.log" ] && cp "gpurun_out/${TAG}_pytest_experimental.log" profiles/r06_pytest_experimental.log ;;
+  experimental) [ -s "gpurun_out/${TAG}_pytest_experimental.log" ] && cp "gpurun_out/${TAG}_pytest_experimental.log" profiles/r06_pytest_experimental.log
+                [ -s "gpurun_out/${TAG}_pytest_two_contacts.log" ] && cp "gpurun_out/${TAG}_pytest_two_contacts.log" profiles/r06_pytest_two_contacts.log ;;
   stamps) [ -s "gpurun_out/${TAG}_stamps.log" ] && cp "gpurun_out/${TAG}_stamps.log" profiles/r06_stamps.log ;;
   probes) [ -s "gpurun_out/${TAG}_probes.log" ] && cp "gpurun_out/${TAG}_probes.log" profiles/r06_probes.log ;;
   variants)
