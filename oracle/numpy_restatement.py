@@ -572,7 +572,7 @@ def node(P, cset, x, s, smooth):
             Lxx += w * Rx.T @ (Arr[:, None] * Rx)
             Lxu += w * Rx.T @ (Arr[:, None] * Ru)
             Luu += w * Ru.T @ (Arr[:, None] * Ru)
-    return dict(xnext=xn0r, cost=float(cost0.real), acc=a0.real, lam=lam0.real, u_squash=np.real(u0), Fx=Fx, Fu=Fu, Lx=Lx, Lu=Lu,
+    return dict(xnext=xn0r, cost=float(cost0.real), acc=a0.real, lam=lam0.real[:6], u_squash=np.real(u0), Fx=Fx, Fu=Fu, Lx=Lx, Lu=Lu,
                 Lxx=Lxx, Lxu=Lxu, Luu=Luu)
 
 

@@ -13,6 +13,7 @@ import sys, os, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 MACROS = [a for a in sys.argv[1:] if a.startswith("EMPC_")]
+ONLY_PAIR = "pair" in sys.argv[1:]  # only the two-contact (CT_PAIR3) section at the end
 LIB = '/tmp/liblane_emulator_asan%s.so' % "".join("_" + m.replace("=", "") for m in MACROS)
 subprocess.check_call(['g++', '-O1', '-g', '-std=c++20', '-pthread', '-fPIC', '-shared', '-fsanitize=address,undefined', '-fno-omit-frame-pointer'] + ["-D" + m for m in MACROS] + [
                        '-I' + os.path.join(ROOT, 'include'), os.path.join(ROOT, 'tests', 'csrc', 'lane_emulator.cpp'), '-o', LIB])
@@ -25,7 +26,7 @@ L.emu_create.argtypes = [C.POINTER(empc.T.ProblemDesc), C.POINTER(empc.T.SolverP
 L.emu_destroy.argtypes=[C.c_void_p]; L.emu_set_x0.argtypes=[C.c_void_p, C.POINTER(C.c_double)]
 L.emu_set_warmstart.argtypes=[C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
 L.emu_solve_c.argtypes=[C.c_void_p, C.c_int, C.c_int]
-for rel, dt, it in (("hexacopter370/trajectories/hover.yaml",40,100),("hexacopter370_flying_arm_3/trajectories/displacement.yaml",80,3),("hexacopter370_flying_arm_3/trajectories/eagle_catch.yaml",32,3),("hextilt_flying_arm_5/trajectories/push_slide.yaml",13,2)):
+for rel, dt, it in () if ONLY_PAIR else (("hexacopter370/trajectories/hover.yaml",40,100),("hexacopter370_flying_arm_3/trajectories/displacement.yaml",80,3),("hexacopter370_flying_arm_3/trajectories/eagle_catch.yaml",32,3),("hextilt_flying_arm_5/trajectories/push_slide.yaml",13,2)):
     t = empc.Trajectory(); t.autoSetup(empc.yaml_path(rel)); p = t.createProblem(dt, True, "IntegratedActionModelEuler")
     prm = ob.default_params()
     for bwd, roll in ((4, 6), (3, 5), (2, 1)):  # the shipped forms first, then the cross-check forms
@@ -40,16 +41,30 @@ import pathlib, tempfile
 from conftest import contact_variant
 L.emu_set_backward_version(4); L.emu_set_rollout_version(6); L.emu_set_linearize_version(2)
 t = empc.Trajectory(); t.autoSetup(empc.yaml_path("hexacopter370_flying_arm_3/trajectories/displacement.yaml"))
-for st in (1, 2):
+for st in () if ONLY_PAIR else (1, 2):
     p = t.createProblem(80, False, "IntegratedActionModelEuler")
     prm = ob.default_params(); prm.solver_type = st
     e = C.c_void_p(L.emu_create(C.byref(p.desc), C.byref(prm), 2)); L.emu_set_warmstart(e, None, None); L.emu_solve_c(e, 4, 0); L.emu_destroy(e)
     print("ok box solver", st, flush=True)
-p = t.createProblem(80, True, "IntegratedActionModelRK4")
 prm = ob.default_params()
-e = C.c_void_p(L.emu_create(C.byref(p.desc), C.byref(prm), 1)); L.emu_set_warmstart(e, None, None); L.emu_solve_c(e, 2, 0); L.emu_destroy(e)
-print("ok rk4", flush=True)
-with tempfile.TemporaryDirectory() as td:
-    _, p = contact_variant(empc, pathlib.Path(td), "ContactModel6D", (11.0, 5.0))
+if not ONLY_PAIR:
+    p = t.createProblem(80, True, "IntegratedActionModelRK4")
     e = C.c_void_p(L.emu_create(C.byref(p.desc), C.byref(prm), 1)); L.emu_set_warmstart(e, None, None); L.emu_solve_c(e, 2, 0); L.emu_destroy(e)
-    print("ok 6D contact", flush=True)
+    print("ok rk4", flush=True)
+    with tempfile.TemporaryDirectory() as td:
+        _, p = contact_variant(empc, pathlib.Path(td), "ContactModel6D", (11.0, 5.0))
+        e = C.c_void_p(L.emu_create(C.byref(p.desc), C.byref(prm), 1)); L.emu_set_warmstart(e, None, None); L.emu_solve_c(e, 2, 0); L.emu_destroy(e)
+        print("ok 6D contact", flush=True)
+# two ContactModel3D per stage (CT_PAIR3): the six-row linearize body, the pair paths of the role-split and per-lane rollouts, RK4
+# stages, both arm classes (the second capture slot behind the rollout's LDS block and the second force behind the linearize unit are
+# the new memory here)
+from conftest import arm5_two_contact_variant, two_contact_variant
+with tempfile.TemporaryDirectory() as td:
+    for name, make in (("9-dof Euler", lambda: two_contact_variant(empc, pathlib.Path(td), "ContactModel3D", (3.0, 1.5), (2.0, 0.7), cone_on_second=True)),
+                       ("9-dof RK4", lambda: two_contact_variant(empc, pathlib.Path(td), "ContactModel3D", integrator="IntegratedActionModelRK4")),
+                       ("11-dof Euler", lambda: arm5_two_contact_variant(empc, pathlib.Path(td), (2.0, 1.0), (0.0, 3.0)))):
+        _, p = make()
+        for roll in (6, 1):
+            L.emu_set_rollout_version(roll)
+            e = C.c_void_p(L.emu_create(C.byref(p.desc), C.byref(prm), 2)); L.emu_set_warmstart(e, None, None); L.emu_solve_c(e, 2, 0); L.emu_destroy(e)
+        print("ok two contacts,", name, flush=True)

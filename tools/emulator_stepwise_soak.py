@@ -90,5 +90,40 @@ def variants():
               "same_minimum", (rep.get("same_minimum") or {}).get("xs_err_max"), "OK" if ok else "FAILED", flush=True)
 
 
+def pair():
+    """python3 tools/emulator_stepwise_soak.py pair <rollouts> <seed> [out.jsonl]: two ContactModel3D per stage (CT_PAIR3, round 6) --
+    the 9-dof arm with the second contact on link 1 / on link 2 with Baumgarte gains and the friction cone on the second contact,
+    RK4 nodes, the 11-dof arm"""
+    import pathlib
+    import tempfile
+    from conftest import arm5_two_contact_variant, two_contact_variant
+    n, seed = int(sys.argv[2]), int(sys.argv[3])
+    out = sys.argv[4] if len(sys.argv) > 4 else os.path.join(ROOT, "profiles", "r06_stepwise_emulator_soak_two_contacts.jsonl")
+    emu = sw.load_emulator()
+    tmp = pathlib.Path(tempfile.mkdtemp())
+    cases = [("eagle_catch + elbow on link 1", two_contact_variant(empc, tmp, "ContactModel3D", link2="flying_arm_3__link_1")[1], {"tight": 1e-6}),
+             ("eagle_catch + elbow on link 2, gains, cone on elbow",
+              two_contact_variant(empc, tmp, "ContactModel3D", (0.0, 4.0), (0.0, 6.0), cone_on_second=True)[1], {"maxiter": 60, "do_same_minimum": False}),
+             ("eagle_catch + elbow on link 1 / RK4",
+              two_contact_variant(empc, tmp, "ContactModel3D", link2="flying_arm_3__link_1", integrator="IntegratedActionModelRK4")[1],
+              {"maxiter": 40, "do_same_minimum": False, "tol_tape": 1e-8}),
+             ("arm5 + elbow on link 3", arm5_two_contact_variant(empc, tmp, (2.0, 1.0), (0.0, 3.0))[1], {"maxiter": 40, "do_same_minimum": False})]
+    for tag, problem, kw in cases:
+        d = problem.desc
+        prm = ob.default_params()
+        x0s = empc.perturbed_x0s(problem.x0, n, nq=d.model.nq, amplitude=0.002, seed=seed)
+        rep = sw.stepwise_parity(lambda k, p2: sw.EmuBackend(emu, d, p2 if p2 is not None else prm, k), d, prm, x0s, chunk=64, tape_every=13, **kw)
+        row = {"workload": tag, "seed": seed, "rollouts": n, "backend": "CPU lane emulator of the kernel bodies (tests/csrc/lane_emulator.cpp)",
+               "variant_macros": os.environ.get("EMU_MACROS", "")}
+        row.update({k: v for k, v in rep.items() if k != "free_run"})
+        row["free_run"] = {k: v for k, v in rep["free_run"].items() if k != "first_divergences"}
+        ok = rep["decisions_checked"] == rep["pairs"] and rep["free_run"]["unexplained"] == 0
+        row["all_claims_hold"] = bool(ok)
+        with open(out, "a") as f:
+            f.write(json.dumps(row, default=float) + "\n")
+        print(tag, "pairs", rep["pairs"], "decisions", rep["decisions_checked"], "unexplained", rep["free_run"]["unexplained"],
+              "same_minimum", (rep.get("same_minimum") or {}).get("xs_err_max"), "OK" if ok else "FAILED", flush=True)
+
+
 if __name__ == "__main__":
-    variants() if sys.argv[1] == "variants" else main()
+    {"variants": variants, "pair": pair}.get(sys.argv[1], main)()
