@@ -117,7 +117,8 @@ typedef struct EmpcCostSet {
   int32_t ncosts;
   int32_t ncontacts;
   EmpcCost costs[EMPC_MAX_COSTS]; /* sorted by name */
-  EmpcContact contacts[EMPC_MAX_CONTACTS];
+  EmpcContact contacts[EMPC_MAX_CONTACTS]; /* sorted by name: the row order of crocoddyl's ContactModelMultiple (src/stage.cpp:38-48);
+                                              two entries: two ContactModel3D (six stacked rows), opt-in kernels */
 } EmpcCostSet;
 
 enum EmpcIntegrator { EMPC_INTEGRATOR_EULER = 0, EMPC_INTEGRATOR_RK4 = 1 };

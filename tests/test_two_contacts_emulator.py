@@ -198,3 +198,38 @@ def test_factory_answer_for_two_contact_problems(empc, tmp_path, monkeypatch):
     _, p1 = contact_variant(empc, tmp_path)
     monkeypatch.delenv("EMPC_EXPERIMENTAL_CONTACT", raising=False)
     assert empc.solver_supported(p1), empc.last_error()
+
+
+def test_both_contact_points_stand_still_positions_only(empc, tmp_path):
+    """The constraint itself, checked through POSITIONS only (no velocity / acceleration recursion, no Jacobian): move the robot
+    along q(s) = q (+) (v s + a s^2 / 2) with the oracle's contact acceleration a and take the second difference of the world
+    position of both contact points -- with zero gains ContactModel3D asks for zero classical acceleration of the point, i.e. a
+    world-frame p'' = 0.  With the acceleration of the ONE-contact problem (end effector only) the elbow point accelerates."""
+    import numpy_restatement as nr
+    from conftest import contact_variant
+    _, problem = two_contact_variant(empc, tmp_path, "ContactModel3D")
+    _, single = contact_variant(empc, tmp_path)
+    d = problem.desc
+    prm = ob.default_params()
+    P = nr.Problem(d, prm)
+    sets = nr.cost_sets_of(d, prm, 0.07)
+    nq, nv, t = d.model.nq, d.model.nv, 45
+    x, u = random_node(problem, d, np.random.default_rng(3))
+
+    def second_difference(a, h=1e-4):
+        def points(s):
+            xq = np.real(nr.state_integrate(nq, x, np.concatenate([x[nq:] * s + 0.5 * a * s * s, np.zeros(nv)])))
+            R, p, _, vel, acc0 = nr.kinematics(P.md, nr._c(xq[:nq]), np.zeros(nv), np.zeros(nv), gravity=False)
+            return [np.real(nr.frame_kin(P.md, ct["frame"], R, p, vel, acc0)[1]) for ct in sets[d.knot_set[t]]["contacts"]]
+        pp, p0, pm = points(h), points(0.0), points(-h)
+        return [np.abs(pp[k] - 2 * p0[k] + pm[k]).max() / h ** 2 for k in range(2)]
+
+    o = ob.OracleSolver(d, prm)
+    o.set_smooth(0.07)
+    both = second_difference(o.node_calc(t, x, u, diff=False)["acc"])
+    o1 = ob.OracleSolver(single.desc, prm)
+    o1.set_smooth(0.07)
+    one = second_difference(o1.node_calc(t, x, u, diff=False)["acc"])
+    print("p'' of (elbow, end effector): two contacts", both, "one contact", one)
+    assert max(both) < 1e-4            # (measured 1.0e-6: truncation of the difference quotient)
+    assert one[1] < 1e-3 and one[0] > 1.0  # (measured 1.5e-4 and 49.7) the end effector is held in both problems, the elbow only in the two-contact one
