@@ -456,10 +456,18 @@ def main():
         tbus = ""
         if torch.cuda.is_available():
             tp = torch.cuda.get_device_properties(tdev)
-            tbus = "%04x:%02x:%02x" % (getattr(tp, "pci_domain_id", 0), getattr(tp, "pci_bus_id", 0), getattr(tp, "pci_device_id", 0))
-        same = float(dev == tdev and (not tbus or busid.lower().startswith(tbus)))
-        bus_num = int(busid.split(":")[1], 16) if busid.count(":") >= 2 else -1
-        mine = torch.tensor([float(rank), float(dev), float(bus_num), float(zlib.crc32(busid.encode()) & 0x7FFFFFFF), same],
+            if all(hasattr(tp, a) for a in ("pci_domain_id", "pci_bus_id", "pci_device_id")):  # (not in every torch build)
+                tbus = "%04x:%02x:%02x" % (tp.pci_domain_id, tp.pci_bus_id, tp.pci_device_id)
+        # the self-check that can fail the run is the device ORDINAL (the solver's memory on torch's device); the PCI string of two
+        # libraries is compared too, but only reported (1 same, 0 differs, -1 not available): its formatting has never been seen on
+        # hardware, and a cosmetic difference must not void a measurement
+        same = float(dev == tdev)
+        bus_same = -1.0 if not (tbus and busid) else float(busid.lower().startswith(tbus))
+        try:
+            bus_num = int(busid.split(":")[1], 16) if busid.count(":") >= 2 else -1
+        except ValueError:
+            bus_num = -1
+        mine = torch.tensor([float(rank), float(dev), float(bus_num), float(zlib.crc32(busid.encode()) & 0x7FFFFFFF), same, bus_same],
                             dtype=torch.float64, device=coll_dev)
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
@@ -687,6 +695,7 @@ def main():
             out["rccl_ranks_seen"] = {"backend": args.backend, "ranks": len(devs), "distinct_devices": distinct,
                                       "rank_device_busnumber": [[r[0], r[1], r[2]] for r in devs],
                                       "solver_device_is_torch_device": [bool(r[4]) for r in devs],
+                                      "pci_bus_id_matches_torch": [r[5] if len(r) > 5 else -1 for r in devs],
                                       "source": "empc_solver_device_info (where the solver's memory lives), gathered after the timed region"}
             if args.backend == "nccl" and (len(devs) != args.gpus or distinct != args.gpus or not all(r[4] for r in devs)):
                 raise SystemExit("multi-GPU self-check failed: %d ranks on %d distinct GPUs, --gpus %d: %s" %

@@ -491,6 +491,40 @@ EMPC_HD bool chol_packed(double* L) {
   }
   return ok;
 }
+// Cholesky of the CONSTRAINT matrix G = Jc M^-1 Jc^T of a two-contact stage (CT_PAIR3), which can be rank deficient: any two
+// points of a stretched chain sit on one line, their constraint rows along that line coincide -- and the solver's default initial
+// guess (every knot at the zero state) is exactly that configuration.  pinocchio::forwardDynamics factors G with Eigen's LLT,
+// which STOPS at the first non-positive pivot and leaves the rest of the matrix as it was (llt_inplace::unblocked: `if (x <= 0)
+// return k`); the triangular solves that follow use that half-factored matrix -- the redundant row gets a multiplier of ~0 and the
+// dynamics come out sane.  The oracle's cholesky() does the same.  This is that behaviour in straight-line code (selects, no
+// branches): from the first failed pivot on, columns keep their entries (diagonal stored as reciprocal like everywhere else).
+// A pivot below 1e-13 of its diagonal entry is rounding noise of a rank-deficient system (its sign is an accident of the
+// summation order, which differs between the nominal pass, linearize and the oracle): treated like a non-positive one, so that
+// every pass of the device makes the same choice.  chol_packed (frsqrt of whatever the pivot is) stays what every other
+// factorisation uses.
+template <int N>
+EMPC_HD bool chol_packed_stop(double* L) {
+  bool stopped = false;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const double raw = L[j * (j + 1) / 2 + j];
+    double s = raw;
+#pragma unroll
+    for (int k = 0; k < j; ++k) s -= L[j * (j + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
+    const bool bad = stopped || !(s > 1e-13 * raw) || is_nan(s);
+    stopped = bad;
+    const double inv = bad ? frcp(raw) : frsqrt(s);
+    L[j * (j + 1) / 2 + j] = inv;
+#pragma unroll
+    for (int i = j + 1; i < N; ++i) {
+      double t = L[i * (i + 1) / 2 + j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) t -= L[i * (i + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
+      L[i * (i + 1) / 2 + j] = bad ? L[i * (i + 1) / 2 + j] : t * inv;
+    }
+  }
+  return !stopped;
+}
 template <int N>
 EMPC_HD void chol_solve_packed(const double* L, double* b) {
 #pragma unroll
@@ -984,7 +1018,7 @@ EMPC_HD void contact_forward_pair3(const MT& m, const ContactT& ctA, const Conta
       for (int i = 0; i < NV; ++i) g += Jc[r][i] * MiJt[c][i];
       G[r * (r + 1) / 2 + c] = g;
     }
-  chol_packed<nc>(G);
+  chol_packed_stop<nc>(G);
 #pragma unroll
   for (int r = 0; r < nc; ++r) {
     double g = a0[r];

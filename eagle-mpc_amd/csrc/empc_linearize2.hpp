@@ -1062,7 +1062,10 @@ EMPC_HD void linearize_unit2(Exec& ex, const DevBuffers& D, int b, int t, int lp
             for (int i = 0; i < NV; ++i) g += N[SM::OFF_JC + r * NV + i] * N[OFF_MIJ + i * NCR + c];
             G[r * (r + 1) / 2 + c] = g;
           }
-        chol_packed<NCR>(G);
+        if constexpr (CT == CT_PAIR3)
+          chol_packed_stop<NCR>(G);  // (rank-deficient pairs: Eigen's stop-at-the-failed-pivot behaviour, see its comment)
+        else
+          chol_packed<NCR>(G);
 #pragma unroll
         for (int i = 0; i < NG; ++i) N[OFF_G + i] = G[i];
       });

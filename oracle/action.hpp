@@ -275,7 +275,10 @@ inline void dam_eval(const Problem& P, int t, const double* x, const double* u_i
         for (int i = 0; i < nv; ++i) acc += Jc[r * nv + i] * MinvJt[i * NCM + c];
         Lc[r * nc + c] = acc;
       }
-    cholesky(Lc, nc);
+    if (ncon > 1)
+      cholesky_rank_deficient(Lc, nc);  // (several contacts: see its comment -- the one stated deviation from Eigen's LLT)
+    else
+      cholesky(Lc, nc);
     for (int r = 0; r < nc; ++r) {
       double acc = a0[r];
       for (int i = 0; i < nv; ++i) acc += Jc[r * nv + i] * afree[i];

@@ -501,6 +501,31 @@ inline bool cholesky(double* A, int n) {
   }
   return true;
 }
+// The same factorisation for the constraint matrix Jc M^-1 Jc^T of a stage with SEVERAL contacts, which can be rank deficient
+// (two point contacts on a stretched chain: the rows along the chain coincide -- and crocoddyl's default initial guess, every
+// knot at the zero state, is that configuration).  Eigen's LLT (pinocchio::forwardDynamics) stops at the first non-positive
+// pivot and leaves the rest of the matrix untouched, as cholesky() above does; the solves that follow give the redundant row a
+// multiplier of ~0.  But on an exactly singular matrix that pivot is rounding noise whose SIGN depends on the summation order:
+// with a tiny positive one the factorisation runs on and the redundant force component is split arbitrarily between the
+// rows (5.6 + 8.0 instead of 13.6 + 0 on the eagle_catch pair; the accelerations are the same, the problem does not determine
+// the split).  Stated deviation: a pivot below 1e-13 of its diagonal entry counts as non-positive, so that the oracle, its FMA
+// build and the device code (chol_packed_stop, empc_dev_model.hpp) all take the branch the reference takes half of the time.
+inline bool cholesky_rank_deficient(double* A, int n) {
+  for (int j = 0; j < n; ++j) {
+    const double raw = A[j * n + j];
+    double s = raw;
+    for (int k = 0; k < j; ++k) s -= A[j * n + k] * A[j * n + k];
+    if (!(s > 1e-13 * raw) || !std::isfinite(s)) return false;
+    const double d = std::sqrt(s);
+    A[j * n + j] = d;
+    for (int i = j + 1; i < n; ++i) {
+      double t = A[i * n + j];
+      for (int k = 0; k < j; ++k) t -= A[i * n + k] * A[j * n + k];
+      A[i * n + j] = t / d;
+    }
+  }
+  return true;
+}
 // solve L L^T x = b in place
 inline void cholesky_solve(const double* L, int n, double* b) {
   for (int i = 0; i < n; ++i) {

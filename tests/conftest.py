@@ -62,7 +62,8 @@ def contact_variant(empc, tmp_path, contact="ContactModel3D", gains=(0.0, 0.0), 
 
 
 def two_contact_variant(empc, tmp_path, second="ContactModel3D", gains=(0.0, 0.0), gains2=(0.0, 0.0), dt=32,
-                        integrator="IntegratedActionModelEuler", link2="flying_arm_3__link_2", squash=True, cone_on_second=False):
+                        integrator="IntegratedActionModelEuler", link2="flying_arm_3__link_2", squash=True, cone_on_second=False,
+                        bent=None, name2="elbow"):
     """eagle_catch with a SECOND contact in its grasp stage (src/stage.cpp:38-48 adds every name of the stage's `contacts` list
     to one ContactModelMultiple; no shipped YAML lists more than one).  The new contact is called "elbow": crocoddyl's
     name-sorted map puts it BEFORE "end_effector", so its rows come first in the stacked Jacobian.  Returns (trajectory, problem)."""
@@ -71,7 +72,8 @@ def two_contact_variant(empc, tmp_path, second="ContactModel3D", gains=(0.0, 0.0
     assert src.count(old) == 1
     new = '          type: "ContactModel3D"\n          link_name: "flying_arm_3__gripper"\n          position: [0, 0, 0]\n'
     new += '          gains: [%r, %r]\n' % (float(gains[0]), float(gains[1]))
-    new += '        - name: "elbow"\n          type: "%s"\n          link_name: "%s"\n          position: [0.1, -0.05, 0.2]\n' % (second, link2)
+    # (name2 = "zz_elbow" sorts AFTER "end_effector": the gripper's rows come first then)
+    new += '        - name: "%s"\n          type: "%s"\n          link_name: "%s"\n          position: [0.1, -0.05, 0.2]\n' % (name2, second, link2)
     if second == "ContactModel6D":
         new += '          orientation: [0, 0, 0, 1]\n'
     new += '          gains: [%r, %r]\n' % (float(gains2[0]), float(gains2[1]))
@@ -80,7 +82,15 @@ def two_contact_variant(empc, tmp_path, second="ContactModel3D", gains=(0.0, 0.0
         old_c = '          mu: 0.7\n          link_name: "flying_arm_3__gripper"\n'
         assert src.count(old_c) == 1
         src = src.replace(old_c, '          mu: 0.7\n          link_name: "%s"\n' % link2)
-    f = tmp_path / ("eagle_catch_two_%s_%g_%g_%g_%g_%d.yaml" % (second, gains[0], gains[1], gains2[0], gains2[1], int(cone_on_second)))
+    if bent is not None:
+        # The file's initial state hangs the arm straight down: ANY two points of a stretched chain sit on one line, their constraint
+        # rows along that line coincide and Jc M^-1 Jc^T is singular (rank 5) -- and the solver's initial guess repeats that state on
+        # every knot.  `bent` = initial joint angles of a regular configuration, for tests that SOLVE the problem.
+        old_i = "  initial_state: [-5, 0, 1.0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0]\n"
+        assert src.count(old_i) == 1
+        src = src.replace(old_i, "  initial_state: [-5, 0, 1.0, 0, 0, 0, 1, %r, %r, %r, 0, 0, 0, 0, 0, 0, 0, 0, 0]\n" % tuple(float(a) for a in bent))
+    f = tmp_path / ("eagle_catch_two_%s_%s_%g_%g_%g_%g_%d%s.yaml" % (second, link2[-6:], gains[0], gains[1], gains2[0], gains2[1], int(cone_on_second),
+                                                                  ("" if bent is None else "_bent") + ("" if name2 == "elbow" else "_" + name2)))
     f.write_text(src)
     tr = empc.Trajectory()
     tr.autoSetup(str(f))
@@ -166,7 +176,7 @@ def arm5_contact_variant(empc, tmp_path, contact="ContactModel3D", gains=(0.0, 0
     return tr, tr.createProblem(dt, True, "IntegratedActionModelEuler")
 
 
-def arm5_two_contact_variant(empc, tmp_path, gains=(0.0, 0.0), gains2=(0.0, 0.0), dt=26, link2="flying_arm_5__link_3"):
+def arm5_two_contact_variant(empc, tmp_path, gains=(0.0, 0.0), gains2=(0.0, 0.0), dt=26, link2="flying_arm_5__link_3", bent=None):
     """arm5_contact_variant with a SECOND ContactModel3D ("elbow", on `link2`) in the appended stage: two contacts per stage
     (src/stage.cpp:38-48) on the (6, 6) robot class -- 64-lane linearize units (empc_inst_6_6_contact_pair.hip; opt-in)."""
     src = open(empc.yaml_path(CONFIGS["push_slide"][0])).read()
@@ -175,7 +185,11 @@ def arm5_two_contact_variant(empc, tmp_path, gains=(0.0, 0.0), gains2=(0.0, 0.0)
     stage = ARM5_CONTACT_STAGE % dict(contact="ContactModel3D", orientation="", g0=float(gains[0]), g1=float(gains[1]))
     stage = stage.rstrip("\n") + ('\n        - name: "elbow"\n          type: "ContactModel3D"\n          link_name: "%s"\n'
                                   '          position: [0.3, 0.0, 0.9]\n          gains: [%r, %r]\n' % (link2, float(gains2[0]), float(gains2[1])))
-    f = tmp_path / ("arm5_two_%g_%g_%g_%g.yaml" % (gains[0], gains[1], gains2[0], gains2[1]))
+    if bent is not None:  # (see two_contact_variant: the stretched arm of the file's initial state is a singular configuration)
+        old_i = "  initial_state: [0, 0, 1.0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0]\n"
+        assert src.count(old_i) == 1
+        src = src.replace(old_i, "  initial_state: [0, 0, 1.0, 0, 0, 0, 1, %r, %r, %r, %r, %r, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0]\n" % tuple(float(a) for a in bent))
+    f = tmp_path / ("arm5_two_%g_%g_%g_%g%s.yaml" % (gains[0], gains[1], gains2[0], gains2[1], "" if bent is None else "_bent"))
     f.write_text(src.rstrip("\n") + "\n" + stage)
     tr = empc.Trajectory()
     tr.autoSetup(str(f))

@@ -149,20 +149,21 @@ def test_two_contact_rk4_kernel_bodies_vs_oracle(empc, emu, tmp_path):
 
 
 def test_two_contact_stepwise_parity_on_the_emulator(empc, tmp_path):
-    """The step-wise argument (tests/stepwise.py) on a two-contact problem that converges (second contact on link 1, no gains: 63
-    iterations from the nominal state): every iteration of the oracle's paths reproduced by the CT_PAIR3 kernel bodies from the
+    """The step-wise argument (tests/stepwise.py) on a two-contact problem that converges (second contact on link 1, no gains, the
+    arm bent in the initial state -- the file's stretched arm is a singular configuration of ANY two point contacts, see
+    conftest.two_contact_variant; 27 iterations from there): every iteration of the oracle's paths reproduced by the CT_PAIR3 kernel bodies from the
     oracle's iterate (tape 1e-9, gains 1e-6, trial costs 1e-9, every decision exactly), every iteration of the device's own paths
     reproduced by the oracle, the same minimiser from a common restart."""
     import stepwise as sw
     from test_gpu_teacher_forced import check
     emu_sw = sw.load_emulator()
-    _, problem = two_contact_variant(empc, tmp_path, "ContactModel3D", link2="flying_arm_3__link_1")
+    _, problem = two_contact_variant(empc, tmp_path, "ContactModel3D", link2="flying_arm_3__link_1", bent=(0.4, -0.7, 0.5))
     d = problem.desc
     prm = ob.default_params()
     x0s = empc.perturbed_x0s(problem.x0, 2, nq=d.model.nq, amplitude=0.002)
     rep = sw.stepwise_parity(lambda n, p2: sw.EmuBackend(emu_sw, d, p2 if p2 is not None else prm, n), d, prm, x0s, chunk=64,
                              tape_every=13, tight=1e-6, tight_maxiter=300)
-    check(rep, max_waived=0.10, min_asserted=100, max_exploded=0)  # (measured: 129 pairs, waived 0.054, 122 asserted)
+    check(rep, max_waived=0.10, min_asserted=80, max_exploded=0)  # (measured: 103 pairs, waived 0.02-0.04, 99-101 asserted)
     assert rep["same_minimum"]["converged_on_oracle"] >= 1 and rep["same_minimum"]["xs_err_max"] < 1e-6  # (measured 2.0e-8)
     print("two contacts: pairs", rep["pairs"], "waived", rep["waived_fraction"], "asserted", rep["decisions_asserted"], rep["same_minimum"], rep["max_rel"])
 
