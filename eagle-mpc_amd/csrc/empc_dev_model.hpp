@@ -187,7 +187,14 @@ EMPC_HD void inertia_apply(const MT& m, int b, const S* mot, S* out) {
 
 // Operational-frame capture: placement and LOCAL velocity / acceleration of up to NCAP frames, filled during the
 // forward recursion when the recursion reaches the frame's body.
-constexpr int NCAP = 2;
+// (2 in the product: every shipped stage names at most two distinct frames.  -DEMPC_NCAP=3 builds a library whose kernels capture
+//  three -- e.g. two contact frames AND a frame cost on a third link -- at ~36 more registers per lane in the full linearize body;
+//  emulator-verified, tests/test_two_contacts_emulator.py::test_three_frames_need_a_build_with_three_captures)
+#ifndef EMPC_NCAP
+#define EMPC_NCAP 2
+#endif
+constexpr int NCAP = EMPC_NCAP;
+static_assert(NCAP >= 2 && NCAP <= 4, "capture slots: 2 (product) to 4");
 // contact rows of a kernel instantiation (template parameter CT / NC): 0 free dynamics, 3 ContactModel3D, 6 ContactModel6D,
 // CT_MIXED a problem whose stages use both (the bodies of 3 and 6 behind a uniform branch on the node's contact type)
 constexpr int CT_MIXED = 9;

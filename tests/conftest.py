@@ -63,7 +63,7 @@ def contact_variant(empc, tmp_path, contact="ContactModel3D", gains=(0.0, 0.0), 
 
 def two_contact_variant(empc, tmp_path, second="ContactModel3D", gains=(0.0, 0.0), gains2=(0.0, 0.0), dt=32,
                         integrator="IntegratedActionModelEuler", link2="flying_arm_3__link_2", squash=True, cone_on_second=False,
-                        bent=None, name2="elbow"):
+                        bent=None, name2="elbow", extra_frame_cost=None):
     """eagle_catch with a SECOND contact in its grasp stage (src/stage.cpp:38-48 adds every name of the stage's `contacts` list
     to one ContactModelMultiple; no shipped YAML lists more than one).  The new contact is called "elbow": crocoddyl's
     name-sorted map puts it BEFORE "end_effector", so its rows come first in the stacked Jacobian.  Returns (trajectory, problem)."""
@@ -82,6 +82,11 @@ def two_contact_variant(empc, tmp_path, second="ContactModel3D", gains=(0.0, 0.0
         old_c = '          mu: 0.7\n          link_name: "flying_arm_3__gripper"\n'
         assert src.count(old_c) == 1
         src = src.replace(old_c, '          mu: 0.7\n          link_name: "%s"\n' % link2)
+    if extra_frame_cost:  # a frame cost on a THIRD link in the grasp stage: three distinct frames (two contacts + this one)
+        old_k = '      contacts:\n        - name: "end_effector"\n'
+        assert src.count(old_k) == 1
+        src = src.replace(old_k, '        - name: "zz_translation_base"\n          type: "CostModelFrameTranslation"\n          weight: 20\n'
+                                 '          link_name: "%s"\n          position: [0, 0, 1.3]\n\n' % extra_frame_cost + old_k)
     if bent is not None:
         # The file's initial state hangs the arm straight down: ANY two points of a stretched chain sit on one line, their constraint
         # rows along that line coincide and Jc M^-1 Jc^T is singular (rank 5) -- and the solver's initial guess repeats that state on
@@ -90,7 +95,7 @@ def two_contact_variant(empc, tmp_path, second="ContactModel3D", gains=(0.0, 0.0
         assert src.count(old_i) == 1
         src = src.replace(old_i, "  initial_state: [-5, 0, 1.0, 0, 0, 0, 1, %r, %r, %r, 0, 0, 0, 0, 0, 0, 0, 0, 0]\n" % tuple(float(a) for a in bent))
     f = tmp_path / ("eagle_catch_two_%s_%s_%g_%g_%g_%g_%d%s.yaml" % (second, link2[-6:], gains[0], gains[1], gains2[0], gains2[1], int(cone_on_second),
-                                                                  ("" if bent is None else "_bent") + ("" if name2 == "elbow" else "_" + name2)))
+                                                                  ("" if bent is None else "_bent") + ("" if name2 == "elbow" else "_" + name2) + ("_x" if extra_frame_cost else "")))
     f.write_text(src)
     tr = empc.Trajectory()
     tr.autoSetup(str(f))

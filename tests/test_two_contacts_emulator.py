@@ -234,3 +234,20 @@ def test_both_contact_points_stand_still_positions_only(empc, tmp_path):
     print("p'' of (elbow, end effector): two contacts", both, "one contact", one)
     assert max(both) < 1e-4            # (measured 1.0e-6: truncation of the difference quotient)
     assert one[1] < 1e-3 and one[0] > 1.0  # (measured 1.5e-4 and 49.7) the end effector is held in both problems, the elbow only in the two-contact one
+
+
+def test_three_frames_need_a_build_with_three_captures(empc, emu, tmp_path):
+    """Two contact frames AND a frame cost on a third link: three distinct frames in one stage.  The product's kernels capture two
+    (NCAP, every shipped stage names at most two) and the factory refuses the problem with that reason; a library built with
+    -DEMPC_NCAP=3 takes it.  On the emulator of such a build (EMU_MACROS="EMPC_NCAP=3"): phase parity against the oracle."""
+    import os
+    _, problem = two_contact_variant(empc, tmp_path, "ContactModel3D", (0.0, 2.0), (0.0, 2.0), extra_frame_cost="hexacopter370__base_link")
+    if "EMPC_NCAP=3" not in os.environ.get("EMU_MACROS", "").split():
+        os.environ["EMPC_EXPERIMENTAL_CONTACT"] = "1"
+        try:
+            assert not empc.solver_supported(problem) and "more distinct frames" in empc.last_error()
+        finally:
+            del os.environ["EMPC_EXPERIMENTAL_CONTACT"]
+        pytest.skip("three capture slots: run with EMU_MACROS=EMPC_NCAP=3 (tools/variant_verdicts.py does)")
+    kernel_bodies(emu, problem, "eagle_catch", 2, 4, 6, tape_tol=TAPE_TOL, **gain_yardstick(problem))
+    kernel_bodies(emu, problem, "eagle_catch", 2, 4, 1, tape_tol=TAPE_TOL, **gain_yardstick(problem))

@@ -53,7 +53,10 @@ def test_two_contact_stepwise(empc, tmp_path):
     x0s[0] = problem.x0
     # (iterates pass next to configurations with cond(Jc M^-1 Jc^T) = 1e8 ... 1e10: tape entries beyond the tolerance there go to the
     #  harness's third-algorithm arbitration -- tests/stepwise.py third_algorithm_distance)
-    rep = sw.stepwise_parity(factory(empc, problem, prm), d, prm, x0s, tape_every=13, tight=1e-6)
+    # initial guess: the bent initial state on every knot (the default guess, the zero state, is a rank-deficient configuration of any
+    # two point contacts on this arm -- DESIGN.md section 4, "Rank-deficient pairs"; the emulator edition covers that start as well)
+    warm = (np.repeat(x0s[:, None, :], d.T + 1, axis=1), np.zeros((len(x0s), d.T, d.nu)))
+    rep = sw.stepwise_parity(factory(empc, problem, prm), d, prm, x0s, tape_every=13, tight=1e-6, warm=warm)
     check(rep, max_waived=0.11, min_asserted=300, max_exploded=8)
     assert rep["same_minimum"]["xs_err_max"] < 1e-4
 

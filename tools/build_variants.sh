@@ -22,6 +22,7 @@ declare -A V=(
   [bwdm4]="$BWD -DEMPC_BWD_MFMA4=1"
   [all]="$BWD -DEMPC_ROLL_CAP_LDS=1 -DEMPC_ROLL_GAP_EARLY"
   [alltri]="$BWD -DEMPC_ROLL_CAP_LDS=1 -DEMPC_ROLL_GAP_EARLY -DEMPC_REC_TRI=1"
+  [ncap3]="-DEMPC_NCAP=3"   # three capture slots: problems whose stages name three distinct frames (not an A/B candidate: a capability)
   [stamps]="-DEMPC_STAMPS"
   [stamps_bwd]="-DEMPC_STAMPS $BWD"
 )
