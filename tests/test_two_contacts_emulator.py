@@ -251,3 +251,19 @@ def test_three_frames_need_a_build_with_three_captures(empc, emu, tmp_path):
         pytest.skip("three capture slots: run with EMU_MACROS=EMPC_NCAP=3 (tools/variant_verdicts.py does)")
     kernel_bodies(emu, problem, "eagle_catch", 2, 4, 6, tape_tol=TAPE_TOL, **gain_yardstick(problem))
     kernel_bodies(emu, problem, "eagle_catch", 2, 4, 1, tape_tol=TAPE_TOL, **gain_yardstick(problem))
+
+
+def test_host_mirror_lists_both_contacts(empc, tmp_path):
+    """Stage::autoSetup (src/stage.cpp:38-48) through the host mirror: both names of the stage's `contacts` list in its
+    ContactModelMultiple, in the name-sorted order crocoddyl's map would stack them, with their factory types; the flat descriptor
+    handed to the kernels carries the same two entries (frames of two different links)."""
+    tr, problem = two_contact_variant(empc, tmp_path, "ContactModel3D", (3.0, 1.5), (2.0, 0.7))
+    grasp = [s for s in tr.stages if s.name == "grasp"][0]
+    assert grasp.n_contacts == 2 and [c["name"] for c in grasp.contacts] == ["elbow", "end_effector"]
+    assert grasp.contact_types == {"elbow": "ContactModel3D", "end_effector": "ContactModel3D"}
+    d = problem.desc
+    sets = [d.sets[k] for k in range(d.n_sets) if d.sets[k].ncontacts == 2]
+    assert len(sets) == 1 and d.has_contact == 1
+    c0, c1 = sets[0].contacts[0], sets[0].contacts[1]
+    assert (c0.name.decode(), c1.name.decode()) == ("elbow", "end_effector") and c0.frame != c1.frame
+    assert tuple(c0.gains) == (2.0, 0.7) and tuple(c1.gains) == (3.0, 1.5) and tuple(c0.ref_p) == (0.1, -0.05, 0.2)
