@@ -32,4 +32,7 @@ for t in $TAGS; do
   echo "== $t: ${V[$t]}"
   make -j"${JOBS:-6}" BUILD=build_$t LIB=libempc_$t.so EXTRA="${V[$t]}" 2>&1 | grep -E "error|Error" | head -5
   ls -la libempc_$t.so | awk '{print $5, $6, $7, $8, $9}'
+  # the objects are not needed once the library is linked (38 MB per variant that a snapshot of the tree would carry to a GPU box:
+  # the committed .gpurunignore lists the libraries by name, not these directories); KEEP_OBJECTS=1 keeps them for inspection
+  [ -n "${KEEP_OBJECTS:-}" ] || rm -rf "build_$t"
 done
