@@ -267,3 +267,31 @@ def test_host_mirror_lists_both_contacts(empc, tmp_path):
     c0, c1 = sets[0].contacts[0], sets[0].contacts[1]
     assert (c0.name.decode(), c1.name.decode()) == ("elbow", "end_effector") and c0.frame != c1.frame
     assert tuple(c0.gains) == (2.0, 0.7) and tuple(c1.gains) == (3.0, 1.5) and tuple(c0.ref_p) == (0.1, -0.05, 0.2)
+
+
+def test_third_algorithm_arbitration_on_an_ill_conditioned_node(empc, tmp_path):
+    """What the step-wise harness's arbitration rests on (tests/stepwise.py third_algorithm_distance): with the arm 1e-4 rad from
+    stretched, Jc M^-1 Jc^T of the two point contacts is 1e-8 from singular.  There the NumPy restatement -- a third algorithm --
+    sits far from the oracle in the digits where the oracle's FMA build (the SAME algorithm, the harness's usual yardstick) still
+    agrees with it; with the arm bent all three agree to 1e-13."""
+    import stepwise as sw
+    _, problem = two_contact_variant(empc, tmp_path, "ContactModel3D", link2="flying_arm_3__link_1")
+    d = problem.desc
+    prm = ob.default_params()
+    o, ofma = ob.OracleSolver(d, prm), ob.OracleSolver(d, prm, variant="fma")
+    for s_ in (o, ofma):
+        s_.set_smooth(0.1)
+    t, dist = 45, {}
+    for tag, arm in (("nearly stretched", (1e-4, -2e-4, 1.5e-4)), ("bent", (0.4, -0.7, 0.5))):
+        x = np.zeros(d.nx)
+        x[6] = 1.0
+        x[7:10] = arm
+        x[d.model.nq:] = 0.05
+        u = np.full(d.nu, 4.0)
+        u[d.n_rotors:] = 0.1
+        it = dict(smooth=0.1, xs=np.tile(x, (d.T + 1, 1)), us=np.tile(u, (d.T, 1)))
+        ref, rf = o.node_calc(t, x, u), ofma.node_calc(t, x, u)
+        dist[tag] = (sw.third_algorithm_distance(d, prm, it, t, "Fu", ref["Fu"]), rel(np.ravel(rf["Fu"]), np.ravel(ref["Fu"])))
+    print("Fu: (NumPy restatement, FMA build) vs oracle:", dist)
+    assert dist["nearly stretched"][0] > 100 * dist["nearly stretched"][1] and dist["nearly stretched"][0] > 1e-11  # (measured 1.1e-10 and 1e-14)
+    assert dist["bent"][0] < 1e-12 and dist["bent"][1] < 1e-12
