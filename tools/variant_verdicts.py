@@ -144,7 +144,7 @@ def main():
             if arith == "moves" or r.returncode != 0:
                 env = dict(os.environ, EMU_MACROS=" ".join(macros))
                 p = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "tests/test_emulator_parity.py", "tests/test_teacher_forced_emulator.py",
-                                    "tests/test_parity_contract_emulator.py"], capture_output=True, text=True, cwd=ROOT, env=env)
+                                    "tests/test_parity_contract_emulator.py", "tests/test_two_contacts_emulator.py"], capture_output=True, text=True, cwd=ROOT, env=env)
                 v["parity"] = p.stdout.strip().splitlines()[-1] if p.stdout.strip() else "no output"
                 v["parity_ok"] = p.returncode == 0
             v["seconds"] = round(time.time() - t0)
