@@ -4,7 +4,7 @@
 #   bash tools/gpurun_r6.sh [phase ...]        phases (default: all, in this order):
 #     check         whole GPU suite on the shipped library + the driver's default bench line            (~25 min)
 #     profiles      rocprofv3 kernel stats over the driver's command + four PMC passes, three workloads (~35 min)
-#     experimental  the opt-in problem classes in a pytest process of their own                         (~10 min)
+#     experimental  the opt-in problem classes (small classes, mixed (6,6), two contacts per stage), each file in a pytest process of its own (~20 min)
 #     probes        v_mfma_f64_4x4x4 layout + cost (decides EMPC_BWD_MFMA4), pipeline latencies         (~3 min)
 #     variants      every libempc_<tag>.so: parity core of the suite + bench lines against the shipped  (~15 min per library)
 #     lines         bench lines of the other BASELINE configurations
@@ -12,7 +12,7 @@
 set -uo pipefail
 cd "$(dirname "${BASH_SOURCE[0]}")/.."
 PHASES="${*:-check profiles experimental probes variants stamps lines}"
-declare -A TMO=([check]=2400 [profiles]=3000 [experimental]=1200 [probes]=400 [variants]=5400 [lines]=1500 [stamps]=900)
+declare -A TMO=([check]=2400 [profiles]=3000 [experimental]=2600 [probes]=400 [variants]=5400 [lines]=1500 [stamps]=900)
 for ph in $PHASES; do
   tag="r06_${ph}"
   echo "=== phase $ph (tag $tag, limit ${TMO[$ph]} s)"
