@@ -145,6 +145,12 @@ def test_baked_family_equals_runtime_family(empc, problems, emu, emu_baked, name
     families agree to rounding, tests/test_gpu_baked.py).  Covers the generated tables and the BakedView / BakedPlatform code
     paths without a GPU."""
     _, problem = problems[name]
+    families_equal(emu, emu_baked, problem)
+
+
+def families_equal(emu, emu_baked, problem):
+    """tape, gains, Vx, expected-improvement sums and six step lengths of the rollout, bit for bit between the runtime-model and the
+    baked instantiation of the kernel bodies (both on the CPU lane emulator)"""
     d = problem.desc
     prm = ob.default_params()
     T, nx, nu, nv = d.T, d.nx, d.nu, d.model.nv
