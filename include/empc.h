@@ -159,7 +159,10 @@ int empc_solver_dims(const EmpcSolver* s, int* batch, int* T, int* nx, int* ndx,
  * class and the problem passes the device-side limits), 0 otherwise with the reason in empc_last_error().  Needs no GPU.
  * Instantiated: (1,4) iris | (1,6) hexacopter370, hextilt | (3,6) hexacopter680_flying_arm_2 |
  * (4,6) hexacopter370_flying_arm_3: free, ContactModel3D, ContactModel6D and mixed-contact dynamics |
- * (6,6) hextilt_flying_arm_5: free, ContactModel3D and ContactModel6D dynamics. */
+ * (6,6) hextilt_flying_arm_5: free, ContactModel3D and ContactModel6D dynamics.
+ * Behind the environment switch EMPC_EXPERIMENTAL_CONTACT=1 (instantiations that have only run on the CPU lane emulator; refused
+ * with that reason otherwise): contact dynamics on the (1,4) / (1,6) / (3,6) classes, stages of both contact types on (6,6), and
+ * stages with TWO ContactModel3D contacts (the reference's ContactModelMultiple, src/stage.cpp:38-48) on (4,6) and (6,6). */
 int empc_solver_supported(const EmpcProblemDesc* problem, const EmpcSolverParams* params);
 
 /* ---- phase-level entry points (device kernels, one call = one launch over the whole batch) ------------------
