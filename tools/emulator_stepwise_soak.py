@@ -126,10 +126,21 @@ def pair():
         # configuration of any two point contacts on these arms, on every knot; the first iterations from there run through
         # rank-deficient and nearly rank-deficient constraint matrices, where two correct algorithms differ in leading digits
         warm = (np.repeat(x0s[:, None, :], d.T + 1, axis=1), np.zeros((n, d.T, d.nu)))
-        rep = sw.stepwise_parity(lambda k, p2: sw.EmuBackend(emu, d, p2 if p2 is not None else prm, k), d, prm, x0s, chunk=64, tape_every=13,
-                                 warm=warm, **kw)
         row = {"workload": tag, "seed": seed, "rollouts": n, "backend": "CPU lane emulator of the kernel bodies (tests/csrc/lane_emulator.cpp)",
                "variant_macros": os.environ.get("EMU_MACROS", ""), "initial_guess": "initial state on every knot, zero controls"}
+        try:
+            rep = sw.stepwise_parity(lambda k, p2: sw.EmuBackend(emu, d, p2 if p2 is not None else prm, k), d, prm, x0s, chunk=64, tape_every=13,
+                                     warm=warm, **kw)
+        except AssertionError as ex:
+            # a numerical assertion of the harness tripped: recorded with its message, the other workloads still run.  On this class
+            # that has so far always been an iterate next to a rank-deficient pair of constraints, where the
+            # harness's tolerances -- calibrated on what the oracle's own FMA build moves by -- are tighter than what two correct
+            # algorithms differ by; every such record needs a look.
+            row.update({"all_claims_hold": False, "harness_assertion": str(ex)[:600]})
+            with open(out, "a") as f:
+                f.write(json.dumps(row, default=float) + "\n")
+            print(tag, "HARNESS ASSERTION", str(ex)[:200], flush=True)
+            continue
         row.update({k: v for k, v in rep.items() if k != "free_run"})
         row["free_run"] = {k: v for k, v in rep["free_run"].items() if k != "first_divergences"}
         ok = rep["decisions_checked"] == rep["pairs"] and rep["free_run"]["unexplained"] == 0
