@@ -256,8 +256,8 @@ def cpu_baseline_and_parity(empc, solver, problem, d, x0s, B, maxiter, unit):
                     "free_paths_equal": fr["same_path_as_oracle"], "free_paths_diverging": fr["diverging"],
                     "same_minimum_xs_err_max": sm.get("xs_err_max"), "same_minimum_us_err_max": sm.get("us_err_max"),
                     "same_minimum_rollouts": sm.get("converged_on_oracle"), "passed": True}
-    except AssertionError as e:  # the bench line reports it; tests/test_gpu_teacher_forced.py is where it fails a run
-        stepwise = {"passed": False, "error": str(e)[:400]}
+    except Exception as e:  # the bench line reports it (whatever it is); tests/test_gpu_teacher_forced.py is where it fails a run
+        stepwise = {"passed": False, "error": "%s: %s" % (type(e).__name__, str(e)[:400])}
     # the contract of the north star on the unperturbed rollout, in the form smoke() asserts (tests/parity_criteria.py): same
     # minimiser from a common restart <= 1e-4, plain-solve cost within 1e-5 relative, identical iterations; plain xs / us reported
     # with a 2e-4 tripwire next to the oracle-vs-its-own-FMA-build yardstick
