@@ -221,63 +221,66 @@ def cpu_baseline_and_parity(empc, solver, problem, d, x0s, B, maxiter, unit):
                           "us_per_iteration": {"AVG": float(us_per_it.mean()), "STDDEV": float(us_per_it.std()),
                                                "MAX": float(us_per_it.max()), "MIN": float(us_per_it.min())},
                           "format": "benchmark/mpc-main-carrot-timings.cpp:42-55 (Avg. time per iteration)"}}}
-    # parity.  (1) free-running batch against the oracle: statistics REPORTED, not judged -- the iteration paths of the contact
-    # problem are rounding-sensitive (profiles/r02_oracle_sensitivity.json); asserted-on-every-run part: both sides solve the
-    # same problem (oracle's cost and dynamics at the GPU's final points).  (2) the decisive, step-wise form on a sample
-    # (tests/stepwise.py): every iteration of the oracle's paths reproduced by the GPU from the oracle's iterate, every
-    # iteration of the GPU's paths reproduced by the oracle from the GPU's iterate, same minimiser from a common restart.
-    import stepwise as sw
-    solver.enable_trace(3 * maxiter + 20)
-    solver.solve([], [], maxiter, x0s=x0s[:solver.batch])
-    gpu = dict(xs=solver.xs_batch[:n_sample], us=solver.us_batch[:n_sample], cost=solver.cost_batch[:n_sample],
-               iter=solver.iter_batch[:n_sample], status=solver.status_batch[:n_sample])
-    stats = pc.batch_statistics(gpu, ref)
-    sample = sorted(set(int(i) for i in np.linspace(0, n_sample - 1, 8)))
-    prm = empc.default_params()
-    smp = pc.sample_checks(ob, d, x0s, gpu, {b: solver.trace(b) for b in sample}, sample,
-                           final_smooth=prm.smooth_init * prm.smooth_mult, th_stop=prm.convergence_stop, maxiter=maxiter)
-    solver.enable_trace(0)
-    per_roll = np.maximum(np.abs(gpu["xs"] - ref["xs"]).reshape(n_sample, -1).max(axis=1),
-                          np.abs(gpu["us"] - ref["us"]).reshape(n_sample, -1).max(axis=1))
-    stepwise = None
-    try:
-        oprm = ob.default_params()
-        rep = sw.stepwise_parity(lambda n, p2: sw.GpuBackend(empc, problem, p2 if p2 is not None else oprm, n), d, oprm,
-                                 np.ascontiguousarray(x0s[sample[:6]]), maxiter=maxiter, tape_every=47)
-        fr, sm = rep["free_run"], rep.get("same_minimum", {})
-        stepwise = {"rollouts": rep["rollouts"], "iterations_teacher_forced": rep["pairs"],
-                    "decisions_exact": rep["decisions_checked"] - rep.get("decisions_excused_chaotic", 0) - rep.get("direction_ties_excused", 0) - rep.get("decisions_excused_tied", 0),
-                    "decisions_excused_blown_up_trial_or_tie": rep.get("decisions_excused_chaotic", 0) + rep.get("direction_ties_excused", 0) + rep.get("decisions_excused_tied", 0),
-                    "trial_costs_checked": rep["trial_costs_checked"], "trial_costs_beyond_1e-9": rep.get("trial_costs_beyond_1e-9", 0),
-                    "tapes_checked": rep["tapes_checked"], "iterates_skipped_exploded": rep.get("iterates_skipped_exploded", 0),
-                    "max_rel": {k: rep["max_rel"].get(k) for k in ("cost", "tape_Fx", "tape_Lxx", "tape_Lx", "K", "k", "Vx", "cost_try_accepted")},
-                    "gpu_iterations_reproduced_by_oracle": fr["oracle_reproduces_device_decision"],
-                    "gpu_iterations": fr["device_iterations"], "unexplained": fr["unexplained"],
-                    "free_paths_equal": fr["same_path_as_oracle"], "free_paths_diverging": fr["diverging"],
-                    "same_minimum_xs_err_max": sm.get("xs_err_max"), "same_minimum_us_err_max": sm.get("us_err_max"),
-                    "same_minimum_rollouts": sm.get("converged_on_oracle"), "passed": True}
-    except Exception as e:  # the bench line reports it (whatever it is); tests/test_gpu_teacher_forced.py is where it fails a run
-        stepwise = {"passed": False, "error": "%s: %s" % (type(e).__name__, str(e)[:400])}
-    # the contract of the north star on the unperturbed rollout, in the form smoke() asserts (tests/parity_criteria.py): same
-    # minimiser from a common restart <= 1e-4, plain-solve cost within 1e-5 relative, identical iterations; plain xs / us reported
-    # with a 2e-4 tripwire next to the oracle-vs-its-own-FMA-build yardstick
-    try:
-        contract = pc.north_star_contract(empc, ob, sw, problem, gpu["xs"][0], gpu["us"][0], float(gpu["cost"][0]), int(gpu["iter"][0]),
-                                          x0=x0s[0], maxiter=maxiter)
-    except Exception as e:  # the line reports it; smoke() and tests/test_gpu_eagle_catch.py are where it fails a run
-        contract = {"passed": False, "failures": ["%s: %s" % (type(e).__name__, str(e)[:300])]}
-    out["parity"] = {"reference": "oracle/liboracle.so (CPU restatement; parity unpinned, DESIGN.md)", "tolerance": 1e-4,
-                     "rollouts_compared": n_sample,
-                     "unperturbed_rollout_max_abs_err": float(per_roll[0]),
-                     "unperturbed_rollout_iterations_equal": bool(gpu["iter"][0] == ref["iter"][0]),
-                     "contract": contract,
-                     "free_running_batch_statistics_reported_not_judged": stats, "sample_checks": smp,
-                     "same_problem": bool(smp["oracle_cost_at_gpu_point_rel_err_max"] is not None and
-                                          smp["oracle_cost_at_gpu_point_rel_err_max"] <= 1e-9 and
-                                          smp["oracle_dynamics_defect_at_gpu_point_max"] <= 1e-8),
-                     "stepwise": stepwise,
-                     "method": "tests/stepwise.py: teacher-forced in both directions + same minimiser from a common restart; "
-                               "tests/test_gpu_teacher_forced.py runs it on 64 rollouts"}
+    try:  # (the CPU baseline above is complete: a failure of the parity leg is reported in its own block)
+        # parity.  (1) free-running batch against the oracle: statistics REPORTED, not judged -- the iteration paths of the contact
+        # problem are rounding-sensitive (profiles/r02_oracle_sensitivity.json); asserted-on-every-run part: both sides solve the
+        # same problem (oracle's cost and dynamics at the GPU's final points).  (2) the decisive, step-wise form on a sample
+        # (tests/stepwise.py): every iteration of the oracle's paths reproduced by the GPU from the oracle's iterate, every
+        # iteration of the GPU's paths reproduced by the oracle from the GPU's iterate, same minimiser from a common restart.
+        import stepwise as sw
+        solver.enable_trace(3 * maxiter + 20)
+        solver.solve([], [], maxiter, x0s=x0s[:solver.batch])
+        gpu = dict(xs=solver.xs_batch[:n_sample], us=solver.us_batch[:n_sample], cost=solver.cost_batch[:n_sample],
+                   iter=solver.iter_batch[:n_sample], status=solver.status_batch[:n_sample])
+        stats = pc.batch_statistics(gpu, ref)
+        sample = sorted(set(int(i) for i in np.linspace(0, n_sample - 1, 8)))
+        prm = empc.default_params()
+        smp = pc.sample_checks(ob, d, x0s, gpu, {b: solver.trace(b) for b in sample}, sample,
+                               final_smooth=prm.smooth_init * prm.smooth_mult, th_stop=prm.convergence_stop, maxiter=maxiter)
+        solver.enable_trace(0)
+        per_roll = np.maximum(np.abs(gpu["xs"] - ref["xs"]).reshape(n_sample, -1).max(axis=1),
+                              np.abs(gpu["us"] - ref["us"]).reshape(n_sample, -1).max(axis=1))
+        stepwise = None
+        try:
+            oprm = ob.default_params()
+            rep = sw.stepwise_parity(lambda n, p2: sw.GpuBackend(empc, problem, p2 if p2 is not None else oprm, n), d, oprm,
+                                     np.ascontiguousarray(x0s[sample[:6]]), maxiter=maxiter, tape_every=47)
+            fr, sm = rep["free_run"], rep.get("same_minimum", {})
+            stepwise = {"rollouts": rep["rollouts"], "iterations_teacher_forced": rep["pairs"],
+                        "decisions_exact": rep["decisions_checked"] - rep.get("decisions_excused_chaotic", 0) - rep.get("direction_ties_excused", 0) - rep.get("decisions_excused_tied", 0),
+                        "decisions_excused_blown_up_trial_or_tie": rep.get("decisions_excused_chaotic", 0) + rep.get("direction_ties_excused", 0) + rep.get("decisions_excused_tied", 0),
+                        "trial_costs_checked": rep["trial_costs_checked"], "trial_costs_beyond_1e-9": rep.get("trial_costs_beyond_1e-9", 0),
+                        "tapes_checked": rep["tapes_checked"], "iterates_skipped_exploded": rep.get("iterates_skipped_exploded", 0),
+                        "max_rel": {k: rep["max_rel"].get(k) for k in ("cost", "tape_Fx", "tape_Lxx", "tape_Lx", "K", "k", "Vx", "cost_try_accepted")},
+                        "gpu_iterations_reproduced_by_oracle": fr["oracle_reproduces_device_decision"],
+                        "gpu_iterations": fr["device_iterations"], "unexplained": fr["unexplained"],
+                        "free_paths_equal": fr["same_path_as_oracle"], "free_paths_diverging": fr["diverging"],
+                        "same_minimum_xs_err_max": sm.get("xs_err_max"), "same_minimum_us_err_max": sm.get("us_err_max"),
+                        "same_minimum_rollouts": sm.get("converged_on_oracle"), "passed": True}
+        except Exception as e:  # the bench line reports it (whatever it is); tests/test_gpu_teacher_forced.py is where it fails a run
+            stepwise = {"passed": False, "error": "%s: %s" % (type(e).__name__, str(e)[:400])}
+        # the contract of the north star on the unperturbed rollout, in the form smoke() asserts (tests/parity_criteria.py): same
+        # minimiser from a common restart <= 1e-4, plain-solve cost within 1e-5 relative, identical iterations; plain xs / us reported
+        # with a 2e-4 tripwire next to the oracle-vs-its-own-FMA-build yardstick
+        try:
+            contract = pc.north_star_contract(empc, ob, sw, problem, gpu["xs"][0], gpu["us"][0], float(gpu["cost"][0]), int(gpu["iter"][0]),
+                                              x0=x0s[0], maxiter=maxiter)
+        except Exception as e:  # the line reports it; smoke() and tests/test_gpu_eagle_catch.py are where it fails a run
+            contract = {"passed": False, "failures": ["%s: %s" % (type(e).__name__, str(e)[:300])]}
+        out["parity"] = {"reference": "oracle/liboracle.so (CPU restatement; parity unpinned, DESIGN.md)", "tolerance": 1e-4,
+                         "rollouts_compared": n_sample,
+                         "unperturbed_rollout_max_abs_err": float(per_roll[0]),
+                         "unperturbed_rollout_iterations_equal": bool(gpu["iter"][0] == ref["iter"][0]),
+                         "contract": contract,
+                         "free_running_batch_statistics_reported_not_judged": stats, "sample_checks": smp,
+                         "same_problem": bool(smp["oracle_cost_at_gpu_point_rel_err_max"] is not None and
+                                              smp["oracle_cost_at_gpu_point_rel_err_max"] <= 1e-9 and
+                                              smp["oracle_dynamics_defect_at_gpu_point_max"] <= 1e-8),
+                         "stepwise": stepwise,
+                         "method": "tests/stepwise.py: teacher-forced in both directions + same minimiser from a common restart; "
+                                   "tests/test_gpu_teacher_forced.py runs it on 64 rollouts"}
+    except Exception as e:
+        out["parity"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:400])}
     return out
 
 
@@ -747,12 +750,21 @@ def main():
                                    "sweeps_per_solve": aggb["sweeps"] / nb,
                                    "note": "plain empc_solver_solve of one batch at a time: ~3/4 of its sweeps run on the few "
                                            "rollouts that need many iterations"}
+        # The side views and the CPU leg run AFTER the timed region: whatever goes wrong in one of them (a host without a compiler, a
+        # box short of memory, an assertion of the parity harness) is reported in its block; it must not take the measured line with it.
+        def guarded(key, fn):
+            try:
+                return fn()
+            except Exception as e:
+                out[key + "_error"] = "%s: %s" % (type(e).__name__, str(e)[:400])
+                return None
         if stream and world == 1 and not args.no_slots_sweep:
-            out["slots_sweep"] = slots_sweep(empc, problem, d, args, local_dev, B, iters_total / B / elapsed)
+            out["slots_sweep"] = guarded("slots_sweep", lambda: slots_sweep(empc, problem, d, args, local_dev, B, iters_total / B / elapsed))
         if world == 1 and not is_mpc and not args.no_secondary and args.config != "displacement":
-            out["secondary"] = secondary_displacement(empc, B, args.maxiter, local_dev)
+            out["secondary"] = guarded("secondary", lambda: secondary_displacement(empc, B, args.maxiter, local_dev))
         if not args.no_cpu_baseline and not is_mpc and world == 1:  # rank 0 at N = 1 only
-            out.update(cpu_baseline_and_parity(empc, solver, problem, d, x0s[:B], B, args.maxiter, out["unit"]))
+            leg = guarded("cpu_baseline", lambda: cpu_baseline_and_parity(empc, solver, problem, d, x0s[:B], B, args.maxiter, out["unit"]))
+            out.update(leg if leg is not None else {"cpu_baseline": None, "parity": None})
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
