@@ -21,7 +21,7 @@ import empc_loader  # noqa: E402
 empc = empc_loader.load()
 import numpy_restatement as nr  # noqa: E402
 import oracle_binding as ob  # noqa: E402
-from conftest import CONFIGS, contact_variant  # noqa: E402
+from conftest import CONFIGS, arm5_two_contact_variant, contact_variant, two_contact_variant  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden", "second_restatement")
 KEYS = ("xnext", "cost", "acc", "lam", "u_squash", "Fx", "Fu", "Lx", "Lu", "Lxx", "Lxu", "Luu")
@@ -38,7 +38,28 @@ CASES = {  # name: (config or contact variant, integrator, smoothing)
 }
 
 
+# Two ContactModel3D per stage (round 6; the CT_PAIR3 kernels are opt-in): fixtures of their own, in a directory the default GPU test
+# does not read -- tests/test_two_contacts_emulator.py (oracle + kernel bodies on the lane emulator) and tests/test_zz_gpu_two_contacts.py
+# use them.  `python tests/golden/make_second_restatement.py two_contacts` writes them.
+OUT2 = os.path.join(ROOT, "tests", "golden", "second_restatement_two_contacts")
+CASES2 = {
+    "eagle_catch_two_contacts": (dict(robot="arm3", gains=(3.0, 1.5), gains2=(2.0, 0.7), cone_on_second=True), "IntegratedActionModelEuler", 0.1),
+    "eagle_catch_two_contacts_rk4": (dict(robot="arm3", gains=(0.0, 0.0), gains2=(0.0, 0.0), cone_on_second=False), "IntegratedActionModelRK4", 0.1),
+    "arm5_two_contacts": (dict(robot="arm5", gains=(2.0, 1.0), gains2=(0.0, 3.0)), "IntegratedActionModelEuler", 0.07),
+}
+
+
+def build_two_contact_problem(meta, integrator, tmp=None):
+    tmp = tmp or pathlib.Path(tempfile.mkdtemp())
+    if meta["robot"] == "arm3":
+        return two_contact_variant(empc, tmp, "ContactModel3D", tuple(meta["gains"]), tuple(meta["gains2"]), integrator=integrator,
+                                   cone_on_second=meta["cone_on_second"])[1]
+    return arm5_two_contact_variant(empc, tmp, tuple(meta["gains"]), tuple(meta["gains2"]))[1]
+
+
 def build_problem(spec, integrator):
+    if isinstance(spec, dict):
+        return build_two_contact_problem(spec, integrator), dict(spec, two_contacts=True)
     if isinstance(spec, tuple):
         _, problem = contact_variant(empc, pathlib.Path(tempfile.mkdtemp()), spec[0], spec[1], integrator=integrator)
         return problem, dict(contact=spec[0], gains=list(spec[1]))
@@ -49,8 +70,9 @@ def build_problem(spec, integrator):
 
 
 def main():
-    os.makedirs(OUT, exist_ok=True)
-    for name, (spec, integrator, smooth) in CASES.items():
+    cases, out = (CASES2, OUT2) if "two_contacts" in sys.argv[1:] else (CASES, OUT)
+    os.makedirs(out, exist_ok=True)
+    for name, (spec, integrator, smooth) in cases.items():
         problem, meta = build_problem(spec, integrator)
         d = problem.desc
         prm = ob.default_params()
@@ -78,7 +100,7 @@ def main():
             us.append(u)
             for k in KEYS:
                 rec[k].append(np.atleast_1d(r[k]))
-        np.savez_compressed(os.path.join(OUT, name + ".npz"), knots=np.array(knots), xs=np.array(xs), us=np.array(us),
+        np.savez_compressed(os.path.join(out, name + ".npz"), knots=np.array(knots), xs=np.array(xs), us=np.array(us),
                             smooth=np.array(smooth), integrator=np.array(integrator), meta=np.array(repr(meta)),
                             **{k: np.array(v) for k, v in rec.items()})
         print(name, "knots", knots)

@@ -310,3 +310,69 @@ def test_pair_bodies_over_baked_tables_equal_the_runtime_family(empc, emu, emu_b
     else:
         _, problem = arm5_two_contact_variant(empc, tmp_path, (2.0, 1.0), (0.0, 3.0))
     families_equal(emu, emu_baked, problem)
+
+
+FIX2 = os.path.join(ROOT, "tests", "golden", "second_restatement_two_contacts")
+NAMES2 = sorted(f[:-4] for f in os.listdir(FIX2) if f.endswith(".npz"))
+
+
+def fixture_problem(empc, g, tmp_path):
+    import ast
+    from conftest import arm5_two_contact_variant as arm5
+    meta = ast.literal_eval(str(g["meta"]))
+    integrator = str(g["integrator"])
+    if meta["robot"] == "arm3":
+        return two_contact_variant(empc, tmp_path, "ContactModel3D", tuple(meta["gains"]), tuple(meta["gains2"]), integrator=integrator,
+                                   cone_on_second=meta["cone_on_second"])[1]
+    return arm5(empc, tmp_path, tuple(meta["gains"]), tuple(meta["gains2"]))[1]
+
+
+@pytest.mark.parametrize("name", NAMES2)
+def test_oracle_and_kernel_bodies_match_the_two_contact_fixtures(empc, emu, tmp_path, name):
+    """tests/golden/second_restatement_two_contacts/*.npz: inputs and NumPy-restatement outputs (data, generated by
+    tests/golden/make_second_restatement.py two_contacts) of one node per distinct cost set of the two-contact problems -- the C++
+    oracle at 1e-10, the linearize kernel bodies on the lane emulator at 1e-9 (1e-8 on RK4 nodes), as the single-contact fixtures
+    are held by tests/test_second_restatement.py and tests/test_gpu_second_restatement.py"""
+    g = np.load(os.path.join(FIX2, name + ".npz"))
+    problem = fixture_problem(empc, g, tmp_path)
+    d = problem.desc
+    prm = ob.default_params()
+    o = ob.OracleSolver(d, prm)
+    o.set_smooth(float(g["smooth"]))
+    for i, t in enumerate(g["knots"]):
+        term = int(t) == d.T
+        r = o.node_calc(int(t), g["xs"][i], None if term else g["us"][i])
+        for key in KEYS:
+            if term and key in ("Fu", "Lu", "Lxu", "Luu"):
+                continue
+            got = r[key][:6] if key == "lam" else r[key]
+            assert rel(np.ravel(got), np.ravel(g[key][i])) < 1e-10, ("oracle", name, int(t), key)
+    # the kernel bodies: the fixture's nodes planted into a trajectory, one linearize pass
+    e = C.c_void_p(emu.emu_create(C.byref(d), C.byref(prm), 1))
+    xs = np.tile(np.array(problem.x0), (d.T + 1, 1))
+    xs[:, 7:7 + 3] += 0.3  # (off the stretched arm: the nodes that are NOT compared must not be singular either)
+    us = np.full((d.T, d.nu), 4.0)
+    us[:, d.n_rotors:] = 0.0
+    for i, t in enumerate(g["knots"]):
+        xs[int(t)] = g["xs"][i]
+        if int(t) < d.T:
+            us[int(t)] = g["us"][i]
+    emu.emu_set_linearize_version(2)
+    emu.emu_set_warmstart(e, ob.P(np.ascontiguousarray(xs)), ob.P(np.ascontiguousarray(us)))
+    emu.emu_phase_setup(e, float(g["smooth"]), 0, 1e-9, 0)
+    tape = np.zeros((d.T + 1, emu.emu_rec(e)))
+    acc = np.zeros((d.T + 1, d.model.nv))
+    emu.emu_phase_linearize(e, ob.P(tape), ob.P(acc))
+    n, m = d.ndx, d.nu
+    nm = n + m
+    tol = 1e-8 if "rk4" in name else 1e-9
+    for i, t in enumerate(g["knots"]):
+        r_ = tape[int(t)]
+        A, HX, o2 = r_[:n * nm].reshape(n, nm), r_[n * nm:2 * n * nm].reshape(n, nm), 2 * n * nm
+        got = {"Fx": A[:, :n], "Fu": A[:, n:], "Lxx": HX[:, :n], "Lxu": HX[:, n:], "Luu": r_[o2:o2 + m * m].reshape(m, m),
+               "Lx": r_[o2 + m * m:o2 + m * m + n], "Lu": r_[o2 + m * m + n:o2 + m * m + n + m]}
+        for key in got:
+            if int(t) == d.T and key in ("Fx", "Fu", "Lxu", "Luu", "Lu"):
+                continue
+            assert rel(np.ravel(got[key]), np.ravel(g[key][i])) < tol, ("kernel bodies", name, int(t), key, rel(np.ravel(got[key]), np.ravel(g[key][i])))
+    emu.emu_destroy(e)

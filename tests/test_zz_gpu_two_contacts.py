@@ -73,3 +73,30 @@ def test_two_contact_solves_are_batch_independent(empc, tmp_path):
     for b in range(4):
         one.solve([], [], 30, x0s=x0s[b:b + 1])
         assert np.array_equal(one.xs_batch[0], s.xs_batch[b]) and one.iter_batch[0] == s.iter_batch[b]
+
+
+def test_linearize_kernel_matches_the_two_contact_fixtures(empc, tmp_path):
+    """tests/golden/second_restatement_two_contacts/*.npz (NumPy restatement: dense stacked KKT, complex-step derivatives; data): every
+    record block of the six-row linearize kernel at 1e-9 (1e-8 on RK4 nodes) -- no oracle involved"""
+    from test_two_contacts_emulator import FIX2, NAMES2, fixture_problem, rel
+    for name in NAMES2:
+        g = np.load(os.path.join(FIX2, name + ".npz"))
+        problem = fixture_problem(empc, g, tmp_path)
+        d = problem.desc
+        s = empc.SolverSbFDDP(problem, batch=1)
+        xs = np.tile(np.array(problem.x0), (d.T + 1, 1))
+        xs[:, 7:7 + 3] += 0.3  # (off the stretched arm)
+        us = np.full((d.T, d.nu), 4.0)
+        us[:, d.n_rotors:] = 0.0
+        for i, t in enumerate(g["knots"]):
+            xs[int(t)] = g["xs"][i]
+            if int(t) < d.T:
+                us[int(t)] = g["us"][i]
+        tape = s.linearize(xs[None], us[None], smooth=float(g["smooth"]), is_feasible=False, x0s=np.array(problem.x0)[None])
+        tol = 1e-9 if "rk4" not in name else 1e-8
+        for i, t in enumerate(g["knots"]):
+            b = s.tape_blocks(tape[0, int(t)])
+            for key in ("Fx", "Fu", "Lx", "Lu", "Lxx", "Lxu", "Luu"):
+                if int(t) == d.T and key in ("Fu", "Lu", "Lxu", "Luu"):
+                    continue
+                assert rel(np.ravel(b[key]), np.ravel(g[key][i])) < tol, (name, int(t), key)
