@@ -424,7 +424,11 @@ def teacher_forced(backend_factory, desc, prm, x0s, paths, maxiter=100, chunk=10
             if blow > 1.0:
                 rep["blown_up_iterates"] = rep.get("blown_up_iterates", 0) + 1
             upd("cost", abs(g.cost - p["cost"]) / scale / blow)
-            assert abs(g.cost - p["cost"]) <= TOL_COST * blow * scale, (where, g.cost, p["cost"])
+            # (the yardstick of every other quantity, for the iterate's own cost too: what the oracle's FMA build and its evaluations
+            #  of the iterate moved by one unit in the last place differ by -- on a node next to a rank-deficient pair of constraints,
+            #  cond 2e6, that is 1e-9 of the cost: round-6 soak of the two-contact class, seed 93)
+            ncost = max(abs(q["cost"] - p["cost"]) for q in pv)
+            assert abs(g.cost - p["cost"]) <= max(TOL_COST * blow * scale, NOISE_FACTOR * ncost), (where, g.cost, p["cost"], ncost)
             assert bool(g.is_feasible) == p["is_feasible"], where
             upd("gapnorm", abs(g.gapnorm - p["gapnorm"]) / (1.0 + abs(p["gapnorm"])))
             ngap = max(abs(q["gapnorm"] - p["gapnorm"]) for q in pv)
