@@ -1,4 +1,4 @@
-"""The C++ mirror classes (eagle-mpc_amd/host/eagle_mpc.hpp) end to end through the example programs.
+"""The C++ mirror classes (eagle-mpc_amd/host/eagle_mpc.hpp) and the C ABI itself end to end through the example programs.
 
 CPU: the examples build against libempc.so and fail loudly without a GPU (no CPU fallback anywhere).
 GPU: they reproduce the oracle's solution of the displacement problem and run the closed loop.
@@ -30,6 +30,21 @@ def test_examples_build_and_refuse_to_run_without_gpu(built, empc):
         r = run(p)
         assert r.returncode == 1
         assert "no HIP device available" in r.stderr and "no CPU fallback" in r.stderr
+
+
+def test_plain_c_example_of_the_c_abi(built, empc):
+    """examples/c/trajectory.c: the boundary used from C99 (gcc -std=c99 -pedantic: include/empc.h is a C header, not only a C++
+    one).  The host side -- YAML factory, shooting problem, the solver query -- needs no GPU; the solve does."""
+    exe = os.path.join(EX, "c", "trajectory")
+    r = subprocess.run([exe, ROOT, "hexacopter370_flying_arm_3/trajectories/eagle_catch.yaml", "32"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert "nx 19 ndx 18 nu 9" in r.stdout and "contact dynamics: yes" in r.stdout and "stage grasp" in r.stdout
+    assert "T = 99 knots" in r.stdout and "a kernel instantiation exists" in r.stdout
+    if empc.device_count() > 0:
+        m = re.search(r"iterations (\d+) cost ([0-9.]+)", r.stdout)
+        assert m and int(m.group(1)) == 64 and "kernels: baked hexacopter370_flying_arm_3, ContactModel3D" in r.stdout
+    else:
+        assert "no HIP device" in r.stdout
 
 
 @pytest.mark.gpu
