@@ -376,3 +376,41 @@ def test_oracle_and_kernel_bodies_match_the_two_contact_fixtures(empc, emu, tmp_
                 continue
             assert rel(np.ravel(got[key]), np.ravel(g[key][i])) < tol, ("kernel bodies", name, int(t), key, rel(np.ravel(got[key]), np.ravel(g[key][i])))
     emu.emu_destroy(e)
+
+
+def test_third_algorithm_rollout_and_condition_number(empc, problems, tmp_path):
+    """the two other arbiters of tests/stepwise.py: the NumPy restatement's forward pass (gap-aware on an infeasible iterate, plain on a
+    feasible one) lands on the oracle's trial costs to 1e-11 on well-conditioned iterates, with the oracle's gains; and
+    constraint_condition() tells a bent arm (cond ~ 50) from a nearly stretched one (1e8) and a knot without contacts (1)"""
+    import stepwise as sw
+    _, problem = problems["displacement"]
+    d = problem.desc
+    prm = ob.default_params()
+    x0s = empc.perturbed_x0s(problem.x0, 1, nq=d.model.nq, amplitude=0.002, seed=5)
+    iterates = sw.oracle_paths(d, prm, x0s, maxiter=12)[0]["iterates"]
+    checked = 0
+    for i in (3, 8):
+        it = iterates[i]
+        ddp = it["phase"] == sw.T.PHASE_DDP
+        o = ob.OracleSolver(d, prm)
+        o.set_x0(x0s[0])
+        p = o.iter_probe(it["xs"], it["us"], it["is_feasible"], it["was_feasible"], ddp, it["xreg"], it["smooth"])
+        K, k, _ = o.last_gains()
+        for a_ in (1, 3):
+            if not p["ok"][a_]:
+                continue
+            c3 = sw.third_algorithm_trial_cost(d, prm, it, x0s[0], K, k, 2.0 ** -a_, ddp, bool(p["is_feasible"]))
+            assert abs(c3 - p["cost_try"][a_]) <= 1e-11 * (1 + abs(p["cost_try"][a_])), (i, a_, c3, p["cost_try"][a_])
+            checked += 1
+    assert checked >= 3
+    _, pair = two_contact_variant(empc, tmp_path, "ContactModel3D", link2="flying_arm_3__link_1")
+    dp = pair.desc
+    conds = {}
+    for tag, arm in (("bent", (0.4, -0.7, 0.5)), ("nearly stretched", (1e-4, -2e-4, 1.5e-4))):
+        x = np.zeros(dp.nx)
+        x[6] = 1.0
+        x[7:10] = arm
+        it = dict(smooth=0.1, xs=np.tile(x, (dp.T + 1, 1)), us=np.zeros((dp.T, dp.nu)))
+        conds[tag] = (sw.constraint_condition(dp, prm, it, 45), sw.constraint_condition(dp, prm, it, 10))
+    print(conds)
+    assert conds["bent"][0] < 1e3 < 1e7 < conds["nearly stretched"][0] and conds["bent"][1] == 1.0
