@@ -263,17 +263,22 @@ def oracle_paths(desc, prm, x0s, maxiter=100, warm=None):
 _THIRD = {}
 
 
+def _third(desc, prm, smooth):
+    """the NumPy restatement's view of a problem at one smoothing value, kept for the last (problem, smoothing) asked for; the cache
+    holds the descriptor itself, so that a later descriptor at the same address is never mistaken for it"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle")) if os.path.join(ROOT, "oracle") not in sys.path else None
+    import numpy_restatement as nr
+    if _THIRD.get("desc") is not desc or _THIRD.get("smooth") != smooth or _THIRD.get("prm") is not prm:
+        _THIRD.clear()
+        _THIRD.update(desc=desc, prm=prm, smooth=smooth, P=nr.Problem(desc, prm), sets=nr.cost_sets_of(desc, prm, smooth))
+    return nr, _THIRD["P"], _THIRD["sets"]
+
+
 def third_algorithm_distance(desc, prm, it, t, key, ref_block):
     """distance of the NumPy second restatement (oracle/numpy_restatement.py) from the oracle on block `key` of knot t of iterate
     `it` -- the arbiter of tape entries on ill-conditioned nodes (see its call site)"""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import numpy_restatement as nr
     smooth = float(it["smooth"])
-    ck = (id(desc), smooth)
-    if ck not in _THIRD:
-        _THIRD.clear()
-        _THIRD[ck] = (nr.Problem(desc, prm), nr.cost_sets_of(desc, prm, smooth))
-    P, sets = _THIRD[ck]
+    nr, P, sets = _third(desc, prm, smooth)
     node = nr.node(P, sets[desc.knot_set[t]], np.asarray(it["xs"][t]), None if t == desc.T else np.asarray(it["us"][t]), smooth)
     return rel(np.ravel(np.asarray(node[key], dtype=float)), np.ravel(ref_block))
 
@@ -281,14 +286,8 @@ def third_algorithm_distance(desc, prm, it, t, key, ref_block):
 def constraint_condition(desc, prm, it, t):
     """condition number of the constraint matrix Jc M^-1 Jc^T of knot t of iterate `it` (1 for a knot without contacts): what the
     Schur-complement form of the contact dynamics -- the reference's, the oracle's and the kernels' -- amplifies rounding by"""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import numpy_restatement as nr
     smooth = float(it["smooth"])
-    ck = (id(desc), smooth)
-    if ck not in _THIRD:
-        _THIRD.clear()
-        _THIRD[ck] = (nr.Problem(desc, prm), nr.cost_sets_of(desc, prm, smooth))
-    P, sets = _THIRD[ck]
+    nr, P, sets = _third(desc, prm, smooth)
     contacts = sets[desc.knot_set[t]]["contacts"]
     if not contacts or not desc.has_contact:
         return 1.0
@@ -322,14 +321,8 @@ def third_algorithm_trial_cost(desc, prm, it, x0, K, k, alpha, ddp, feasible):
     SolverFDDP::forwardPass / SolverSbFDDP::forwardPassDDP as oracle/solver.hpp forward_pass states them (gap-aware unless the
     iterate is feasible or alpha = 1; the clean-up pass ignores gaps), on dynamics and costs evaluated by a third algorithm --
     the arbiter of trial costs on rollouts through ill-conditioned nodes.  None when the rollout does not survive."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import numpy_restatement as nr
     smooth = float(it["smooth"])
-    ck = (id(desc), smooth)
-    if ck not in _THIRD:
-        _THIRD.clear()
-        _THIRD[ck] = (nr.Problem(desc, prm), nr.cost_sets_of(desc, prm, smooth))
-    P, sets = _THIRD[ck]
+    nr, P, sets = _third(desc, prm, smooth)
     nq, Tn = P.nq, desc.T
     xs, us = np.asarray(it["xs"]), np.asarray(it["us"])
     box = prm.solver_type != T.SOLVER_SBFDDP
